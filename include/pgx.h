@@ -1,0 +1,187 @@
+/*
+ * pgx.h -- C ABI of the MI355X-native find_mems path (libpgx.so).
+ *
+ * The reference (parsaeskandar/pangenome-index @ 2025-10-24) has no FFI layer: its boundary is the
+ * `find_mems` process contract plus C++ member functions compiled into each CLI.  This header is
+ * the flat boundary a maintainer would bind instead; every entry point names the reference code
+ * it replaces (paths relative to /root/reference).  Plain pointers and sizes only; no exceptions
+ * cross this boundary; every function returns a pgx_status and pgx_last_error() holds the text.
+ *
+ * There is NO CPU fallback behind these entry points: anything that computes (rank / extend /
+ * find_mems / tag queries) runs as HIP kernels on a gfx950 device and fails with
+ * PGX_ERR_NO_DEVICE when none is usable.
+ */
+#ifndef PGX_H
+#define PGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGX_ABI_VERSION 1
+
+typedef enum {
+    PGX_OK = 0,
+    PGX_ERR_IO = 1,          /* cannot open / read (find_mems.cpp:30,91 exit(EXIT_FAILURE)) */
+    PGX_ERR_FORMAT = 2,      /* sdsl::simple_sds::InvalidData in the reference (r-index.cpp:412-419) */
+    PGX_ERR_UNSUPPORTED = 3, /* valid file, but a shape this build does not handle */
+    PGX_ERR_NO_DEVICE = 4,   /* no usable HIP device / kernel image */
+    PGX_ERR_HIP = 5,         /* a HIP runtime call failed */
+    PGX_ERR_ARG = 6,
+    PGX_ERR_NOMEM = 7
+} pgx_status;
+
+/* mode: which extension tables are loaded into the device image (same kernels either way) */
+#define PGX_MODE_COMPAT 0u /* bit-exact with the reference, quirks included (default)          */
+#define PGX_MODE_STRICT 1u /* textbook FMD over the true ranks; equals COMPAT on sigma=6 indexes */
+
+/* tag file formats (SURVEY section 5 "Tag formats") */
+#define PGX_TAGS_AUTO 0u
+#define PGX_TAGS_BYTECODE 1u /* TagArray::load_compressed_tags      src/tag_arrays.cpp:739-763 */
+#define PGX_TAGS_COMPACT 2u  /* TagArray::load_compressed_tags_sdsl src/tag_arrays.cpp:766-776 */
+
+/* struct MEM, include/pangenome_index/algorithm.hpp:644-651 (32 bytes, same field order) */
+typedef struct {
+    uint64_t start;
+    uint64_t end;
+    uint64_t bwt_start;
+    int64_t size;
+} pgx_mem;
+
+/* FastLocate::bi_interval, include/pangenome_index/r-index.hpp:118-130 */
+typedef struct {
+    uint64_t forward;
+    uint64_t reverse;
+    int64_t size;
+} pgx_biint;
+
+typedef struct pgx_index pgx_index; /* FastLocate + TagArray, host image + per-device images */
+typedef struct pgx_batch pgx_batch; /* one device-resident read batch and its results */
+
+typedef struct {
+    uint64_t bwt_size;      /* FastLocate::bwt_size(), r-index.hpp:568 */
+    uint64_t sigma;         /* C.size() */
+    uint64_t n_sequences;   /* FastLocate::tot_strings(), r-index.hpp:484 */
+    uint64_t n_ref_blocks;  /* blocks in the file (10 runs each, r-index.hpp:312) */
+    uint64_t n_runs;        /* logical BWT runs held by the image */
+    uint64_t n_dev_blocks;  /* 64-byte device rank blocks */
+    uint64_t dir_entries;   /* directory entries (u32) */
+    uint32_t dir_shift;
+    uint32_t is_encoded;    /* FastLocate::is_encoded(), r-index.hpp:409 */
+    uint32_t has_N;         /* encoded_has_N */
+    uint32_t mode;
+    uint32_t has_tags;
+    uint32_t tag_format;
+    uint64_t n_tag_runs;    /* ones in bwt_intervals */
+    uint64_t tag_dir_entries;
+    uint32_t tag_dir_shift;
+    uint32_t image_in_lds;  /* 1 when the rank image fits the per-workgroup LDS budget */
+    uint64_t image_bytes;   /* device bytes of the rank image (blocks + directory + starts) */
+    uint64_t tag_image_bytes;
+    double ref_block_mean_bytes; /* mean encoded block size of the reference layout (B_blk) */
+} pgx_index_info;
+
+const char *pgx_last_error(void);
+int pgx_abi_version(void);
+
+/* ---- index lifetime ---------------------------------------------------------------------- */
+/* Replaces FastLocate::load_encoded (src/r-index.cpp:406-459, legacy fall-back :378-404) and
+ * TagArray::load_compressed_tags{,_sdsl} (src/tag_arrays.cpp:739-776).  tags_path may be NULL.
+ * Host-only: parses the files and builds the flat device image in host memory. */
+pgx_status pgx_index_open(const char *ri_path, const char *tags_path, uint32_t tags_format,
+                          uint32_t mode, pgx_index **out);
+pgx_status pgx_index_info_get(const pgx_index *h, pgx_index_info *info);
+void pgx_index_close(pgx_index *h);
+
+/* Copy the image to a HIP device (idempotent per device). */
+pgx_status pgx_index_to_device(pgx_index *h, int device);
+
+/* Host views of the flat image (for tests that verify the layout without a GPU).  `which`:
+ * 0 rank blocks (64 B each), 1 directory (u32), 2 block starts (u64), 3 tag run starts (u64),
+ * 4 tag values (u64), 5 tag directory (u32), 6 constants table (see pgx_image.h). */
+pgx_status pgx_index_image_view(const pgx_index *h, int which, const void **ptr, uint64_t *bytes);
+
+/* ---- index construction (build side; CPU, run once) --------------------------------------- */
+/* Replaces build_rindex (src/build_rindex.cpp:13-21 -> FastLocate(std::string) src/r-index.cpp:778
+ * + serialize_encoded :297-376).  encoded=0 writes the legacy layout (serialize, :266-294). */
+pgx_status pgx_build_rindex(const char *rlbwt_path, const char *out_ri_path, int encoded);
+/* BWT of a newline-terminated sequence collection (what grlBWT produces for the reference):
+ * writes the grlBWT .rl_bwt layout read by bwt_buff_reader. */
+pgx_status pgx_build_rlbwt(const char *text_path, const char *out_rlbwt_path);
+/* Write a compact sdsl tag file (format 3, src/tag_arrays.cpp:940-974 + :622-654) from parallel
+ * arrays of run values (already `offset | rev<<10 | node<<11`) and run lengths. */
+pgx_status pgx_write_compact_tags(const char *out_path, const uint64_t *values,
+                                  const uint64_t *lengths, uint64_t n_runs);
+
+/* ---- primitives (tests; mirror the public FastLocate / TagArray query API) ----------------- */
+/* FastLocate::rank_at_cached_encoded (src/r-index.cpp:619-641): out[i*6 .. i*6+sigma) per position;
+ * entries >= sigma are zero.  true_codes!=0 returns the six true code ranks instead. */
+pgx_status pgx_rank_batch(pgx_index *h, int device, const uint64_t *pos, uint64_t n,
+                          int true_codes, uint64_t *out);
+/* FastLocate::backward_extend_encoded / forward_extend_encoded (src/r-index.cpp:713-764) */
+pgx_status pgx_extend_batch(pgx_index *h, int device, const pgx_biint *in, const uint8_t *sym,
+                            const uint8_t *forward, uint64_t n, pgx_biint *out);
+/* TagArray::query_compressed{,_compact} (src/tag_arrays.cpp:780-890) without the printing.
+ * Two-call pattern: positions==NULL returns counts only.  pos_offsets has n+1 entries. */
+pgx_status pgx_tag_query_batch(pgx_index *h, int device, const uint64_t *start, const uint64_t *end,
+                               uint64_t n, uint64_t *run_nums, uint64_t *pos_offsets,
+                               uint64_t *positions, uint64_t positions_cap, uint64_t *n_overflow);
+
+/* ---- the hot path: find_mems over a batch of reads ----------------------------------------- */
+#define PGX_RUN_TAGS 1u    /* also run the tag queries of find_mems.cpp:129 */
+#define PGX_RUN_TIMING 2u  /* record HIP events around each kernel (pgx_batch_timing)           */
+
+typedef struct {
+    uint64_t n_reads;
+    uint64_t n_mems;
+    const uint64_t *mem_offsets;    /* n_reads+1; MEMs of read i = mems[mem_offsets[i] .. [i+1])   */
+    const pgx_mem *mems;            /* discovery order (find_all_mems, algorithm.hpp:739-757)     */
+    const uint64_t *tag_run_counts; /* per MEM: number_of_runs (tag_arrays.cpp:860); NULL w/o tags */
+    const uint64_t *pos_offsets;    /* n_mems+1; NULL w/o tags                                    */
+    const uint64_t *positions;      /* sorted unique graph positions per MEM (tag_arrays.cpp:882) */
+    uint64_t n_positions;
+    uint64_t n_extensions;          /* backward+forward extensions performed (counter)           */
+    uint64_t n_tag_overflow;        /* tag queries that read past the stored runs (ref: UB)      */
+} pgx_result;
+
+typedef struct {
+    float ms_find_mems;   /* the dominant kernel (pgx_find_mems_kernel) */
+    float ms_compact;     /* MEM compaction + scans */
+    float ms_tag_locate;
+    float ms_tag_gather;
+    float ms_tag_sort;
+    float ms_total;       /* first launch -> last launch, device time */
+    uint32_t find_mems_launches;
+} pgx_timing;
+
+/* Upload reads (read i = reads[offsets[i] .. offsets[i+1]); the `std::getline` lines of
+ * find_mems.cpp:96-98, empty lines already skipped by the caller) to `device`. */
+pgx_status pgx_batch_create(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets,
+                            uint64_t n_reads, pgx_batch **out);
+/* Run find_all_mems (+ tag queries) for every read of the batch; results stay on the device.
+ * `stream` is a hipStream_t (NULL = default stream).  Asynchronous except for the few scalar
+ * read-backs that size intermediate buffers. */
+pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min_occ, uint32_t flags, void *stream);
+/* Copy the results of the last run to host memory owned by the batch (valid until next run/free) */
+pgx_status pgx_batch_result(pgx_batch *b, pgx_result *out);
+/* Device-side totals of the last run without downloading arrays */
+pgx_status pgx_batch_counts(pgx_batch *b, uint64_t *n_mems, uint64_t *n_positions, uint64_t *n_extensions);
+pgx_status pgx_batch_timing(pgx_batch *b, pgx_timing *out);
+void pgx_batch_free(pgx_batch *b);
+
+/* Convenience: create + run + result in one call (what the find_mems CLI uses). */
+pgx_status pgx_find_mems_batch(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets,
+                               uint64_t n_reads, uint64_t min_len, uint64_t min_occ, uint32_t flags,
+                               pgx_batch **batch_out, pgx_result *result_out);
+
+/* device helpers */
+pgx_status pgx_device_count(int *n);
+pgx_status pgx_device_name(int device, char *buf, size_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,305 @@
+// pgx_build.cpp -- build-side helpers (CPU, run once): text -> RLBWT, RLBWT -> .ri, compact tag writer.
+//
+// These exist because no encoded .ri and no sdsl-compact tag file ships with the reference
+// (SURVEY section 0 "Fixture reality check"): the find_mems path needs both as inputs.
+//   pgx_build_rlbwt        what grlBWT produces for the reference (bwt_buff_reader layout)
+//   pgx_build_rindex       FastLocate(std::string) src/r-index.cpp:778-965 (block building) +
+//                          serialize_encoded :297-376 / serialize :266-294
+//   pgx_write_compact_tags append_compact_run_streamed + merge_compressed_files_sdsl,
+//                          src/tag_arrays.cpp:940-974, 622-654
+#include <algorithm>
+#include <cstdio>
+#include <memory>
+
+#include "pgx_host.hpp"
+
+using namespace pgx;
+
+#define PGX_GUARD_BEGIN try {
+#define PGX_GUARD_END                                                                               \
+    }                                                                                               \
+    catch (const pgx::Error &e) { pgx::set_last_error(e.what()); return e.code; }                   \
+    catch (const std::bad_alloc &) { pgx::set_last_error("out of host memory"); return PGX_ERR_NOMEM; } \
+    catch (const std::exception &e) { pgx::set_last_error(e.what()); return PGX_ERR_FORMAT; }
+
+template <class T> static void put(std::vector<uint8_t> &out, T v) {
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(&v);
+    out.insert(out.end(), p, p + sizeof(T));
+}
+static inline unsigned hi_bit(uint64_t x) { return x ? 63u - (unsigned)__builtin_clzll(x) : 0u; }
+
+// ------------------------------------------------------------------------------------------
+// SA-IS (Nong, Zhang, Chan 2009) over an int32 string whose last symbol is a unique minimum.
+namespace {
+struct Sais {
+    static inline bool tget(const std::vector<uint8_t> &t, int64_t i) { return (t[(size_t)i >> 3] >> (i & 7)) & 1; }
+    static inline void tset(std::vector<uint8_t> &t, int64_t i, bool b) {
+        if (b) t[(size_t)i >> 3] |= (uint8_t)(1u << (i & 7));
+        else t[(size_t)i >> 3] &= (uint8_t)~(1u << (i & 7));
+    }
+    static inline bool is_lms(const std::vector<uint8_t> &t, int64_t i) { return i > 0 && tget(t, i) && !tget(t, i - 1); }
+
+    static void buckets(const int32_t *s, int32_t n, int32_t K, std::vector<int32_t> &bkt, bool end) {
+        std::fill(bkt.begin(), bkt.end(), 0);
+        for (int32_t i = 0; i < n; i++) bkt[(size_t)s[i]]++;
+        int32_t sum = 0;
+        for (int32_t c = 0; c < K; c++) {
+            sum += bkt[(size_t)c];
+            bkt[(size_t)c] = end ? sum : sum - bkt[(size_t)c];
+        }
+    }
+    static void induce(const std::vector<uint8_t> &t, int32_t *SA, const int32_t *s, std::vector<int32_t> &bkt, int32_t n, int32_t K) {
+        buckets(s, n, K, bkt, false);
+        for (int32_t i = 0; i < n; i++) {
+            int32_t j = SA[i] - 1;
+            if (SA[i] > 0 && !tget(t, j)) SA[bkt[(size_t)s[j]]++] = j;
+        }
+        buckets(s, n, K, bkt, true);
+        for (int32_t i = n - 1; i >= 0; i--) {
+            int32_t j = SA[i] - 1;
+            if (SA[i] > 0 && tget(t, j)) SA[--bkt[(size_t)s[j]]] = j;
+        }
+    }
+    static void run(const int32_t *s, int32_t *SA, int32_t n, int32_t K) {
+        if (n == 1) { SA[0] = 0; return; }
+        std::vector<uint8_t> t((size_t)n / 8 + 1, 0);
+        tset(t, n - 1, true);
+        for (int32_t i = n - 2; i >= 0; i--) tset(t, i, s[i] < s[i + 1] || (s[i] == s[i + 1] && tget(t, i + 1)));
+        std::vector<int32_t> bkt((size_t)K);
+        buckets(s, n, K, bkt, true);
+        for (int32_t i = 0; i < n; i++) SA[i] = -1;
+        for (int32_t i = 1; i < n; i++)
+            if (is_lms(t, i)) SA[--bkt[(size_t)s[i]]] = i;
+        induce(t, SA, s, bkt, n, K);
+        int32_t n1 = 0;
+        for (int32_t i = 0; i < n; i++)
+            if (is_lms(t, SA[i])) SA[n1++] = SA[i];
+        for (int32_t i = n1; i < n; i++) SA[i] = -1;
+        int32_t name = 0, prev = -1;
+        for (int32_t i = 0; i < n1; i++) {
+            int32_t pos = SA[i];
+            bool diff = false;
+            for (int32_t d = 0; d < n; d++) {
+                if (prev == -1 || s[pos + d] != s[prev + d] || tget(t, pos + d) != tget(t, prev + d)) { diff = true; break; }
+                else if (d > 0 && (is_lms(t, pos + d) || is_lms(t, prev + d))) break;
+            }
+            if (diff) { name++; prev = pos; }
+            SA[n1 + pos / 2] = name - 1;
+        }
+        for (int32_t i = n - 1, j = n - 1; i >= n1; i--)
+            if (SA[i] >= 0) SA[j--] = SA[i];
+        int32_t *SA1 = SA, *s1 = SA + n - n1;
+        if (name < n1) run(s1, SA1, n1, name);
+        else for (int32_t i = 0; i < n1; i++) SA1[s1[i]] = i;
+        buckets(s, n, K, bkt, true);
+        for (int32_t i = 1, j = 0; i < n; i++)
+            if (is_lms(t, i)) s1[j++] = i;
+        for (int32_t i = 0; i < n1; i++) SA1[i] = s1[SA1[i]];
+        for (int32_t i = n1; i < n; i++) SA[i] = -1;
+        for (int32_t i = n1 - 1; i >= 0; i--) {
+            int32_t j = SA[i];
+            SA[i] = -1;
+            SA[--bkt[(size_t)s[j]]] = j;
+        }
+        induce(t, SA, s, bkt, n, K);
+    }
+};
+} // namespace
+
+// BWT of the collection S_0 \n S_1 \n ... with endmarkers ordered by sequence number (the
+// convention of the reference's fixtures and of tests/test_rindex.cpp:35-60: rotations of the text
+// with distinct increasing terminators).  Output: grlBWT run file (u64 bytes/symbol = 1,
+// u64 bytes/length, then (symbol, length) records).
+extern "C" pgx_status pgx_build_rlbwt(const char *text_path, const char *out_rlbwt_path) {
+    PGX_GUARD_BEGIN
+    if (!text_path || !out_rlbwt_path) throw Error(PGX_ERR_ARG, "pgx_build_rlbwt: null argument");
+    std::vector<uint8_t> text = read_whole_file(text_path);
+    if (!text.empty() && text.back() != '\n') text.push_back('\n');
+    const uint64_t n = text.size();
+    if (n + 1 >= (1ull << 31)) throw Error(PGX_ERR_UNSUPPORTED, "text longer than 2^31 - 2 symbols");
+    uint64_t m = 0;
+    for (uint8_t c : text) m += (c == '\n');
+    // alphabet: 0 = extra terminator, 1..m = endmarkers by sequence, then present bytes by value
+    int32_t rank_of[256];
+    bool present[256] = {false};
+    for (uint8_t c : text) present[c] = true;
+    int32_t K = (int32_t)m + 1;
+    for (int c = 0; c < 256; c++)
+        if (present[c] && c != '\n') rank_of[c] = K++;
+    std::vector<int32_t> s(n + 1), SA(n + 1);
+    int32_t seq = 0;
+    for (uint64_t i = 0; i < n; i++) s[i] = text[i] == '\n' ? ++seq : rank_of[text[i]];
+    s[n] = 0;
+    Sais::run(s.data(), SA.data(), (int32_t)(n + 1), K);
+    s.clear();
+    s.shrink_to_fit();
+    std::vector<std::pair<uint8_t, uint64_t>> runs;
+    uint64_t max_len = 1;
+    for (uint64_t i = 1; i <= n; i++) { // SA[0] is the extra terminator
+        uint64_t p = (uint64_t)SA[i];
+        uint8_t c = p ? text[p - 1] : text[n - 1];
+        if (!runs.empty() && runs.back().first == c) { runs.back().second++; max_len = std::max(max_len, runs.back().second); }
+        else runs.emplace_back(c, 1);
+    }
+    uint64_t bl = 1;
+    while (bl < 8 && (max_len >> (8 * bl))) bl++;
+    std::vector<uint8_t> out;
+    put<uint64_t>(out, 1);
+    put<uint64_t>(out, bl);
+    for (auto &r : runs) {
+        out.push_back(r.first);
+        for (uint64_t b = 0; b < bl; b++) out.push_back((uint8_t)(r.second >> (8 * b)));
+    }
+    write_whole_file(out_rlbwt_path, out);
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+// ------------------------------------------------------------------------------------------
+static std::vector<std::pair<uint8_t, uint64_t>> read_rlbwt(const std::string &path) {
+    std::vector<uint8_t> f = read_whole_file(path);
+    ByteReader r(f.data(), f.size());
+    uint64_t bs = r.get<uint64_t>("rl_bwt header"), bl = r.get<uint64_t>("rl_bwt header");
+    if (bs == 0 || bs > 8 || bl == 0 || bl > 8) throw Error(PGX_ERR_FORMAT, "rl_bwt: bad record widths");
+    if ((f.size() - 16) % (bs + bl)) throw Error(PGX_ERR_FORMAT, "rl_bwt: size is not a whole number of records");
+    std::vector<std::pair<uint8_t, uint64_t>> runs;
+    while (r.o < r.n) {
+        uint64_t sym = 0, len = 0;
+        std::memcpy(&sym, r.p + r.o, bs);
+        std::memcpy(&len, r.p + r.o + bs, bl);
+        r.o += bs + bl;
+        if (sym > 255) throw Error(PGX_ERR_UNSUPPORTED, "rl_bwt: symbol > 255");
+        runs.emplace_back((uint8_t)sym, len);
+    }
+    return runs;
+}
+
+extern "C" pgx_status pgx_build_rindex(const char *rlbwt_path, const char *out_ri_path, int encoded) {
+    PGX_GUARD_BEGIN
+    if (!rlbwt_path || !out_ri_path) throw Error(PGX_ERR_ARG, "pgx_build_rindex: null argument");
+    auto file_runs = read_rlbwt(rlbwt_path);
+    // calculate_C, r-index.hpp:440-482: sym_map = rank among present byte values; C = exclusive sums
+    uint64_t freq[256] = {0}, n = 0;
+    for (auto &r : file_runs) { freq[r.first] += r.second; n += r.second; }
+    uint8_t sym_map[256] = {0};
+    std::vector<uint64_t> C;
+    {
+        uint64_t acc = 0;
+        uint8_t k = 0;
+        for (int c = 0; c < 256; c++)
+            if (freq[c]) { sym_map[c] = k++; C.push_back(acc); acc += freq[c]; }
+    }
+    const uint64_t sigma = C.size();
+    for (int c = 0; c < 256; c++)
+        if (freq[c] && code_of_byte((uint8_t)c) < 0) throw Error(PGX_ERR_UNSUPPORTED, "BWT symbol outside {\\n,A,C,G,N,T}");
+    if (!freq[(uint8_t)'\n']) throw Error(PGX_ERR_UNSUPPORTED, "BWT without endmarkers");
+    // logical runs: every endmarker is its own run (src/r-index.cpp:840-848), blocks of 10 (:312)
+    struct Blk { std::vector<uint64_t> cum; std::vector<std::pair<uint8_t, uint64_t>> runs; uint64_t start; };
+    std::vector<Blk> blocks;
+    std::vector<uint64_t> cum(sigma, 0);
+    uint64_t pos = 0, total_runs = 0;
+    auto push_run = [&](uint8_t sym, uint64_t len) {
+        if (blocks.empty() || blocks.back().runs.size() == 10) blocks.push_back(Blk{cum, {}, pos});
+        blocks.back().runs.emplace_back(sym, len);
+        cum[sym_map[sym]] += len;
+        pos += len;
+        total_runs++;
+    };
+    for (auto &r : file_runs) {
+        if (r.second == 0) continue;
+        if (r.first == '\n') for (uint64_t i = 0; i < r.second; i++) push_run('\n', 1);
+        else push_run(r.first, r.second);
+    }
+    const uint64_t n_file_blocks = total_runs / 10 + 1; // blocks.resize((total_runs / block_size) + 1), :802
+    std::vector<uint8_t> out;
+    put<uint32_t>(out, 0x6B3741D8u);
+    put<uint32_t>(out, 1);
+    put<uint64_t>(out, 1);                    // max_length (SA samples are not built here yet)
+    put<uint64_t>(out, encoded ? 1ull : 0ull); // flags
+    IntVector empty_iv;                        // samples
+    empty_iv.write(out, true);
+    SdVector empty_sd;                         // last
+    empty_sd.write(out);
+    empty_iv.write(out, true);                 // last_to_run
+    {
+        std::vector<uint64_t> sm(256);
+        for (int c = 0; c < 256; c++) sm[c] = sym_map[c];
+        IntVector::pack(sm, 8).write(out, false);
+        IntVector::pack(C, 64).write(out, false);
+    }
+    SdVector bsp;
+    bsp.size = n;
+    for (auto &b : blocks) bsp.ones.push_back(b.start);
+    bsp.write(out);
+    put<uint64_t>(out, n);
+    if (encoded) { // serialize_encoded, src/r-index.cpp:312-372
+        put<uint64_t>(out, 10);
+        bool hasN = freq[(uint8_t)'N'] != 0;
+        put<uint8_t>(out, hasN ? 1 : 0);
+        std::vector<uint8_t> stream;
+        std::vector<uint64_t> offs;
+        for (uint64_t b = 0; b < n_file_blocks; b++) {
+            offs.push_back(stream.size());
+            if (b < blocks.size()) {
+                for (uint64_t i = 0; i < sigma; i++) bytecode_write(stream, blocks[b].cum[i]);
+                for (auto &ru : blocks[b].runs) {
+                    uint64_t prefix = std::min<uint64_t>(ru.second - 1, 31);
+                    stream.push_back((uint8_t)((code_of_byte(ru.first) << 5) | (int)prefix));
+                    if (prefix == 31) bytecode_write(stream, ru.second - 32);
+                }
+            } else {
+                for (int i = 0; i < 8; i++) bytecode_write(stream, 0); // Run_blocks(): character_cum_ranks(8), hpp:144
+            }
+        }
+        unsigned w = offs.back() ? hi_bit(offs.back()) + 1 : 64; // sdsl::bits::length; width(0) keeps 64
+        IntVector::pack(offs, (uint8_t)w).write(out, true);
+        put<uint64_t>(out, stream.size());
+        out.insert(out.end(), stream.begin(), stream.end());
+    } else { // serialize, src/r-index.cpp:284-291 ; Run_blocks::serialize r-index.hpp:261-277
+        put<uint64_t>(out, n_file_blocks);
+        for (uint64_t b = 0; b < n_file_blocks; b++) {
+            if (b < blocks.size()) {
+                IntVector::pack(blocks[b].cum, 64).write(out, false);
+                put<uint64_t>(out, blocks[b].runs.size());
+                for (auto &ru : blocks[b].runs) { put<uint64_t>(out, ru.first); put<uint64_t>(out, ru.second); }
+            } else {
+                IntVector::pack(std::vector<uint64_t>(8, 0), 64).write(out, false);
+                put<uint64_t>(out, 0);
+            }
+        }
+    }
+    write_whole_file(out_ri_path, out);
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" pgx_status pgx_write_compact_tags(const char *out_path, const uint64_t *values, const uint64_t *lengths, uint64_t n_runs) {
+    PGX_GUARD_BEGIN
+    if (!out_path || (n_runs && (!values || !lengths))) throw Error(PGX_ERR_ARG, "pgx_write_compact_tags: null argument");
+    std::vector<uint64_t> items;
+    SdVector starts, intervals;
+    uint64_t bwt_pos = 0, max_node = 0;
+    auto emit = [&](uint64_t v, uint64_t len) {
+        intervals.ones.push_back(bwt_pos);
+        bwt_pos += len;
+        if (items.size() % 10 == 0) starts.ones.push_back(items.size());
+        items.push_back(v);
+    };
+    for (uint64_t i = 0; i < n_runs; i++) {
+        uint64_t len = lengths[i];
+        max_node = std::max(max_node, values[i] >> 11);
+        while (len >= 512) { emit(values[i], 511); len -= 511; } // max_tag_len = 1 << length_bits, tag_arrays.cpp:941-957
+        if (len > 0) emit(values[i], len);
+    }
+    const unsigned width = 10 + 1 + (hi_bit(max_node) + 1); // merge_tags.cpp:636-637
+    starts.size = starts.ones.empty() ? 1 : starts.ones.back() + 1; // builder(start_pos + 1, ones), tag_arrays.cpp:626
+    intervals.size = bwt_pos + 1;                                   // builder(cumulative_run_bwt_position + 1, runs), :635
+    std::vector<uint8_t> out;
+    IntVector::pack(items, (uint8_t)width).write(out, true);
+    starts.write(out);
+    intervals.write(out);
+    write_whole_file(out_path, out);
+    return PGX_OK;
+    PGX_GUARD_END
+}

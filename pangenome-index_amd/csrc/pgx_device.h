@@ -1,0 +1,54 @@
+// pgx_device.h -- kernel-side view of the device image + kernel declarations (HIP only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pgx.h"
+#include "pgx_image.h"
+
+#define PGX_FM_THREADS 256
+
+// passed by value to every kernel (all pointers are device pointers)
+struct PgxDevImage {
+    const uint4 *blocks;      // n_blocks * 4 (64-byte rank blocks)
+    const uint32_t *dir;      // dir_entries
+    const uint64_t *bstart;   // n_blocks
+    const PgxConsts *consts;  // tables (ext_tab, C, slot_code)
+    const uint64_t *tstart;   // n_tag_runs
+    const uint64_t *tvals;    // n_tag_items
+    const uint32_t *tdir;     // tag_dir_entries
+    uint64_t n;
+    uint64_t dir_entries;
+    uint64_t n_tag_runs, n_tag_items, tag_dir_entries;
+    uint32_t n_blocks;
+    uint32_t dir_shift;
+    uint32_t excl_mask;
+    uint32_t tag_dir_shift;
+};
+
+template <bool LDS_IMAGE>
+__global__ void pgx_find_mems_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
+                                     uint64_t min_len, uint64_t min_occ, const uint64_t *slot_off, pgx_mem *slots,
+                                     uint32_t *mem_count, unsigned long long *n_ext_total);
+__global__ void pgx_rank_kernel(PgxDevImage img, const uint64_t *pos, uint64_t n, int true_codes, uint64_t *out);
+template <bool LDS_IMAGE>
+__global__ void pgx_extend_kernel(PgxDevImage img, const pgx_biint *in, const uint8_t *sym, const uint8_t *forward, uint64_t n,
+                                  pgx_biint *out);
+__global__ void pgx_scan_partial_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, uint64_t *block_sums);
+__global__ void pgx_scan_sums_kernel(uint64_t *block_sums, uint64_t nb);
+__global__ void pgx_scan_apply_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, const uint64_t *block_sums,
+                                      uint64_t nb, uint64_t *out);
+__global__ void pgx_compact_mems_kernel(uint64_t n_reads, const uint64_t *slot_off, const pgx_mem *slots,
+                                        const uint32_t *mem_count, const uint64_t *mem_off, pgx_mem *mems);
+__global__ void pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *mems, const uint64_t *qstart, const uint64_t *qend,
+                                      uint64_t n, uint64_t *run_nums, uint64_t *first_item);
+__global__ void pgx_tag_gather_kernel(PgxDevImage img, uint64_t n, const uint64_t *run_nums, const uint64_t *first_item,
+                                      const uint64_t *seg_off, uint64_t *buf, unsigned long long *n_overflow);
+__global__ void pgx_tag_sort_unique_kernel(uint64_t n, const uint64_t *run_nums, const uint64_t *seg_off, uint64_t *buf,
+                                           uint64_t *scratch, const uint64_t *scratch_off, uint64_t *ucount);
+__global__ void pgx_tag_compact_kernel(uint64_t n, const uint64_t *ucount, const uint64_t *seg_off, const uint64_t *buf,
+                                       const uint64_t *pos_off, uint64_t *positions);
+__global__ void pgx_tag_scratch_need_kernel(uint64_t n, const uint64_t *run_nums, uint64_t *need);
+
+#define PGX_SCAN_BLOCK_ITEMS 2048 // 256 threads x 8 items (pgx_kernels.hip PGX_SCAN_ITEMS)

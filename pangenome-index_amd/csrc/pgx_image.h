@@ -1,0 +1,62 @@
+/*
+ * pgx_image.h -- flat, pointer-free device image of the FastLocate rank structure and the
+ * TagArray, shared by the host builder (pgx_index.cpp) and the HIP kernels (pgx_kernels.hip).
+ *
+ * Only rank *values* are observable through the reference API, so the layout is
+ * chosen for the GPU, not translated from the reference's Elias-Fano + varint blocks:
+ *
+ *  rank block (64 bytes = one half cache line, 16 dwords, loaded as 4 x dwordx4 by one lane)
+ *    dw 0..5   low 32 bits of the six absolute counts c6[code] of BWT[0, block_start)
+ *              (code order = nuc = \n A C G N T, include/pangenome_index/utils.hpp:11)
+ *    dw 6      high 8 bits of c6[0..3]  (counts are 40-bit: n < 2^40)
+ *    dw 7      bits 0..15 high 8 bits of c6[4..5]; bits 16..20 number of run entries used
+ *    dw 8..15  16 run entries of 16 bits: code << 13 | length (1..8191); length 0 = unused
+ *    block_start = sum of the counts whose code is not in `excl_mask` (see PgxConsts)
+ *  directory   u32 dir[i] = last block whose start <= (i << dir_shift); (n >> dir_shift) + 2 entries
+ *  block starts u64 bstart[b]  (binary-searched only when dir[i] != dir[i+1])
+ *
+ *  tag image: u64 tstart[r] (first BWT position of tag run r, ascending), u64 tvals[r] (the
+ *  graph position the reference prints: node << 11 | rev << 10 | offset), u32 tdir like dir.
+ *
+ * The reference's quirks are carried by the tables in PgxConsts, never by branches:
+ * the same kernels serve PGX_MODE_COMPAT and PGX_MODE_STRICT.
+ */
+#ifndef PGX_IMAGE_H
+#define PGX_IMAGE_H
+
+#include <stdint.h>
+
+#define PGX_BLOCK_BYTES 64
+#define PGX_BLOCK_RUNS 16
+#define PGX_RUN_LEN_BITS 13
+#define PGX_RUN_LEN_MAX 8191u
+#define PGX_COUNT_BITS 40
+
+/* ext_tab entry (one per byte value and direction): how to extend by that byte */
+#define PGX_EXT_CV(e) ((e) & 7u)            /* nuc code whose rank gives the new interval     */
+#define PGX_EXT_V(e) (((e) >> 3) & 7u)      /* slot into C[]                                  */
+#define PGX_EXT_M(e) (((e) >> 6) & 0x3FFFFu) /* 6 x 3-bit multiplicities over codes (k' update) */
+#define PGX_EXT_KILL(e) (((e) >> 24) & 1u)  /* extension always yields the empty interval     */
+#define PGX_EXT_MAKE(cv, v, m, kill) \
+    ((uint32_t)(cv) | ((uint32_t)(v) << 3) | ((uint32_t)(m) << 6) | ((uint32_t)(kill) << 24))
+
+typedef struct {
+    uint64_t n;           /* bwt size (sequence_size) */
+    uint64_t C[8];        /* C[slot], r-index.hpp:310 */
+    uint32_t ext_tab[512]; /* [0..255] backward by byte, [256..511] forward by byte */
+    uint32_t slot_code[8]; /* rank cache slot i -> nuc code (rank_at_cached_encoded view) */
+    uint32_t sigma;
+    uint32_t excl_mask;   /* codes whose header count is NOT part of block_start (legacy quirk 1) */
+    uint32_t dir_shift;
+    uint32_t n_blocks;
+    uint64_t dir_entries;
+    /* tags */
+    uint64_t n_tag_runs;
+    uint64_t tag_dir_entries;
+    uint32_t tag_dir_shift;
+    uint32_t has_tags;
+    uint32_t mode;
+    uint32_t pad_;
+} PgxConsts;
+
+#endif

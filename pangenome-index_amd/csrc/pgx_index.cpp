@@ -1,0 +1,485 @@
+// pgx_index.cpp -- file parsing and device-image construction (host, run once per index).
+//
+// Replaces the loaders FastLocate::load_encoded / load (src/r-index.cpp:378-459) and
+// TagArray::load_compressed_tags{,_sdsl} (src/tag_arrays.cpp:739-776): instead of rebuilding SDSL
+// objects it normalises both .ri layouts to a list of logical BWT runs and packs them into the
+// flat image of pgx_image.h.  No query arithmetic lives here.
+#include <algorithm>
+#include <cstdio>
+#include <memory>
+
+#include "pgx_host.hpp"
+
+namespace pgx {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &m) { g_last_error = m; }
+const std::string &last_error() { return g_last_error; }
+
+static inline unsigned bytecode_len(uint64_t v) {
+    unsigned k = 1;
+    while (v > 0x7F) { v >>= 7; k++; }
+    return k;
+}
+
+// ------------------------------------------------------------------------------------------
+void RiFile::parse(const uint8_t *p, uint64_t n) {
+    ByteReader r(p, n);
+    // Header::load src/r-index.cpp:171-177, checks :412-420
+    tag = r.get<uint32_t>("header");
+    version = r.get<uint32_t>("header");
+    max_length = r.get<uint64_t>("header");
+    flags = r.get<uint64_t>("header");
+    if (tag != 0x6B3741D8u) throw Error(PGX_ERR_FORMAT, "FastLocate: Invalid tag");
+    if (version != 1) throw Error(PGX_ERR_FORMAT, "FastLocate: Expected v1, got v" + std::to_string(version));
+    samples.read(r, 0, "samples");
+    last.read(r, "last");
+    last_to_run.read(r, 0, "last_to_run");
+    IntVector sm, Cv;
+    sm.read(r, 8, "sym_map");
+    Cv.read(r, 64, "C");
+    blocks_start_pos.read(r, "blocks_start_pos");
+    sequence_size = r.get<uint64_t>("sequence_size");
+    if (sm.size() != 256) throw Error(PGX_ERR_FORMAT, "FastLocate: sym_map must have 256 entries");
+    for (int i = 0; i < 256; i++) sym_map[i] = (uint8_t)sm.get((uint64_t)i);
+    C.resize(Cv.size());
+    for (uint64_t i = 0; i < C.size(); i++) C[i] = Cv.get(i);
+    const uint64_t sigma = C.size();
+    if (sigma < 2 || sigma > 6) throw Error(PGX_ERR_UNSUPPORTED, "alphabet size " + std::to_string(sigma) + " not in 2..6");
+    if (sequence_size >> PGX_COUNT_BITS) throw Error(PGX_ERR_UNSUPPORTED, "BWT longer than 2^40 symbols");
+    // every indexed symbol must be one of nuc (symbol_to_code, r-index.hpp:664-668)
+    uint64_t present = 0;
+    for (int c = 0; c < 256; c++) {
+        bool in_index = sym_map[c] != 0 || c == '\n';
+        if (sym_map[c] >= sigma) throw Error(PGX_ERR_FORMAT, "sym_map value out of range");
+        if (sym_map[c] != 0 && code_of_byte((uint8_t)c) < 0)
+            throw Error(PGX_ERR_UNSUPPORTED, "indexed symbol outside {\\n,A,C,G,N,T}");
+        if (in_index && code_of_byte((uint8_t)c) >= 0) present++;
+    }
+    if (present != sigma) throw Error(PGX_ERR_UNSUPPORTED, "sym_map and C disagree on the alphabet");
+    if (sym_map[(uint8_t)'\n'] != 0) throw Error(PGX_ERR_UNSUPPORTED, "endmarker must map to 0");
+
+    blocks.clear();
+    double enc_bytes = 0;
+    if (flags & 1ULL) { // ENCODED_BLOCKS, src/r-index.cpp:441-455
+        encoded = true;
+        enc_block_size = r.get<uint64_t>("encoded_block_size");
+        hasN = r.get<uint8_t>("encoded_has_N") != 0;
+        IntVector starts;
+        starts.read(r, 0, "blocks_encoded_start_bits");
+        uint64_t nbytes = r.get<uint64_t>("blocks_encoded_stream_size");
+        r.need(nbytes, "blocks_encoded_stream");
+        const uint8_t *s = r.p + r.o;
+        r.o += nbytes;
+        if (starts.size() == 0) throw Error(PGX_ERR_UNSUPPORTED, "encoded index without blocks");
+        // rank_at_cached_encoded reads hasN?6:5 cumulative varints (src/r-index.cpp:624) while the
+        // writer emits sigma of them (:339): any other combination mis-parses in the reference.
+        if ((hasN ? 6u : 5u) != sigma)
+            throw Error(PGX_ERR_UNSUPPORTED, "encoded index with sigma != (hasN ? 6 : 5): the reference mis-parses it");
+        n_file_blocks = starts.size();
+        for (uint64_t b = 0; b < n_file_blocks; b++) {
+            uint64_t loc = starts.get(b), end = (b + 1 < n_file_blocks) ? starts.get(b + 1) : nbytes;
+            if (loc > end || end > nbytes) throw Error(PGX_ERR_FORMAT, "encoded block offsets not monotone");
+            RefBlock blk;
+            blk.cum.resize(sigma);
+            for (uint64_t i = 0; i < sigma && loc < end; i++) blk.cum[i] = bytecode_read(s, end, loc, "encoded block header");
+            while (loc < end) {
+                uint8_t h = s[loc++];
+                uint8_t code = (h >> 5) & 7;
+                uint64_t prefix = h & 0x1F;
+                uint64_t len = prefix < 31 ? prefix + 1 : 32 + bytecode_read(s, end, loc, "encoded run");
+                if (code > 5) throw Error(PGX_ERR_FORMAT, "encoded run with code > 5");
+                blk.runs.emplace_back(code, len);
+            }
+            blocks.push_back(std::move(blk));
+        }
+        enc_bytes = (double)nbytes;
+    } else { // FastLocate::load src/r-index.cpp:395-402 ; Run_blocks::load r-index.hpp:280-290
+        encoded = false;
+        n_file_blocks = r.get<uint64_t>("blocks_size");
+        if (n_file_blocks > n) throw Error(PGX_ERR_FORMAT, "blocks_size larger than the file");
+        for (uint64_t b = 0; b < n_file_blocks; b++) {
+            IntVector cum;
+            cum.read(r, 64, "block cumulative ranks");
+            RefBlock blk;
+            blk.cum.resize(cum.size());
+            for (uint64_t i = 0; i < cum.size(); i++) blk.cum[i] = cum.get(i);
+            uint64_t nruns = r.get<uint64_t>("runs_size");
+            r.need(nruns * 16, "block runs");
+            for (uint64_t i = 0; i < nruns; i++) {
+                uint64_t sym = r.get<uint64_t>("run"), len = r.get<uint64_t>("run");
+                int code = sym < 256 ? code_of_byte((uint8_t)sym) : -1;
+                if (code < 0) throw Error(PGX_ERR_UNSUPPORTED, "BWT symbol outside {\\n,A,C,G,N,T}");
+                blk.runs.emplace_back((uint8_t)code, len);
+            }
+            for (uint64_t i = 0; i < sigma; i++) enc_bytes += bytecode_len(i < blk.cum.size() ? blk.cum[i] : 0);
+            for (auto &ru : blk.runs) enc_bytes += 1 + (ru.second >= 32 ? bytecode_len(ru.second - 32) : 0);
+            blocks.push_back(std::move(blk));
+        }
+    }
+    if (r.o != n) throw Error(PGX_ERR_FORMAT, "trailing bytes after the r-index");
+    // drop never-filled trailing blocks and validate against blocks_start_pos
+    while (!blocks.empty() && blocks.back().runs.empty()) blocks.pop_back();
+    if (blocks.size() != blocks_start_pos.ones.size())
+        throw Error(PGX_ERR_FORMAT, "blocks_start_pos does not match the number of non-empty blocks");
+    std::vector<uint64_t> acc(sigma, 0);
+    uint64_t pos = 0;
+    for (uint64_t b = 0; b < blocks.size(); b++) {
+        if (blocks_start_pos.ones[b] != pos) throw Error(PGX_ERR_FORMAT, "block start position mismatch");
+        for (uint64_t i = 0; i < sigma; i++)
+            if (blocks[b].cum.size() < sigma || blocks[b].cum[i] != acc[i])
+                throw Error(PGX_ERR_FORMAT, "block cumulative ranks do not match the runs");
+        for (auto &ru : blocks[b].runs) {
+            if (ru.second == 0) throw Error(PGX_ERR_FORMAT, "zero-length run");
+            uint8_t sm_idx = sym_map[kNuc[ru.first]];
+            if (ru.first != 0 && sm_idx == 0) throw Error(PGX_ERR_FORMAT, "run symbol not in the alphabet");
+            acc[sm_idx] += ru.second;
+            pos += ru.second;
+        }
+    }
+    if (pos != sequence_size) throw Error(PGX_ERR_FORMAT, "runs do not add up to sequence_size");
+    ref_block_mean_bytes = blocks.empty() ? 0.0 : enc_bytes / (double)blocks.size();
+}
+
+// ------------------------------------------------------------------------------------------
+static bool try_parse_tags(TagFile &tf, const uint8_t *p, uint64_t n, uint32_t fmt) {
+    try {
+        ByteReader r(p, n);
+        tf.items.clear();
+        if (fmt == PGX_TAGS_BYTECODE) { // load_compressed_tags, src/tag_arrays.cpp:739-763
+            uint64_t nbytes = r.get<uint64_t>("encoded_runs size");
+            r.need(nbytes, "encoded_runs");
+            const uint8_t *s = r.p + r.o;
+            uint64_t i = 0;
+            std::vector<uint64_t> byte_off;
+            while (i < nbytes) {
+                byte_off.push_back(i);
+                tf.items.push_back(bytecode_read(s, nbytes, i, "tag run"));
+            }
+            r.o += nbytes;
+            tf.starts.read(r, "encoded_runs_starts_sd");
+            tf.bwt_intervals.read(r, "bwt_intervals");
+            if (r.o != n) return false;
+            // starts hold the byte offset of every 10th run (encoded_start_every_k_run, tag_arrays.hpp:120)
+            for (uint64_t k = 0; k < tf.starts.ones.size(); k++) {
+                if (k * 10 >= byte_off.size() || byte_off[k * 10] != tf.starts.ones[k])
+                    throw Error(PGX_ERR_UNSUPPORTED, "tag run sampling is not 'every 10th run'");
+                tf.starts.ones[k] = k * 10; // normalise to item indexes
+            }
+        } else { // load_compressed_tags_sdsl, src/tag_arrays.cpp:766-776
+            IntVector iv;
+            iv.read(r, 0, "encoded_runs_iv");
+            if (iv.width == 0) return false;
+            tf.starts.read(r, "encoded_runs_starts_sd");
+            tf.bwt_intervals.read(r, "bwt_intervals");
+            if (r.o != n) return false;
+            tf.items.resize(iv.size());
+            for (uint64_t i = 0; i < tf.items.size(); i++) tf.items[i] = iv.get(i);
+            for (uint64_t k = 0; k < tf.starts.ones.size(); k++)
+                if (tf.starts.ones[k] != k * 10) throw Error(PGX_ERR_UNSUPPORTED, "tag run sampling is not 'every 10th run'");
+        }
+        if (tf.starts.ones.size() != (tf.items.size() + 9) / 10)
+            throw Error(PGX_ERR_UNSUPPORTED, "tag run sampling is not 'every 10th run'");
+        tf.format = fmt;
+        return true;
+    } catch (const Error &e) {
+        if (e.code == PGX_ERR_UNSUPPORTED) throw;
+        return false;
+    }
+}
+
+void TagFile::parse(const uint8_t *p, uint64_t n, uint32_t format_hint) {
+    if (format_hint == PGX_TAGS_BYTECODE || format_hint == PGX_TAGS_COMPACT) {
+        if (!try_parse_tags(*this, p, n, format_hint)) throw Error(PGX_ERR_FORMAT, "tag file does not parse in the requested format");
+        return;
+    }
+    // AUTO: the format that consumes the file exactly wins (they cannot both: the first 8 bytes
+    // are a byte count in one and a bit count in the other).
+    if (try_parse_tags(*this, p, n, PGX_TAGS_COMPACT)) return;
+    if (try_parse_tags(*this, p, n, PGX_TAGS_BYTECODE)) return;
+    throw Error(PGX_ERR_FORMAT, "tag file is neither the ByteCode nor the sdsl-compact layout");
+}
+
+// ------------------------------------------------------------------------------------------
+// Extension tables.  For a byte `a` the reference computes (src/r-index.cpp:713-756):
+//   comp_idx = sym_map[complement(a)];  for b = 0.. while sym_map[nuc[b]] < comp_idx:
+//       k' += R[sym_map[complement(nuc[b])]] - Q[...]
+//   s = R[sym_map[a]] - Q[sym_map[a]];  k = Q[sym_map[a]] + C[sym_map[a]]
+// where R/Q = rank_at_cached(k+s / k), whose slot i holds (encoded, :634-638) counts6[sym_map[nuc[i]]]
+// or (legacy, :596-601) rank(nuc[i]) + cum[sym_map[nuc[i]]].  Everything above is a function of the
+// byte alone, so it is tabulated here once; the kernels only see (code, slot, multiplicities).
+static void complement_table(uint8_t comp[256]) { // src/r-index.cpp:1512-1529
+    for (int i = 0; i < 256; i++) comp[i] = (uint8_t)i;
+    comp['A'] = 'T'; comp['C'] = 'G'; comp['G'] = 'C'; comp['T'] = 'A';
+    comp['a'] = 't'; comp['c'] = 'g'; comp['g'] = 'c'; comp['t'] = 'a';
+}
+
+void build_ext_tables(const RiFile &ri, uint32_t mode, PgxConsts &c) {
+    const uint32_t sigma = (uint32_t)ri.C.size();
+    uint8_t comp[256];
+    complement_table(comp);
+    c.sigma = sigma;
+    for (int i = 0; i < 8; i++) { c.C[i] = i < (int)sigma ? ri.C[i] : 0; c.slot_code[i] = 0; }
+    c.excl_mask = 0;
+    if (mode == PGX_MODE_STRICT) {
+        static const int COMP_CODE[6] = {0, 5, 3, 2, 4, 1};
+        for (uint32_t i = 0; i < sigma; i++) { // slot -> code view for pgx_rank_batch
+            for (int code = 0; code < 6; code++)
+                if ((code == 0 || ri.sym_map[kNuc[code]] != 0) && ri.sym_map[kNuc[code]] == i) c.slot_code[i] = (uint32_t)code;
+        }
+        for (int dir = 0; dir < 2; dir++)
+            for (int byte = 0; byte < 256; byte++) {
+                uint8_t a = dir ? comp[byte] : (uint8_t)byte;
+                int code = code_of_byte(a);
+                bool ok = code >= 0 && (code == 0 || ri.sym_map[a] != 0);
+                uint32_t m = 0;
+                if (ok)
+                    for (int x = 0; x < COMP_CODE[code]; x++) m += 1u << (3 * COMP_CODE[x]);
+                c.ext_tab[dir * 256 + byte] = ok ? PGX_EXT_MAKE(code, ri.sym_map[a], m, 0) : PGX_EXT_MAKE(0, 0, 0, 1);
+            }
+        return;
+    }
+    // COMPAT: slot i of the rank cache
+    uint32_t slot_src[8] = {0};
+    for (uint32_t i = 0; i < sigma; i++) {
+        if (ri.encoded) {
+            slot_src[i] = ri.sym_map[kNuc[i]]; // counts6[sym_map[nuc[i]]]
+        } else {
+            bool present = (i == 0) || ri.sym_map[kNuc[i]] != 0;
+            slot_src[i] = i; // absent symbol: header count of code i holds cum[0] of the reference block
+            if (!present) c.excl_mask |= 1u << i;
+        }
+        c.slot_code[i] = slot_src[i];
+    }
+    for (int dir = 0; dir < 2; dir++)
+        for (int byte = 0; byte < 256; byte++) {
+            uint8_t a = dir ? comp[byte] : (uint8_t)byte; // forward_extend: backward by complement (:761)
+            uint32_t v = ri.sym_map[a];
+            uint32_t comp_idx = ri.sym_map[comp[a]];
+            uint32_t mult[6] = {0, 0, 0, 0, 0, 0};
+            for (int b = 0; b < 6 && ri.sym_map[kNuc[b]] < comp_idx; b++) {
+                uint32_t idx = ri.sym_map[comp[kNuc[b]]];
+                mult[slot_src[idx]]++;
+            }
+            uint32_t m = 0;
+            for (int code = 0; code < 6; code++) m |= mult[code] << (3 * code);
+            c.ext_tab[dir * 256 + byte] = PGX_EXT_MAKE(slot_src[v], v, m, 0);
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+static void put_block(std::vector<uint8_t> &blocks, const uint64_t c6[6], const std::vector<std::pair<uint8_t, uint32_t>> &ent) {
+    uint32_t dw[16] = {0};
+    for (int i = 0; i < 6; i++) dw[i] = (uint32_t)c6[i];
+    for (int i = 0; i < 4; i++) dw[6] |= (uint32_t)((c6[i] >> 32) & 0xFF) << (8 * i);
+    dw[7] = (uint32_t)((c6[4] >> 32) & 0xFF) | ((uint32_t)((c6[5] >> 32) & 0xFF) << 8) | ((uint32_t)ent.size() << 16);
+    for (size_t e = 0; e < ent.size(); e++) {
+        uint32_t v = ((uint32_t)ent[e].first << PGX_RUN_LEN_BITS) | ent[e].second;
+        dw[8 + e / 2] |= v << (16 * (e & 1));
+    }
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(dw);
+    blocks.insert(blocks.end(), p, p + PGX_BLOCK_BYTES);
+}
+
+void build_rank_image(const RiFile &ri, uint32_t mode, HostImage &img) {
+    PgxConsts &c = img.consts;
+    std::memset(&c, 0, sizeof c);
+    c.n = ri.sequence_size;
+    c.mode = mode;
+    build_ext_tables(ri, mode, c);
+    // Device blocks must refine the reference's blocks only when a header slot carries the
+    // reference-block cumulative endmarker count (legacy layout, absent symbol, COMPAT).
+    const bool refine = c.excl_mask != 0;
+    img.blocks.clear();
+    img.bstart.clear();
+    uint64_t c6[6] = {0, 0, 0, 0, 0, 0}; // true counts at the current position
+    uint64_t head[6];
+    std::vector<std::pair<uint8_t, uint32_t>> ent;
+    uint64_t pos = 0, block_pos = 0, E = 0, n_runs = 0;
+    auto open_block = [&]() {
+        for (int i = 0; i < 6; i++) head[i] = (c.excl_mask >> i) & 1 ? E : c6[i];
+        block_pos = pos;
+        ent.clear();
+    };
+    auto close_block = [&]() {
+        if (ent.empty()) return;
+        put_block(img.blocks, head, ent);
+        img.bstart.push_back(block_pos);
+        ent.clear();
+    };
+    open_block();
+    for (uint64_t b = 0; b < ri.blocks.size(); b++) {
+        if (refine) {
+            close_block();
+            E = ri.blocks[b].cum[0]; // cum[sym_map[absent]] == cum[0] (src/r-index.cpp:600)
+            open_block();
+        }
+        for (auto &ru : ri.blocks[b].runs) {
+            n_runs++;
+            uint64_t left = ru.second;
+            while (left) {
+                // merge into the previous entry of the same code when it still has room
+                if (!ent.empty() && ent.back().first == ru.first && ent.back().second < PGX_RUN_LEN_MAX) {
+                    uint32_t add = (uint32_t)std::min<uint64_t>(left, PGX_RUN_LEN_MAX - ent.back().second);
+                    ent.back().second += add;
+                    left -= add; pos += add; c6[ru.first] += add;
+                    continue;
+                }
+                if (ent.size() == PGX_BLOCK_RUNS) { close_block(); open_block(); }
+                uint32_t take = (uint32_t)std::min<uint64_t>(left, PGX_RUN_LEN_MAX);
+                ent.emplace_back(ru.first, take);
+                left -= take; pos += take; c6[ru.first] += take;
+            }
+        }
+    }
+    close_block();
+    if (img.bstart.empty()) { // empty BWT: a single empty block keeps the kernels branch-free
+        uint64_t z[6] = {0};
+        put_block(img.blocks, z, {});
+        img.bstart.push_back(0);
+    }
+    img.n_runs = n_runs;
+    const uint64_t nb = img.bstart.size();
+    if (nb >> 32) throw Error(PGX_ERR_UNSUPPORTED, "more than 2^32 device blocks");
+    c.n_blocks = (uint32_t)nb;
+    // directory: ~4 buckets per block
+    uint32_t shift = 0;
+    while (shift < 40 && ((c.n >> (shift + 1)) + 2) >= 4 * nb) shift++;
+    c.dir_shift = shift;
+    c.dir_entries = (c.n >> shift) + 2;
+    img.dir.resize(c.dir_entries);
+    uint64_t bi = 0;
+    for (uint64_t i = 0; i < c.dir_entries; i++) {
+        uint64_t p = i << shift;
+        while (bi + 1 < nb && img.bstart[bi + 1] <= p) bi++;
+        img.dir[i] = (uint32_t)bi;
+    }
+}
+
+void build_tag_image(const TagFile &tf, HostImage &img) {
+    PgxConsts &c = img.consts;
+    const uint64_t nr = tf.bwt_intervals.ones.size();
+    img.tstart = tf.bwt_intervals.ones;
+    img.tvals.resize(tf.items.size());
+    for (uint64_t i = 0; i < tf.items.size(); i++) {
+        uint64_t v = tf.items[i];
+        // decode_run (src/tag_arrays.cpp:59-70, length_bits=9) / decode_run_length_compact (:47-55)
+        // followed by gbwtgraph::Position::encode = node << 11 | rev << 10 | offset
+        uint64_t off = v & 0x3FF, rev = (v >> 10) & 1;
+        uint64_t node = tf.format == PGX_TAGS_BYTECODE ? v >> 20 : v >> 11;
+        img.tvals[i] = (node << 11) | (rev << 10) | off;
+    }
+    c.has_tags = 1;
+    c.n_tag_runs = nr;
+    uint64_t span = tf.bwt_intervals.size ? tf.bwt_intervals.size : 1;
+    uint32_t shift = 0;
+    while (shift < 40 && ((span >> (shift + 1)) + 2) >= 2 * (nr + 1)) shift++;
+    c.tag_dir_shift = shift;
+    c.tag_dir_entries = (span >> shift) + 2;
+    // tdir[i] = number of run starts <= (i << shift)   (an upper_bound seed)
+    img.tdir.resize(c.tag_dir_entries);
+    uint64_t k = 0;
+    for (uint64_t i = 0; i < c.tag_dir_entries; i++) {
+        uint64_t p = i << shift;
+        while (k < nr && img.tstart[k] <= p) k++;
+        img.tdir[i] = (uint32_t)k;
+    }
+    if (nr >> 32) throw Error(PGX_ERR_UNSUPPORTED, "more than 2^32 tag runs");
+}
+
+} // namespace pgx
+
+// ------------------------------------------------------------------------------------------
+// C ABI (host part)
+using namespace pgx;
+
+extern "C" const char *pgx_last_error(void) { return pgx::last_error().c_str(); }
+extern "C" int pgx_abi_version(void) { return PGX_ABI_VERSION; }
+
+#define PGX_GUARD_BEGIN try {
+#define PGX_GUARD_END                                                    \
+    }                                                                    \
+    catch (const pgx::Error &e) { pgx::set_last_error(e.what()); return e.code; } \
+    catch (const std::bad_alloc &) { pgx::set_last_error("out of host memory"); return PGX_ERR_NOMEM; } \
+    catch (const std::exception &e) { pgx::set_last_error(e.what()); return PGX_ERR_FORMAT; }
+
+void pgx_release_device_images(pgx_index *h); // pgx_runtime.hip
+
+extern "C" pgx_status pgx_index_open(const char *ri_path, const char *tags_path, uint32_t tags_format,
+                                     uint32_t mode, pgx_index **out) {
+    PGX_GUARD_BEGIN
+    if (!ri_path || !out) throw Error(PGX_ERR_ARG, "pgx_index_open: null argument");
+    if (mode != PGX_MODE_COMPAT && mode != PGX_MODE_STRICT) throw Error(PGX_ERR_ARG, "pgx_index_open: bad mode");
+    *out = nullptr;
+    std::unique_ptr<pgx_index> h(new pgx_index());
+    h->mode = mode;
+    {
+        std::vector<uint8_t> f;
+        try { f = read_whole_file(ri_path); }
+        catch (const Error &) { throw Error(PGX_ERR_IO, std::string("Cannot open r-index: ") + ri_path); } // find_mems.cpp:30
+        h->ri.parse(f.data(), f.size());
+    }
+    build_rank_image(h->ri, mode, h->img);
+    if (tags_path) {
+        std::vector<uint8_t> f = read_whole_file(tags_path);
+        h->tags.parse(f.data(), f.size(), tags_format);
+        build_tag_image(h->tags, h->img);
+        h->has_tags = true;
+    }
+    *out = h.release();
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" void pgx_index_close(pgx_index *h) {
+    if (!h) return;
+    pgx_release_device_images(h);
+    delete h;
+}
+
+extern "C" pgx_status pgx_index_info_get(const pgx_index *h, pgx_index_info *info) {
+    PGX_GUARD_BEGIN
+    if (!h || !info) throw Error(PGX_ERR_ARG, "pgx_index_info_get: null argument");
+    std::memset(info, 0, sizeof *info);
+    const PgxConsts &c = h->img.consts;
+    info->bwt_size = c.n;
+    info->sigma = c.sigma;
+    info->n_sequences = h->ri.C.size() > 1 ? h->ri.C[1] - h->ri.C[0] : 0; // tot_strings, r-index.hpp:484
+    info->n_ref_blocks = h->ri.n_file_blocks;
+    info->n_runs = h->img.n_runs;
+    info->n_dev_blocks = c.n_blocks;
+    info->dir_entries = c.dir_entries;
+    info->dir_shift = c.dir_shift;
+    info->is_encoded = h->ri.encoded;
+    info->has_N = h->ri.hasN;
+    info->mode = h->mode;
+    info->has_tags = h->has_tags;
+    info->tag_format = h->tags.format;
+    info->n_tag_runs = c.n_tag_runs;
+    info->tag_dir_entries = c.tag_dir_entries;
+    info->tag_dir_shift = c.tag_dir_shift;
+    info->image_bytes = h->img.blocks.size() + h->img.dir.size() * 4 + h->img.bstart.size() * 8;
+    info->tag_image_bytes = h->img.tstart.size() * 8 + h->img.tvals.size() * 8 + h->img.tdir.size() * 4;
+    info->image_in_lds = info->image_bytes <= 48 * 1024;
+    info->ref_block_mean_bytes = h->ri.ref_block_mean_bytes;
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_index_image_view(const pgx_index *h, int which, const void **ptr, uint64_t *bytes) {
+    PGX_GUARD_BEGIN
+    if (!h || !ptr || !bytes) throw Error(PGX_ERR_ARG, "pgx_index_image_view: null argument");
+    const HostImage &m = h->img;
+    switch (which) {
+    case 0: *ptr = m.blocks.data(); *bytes = m.blocks.size(); break;
+    case 1: *ptr = m.dir.data(); *bytes = m.dir.size() * 4; break;
+    case 2: *ptr = m.bstart.data(); *bytes = m.bstart.size() * 8; break;
+    case 3: *ptr = m.tstart.data(); *bytes = m.tstart.size() * 8; break;
+    case 4: *ptr = m.tvals.data(); *bytes = m.tvals.size() * 8; break;
+    case 5: *ptr = m.tdir.data(); *bytes = m.tdir.size() * 4; break;
+    case 6: *ptr = &m.consts; *bytes = sizeof(PgxConsts); break;
+    default: throw Error(PGX_ERR_ARG, "pgx_index_image_view: unknown view");
+    }
+    return PGX_OK;
+    PGX_GUARD_END
+}

@@ -1,0 +1,562 @@
+// pgx_runtime.hip -- device memory, launches and the batch pipeline behind the C ABI.
+//
+// Pipeline of pgx_batch_run (one HIP stream, results stay on the device):
+//   scan(cap)      -> slot offsets (worst-case MEMs per read: len - min_len + 1)
+//   find_mems      -> MEM slots + per-read counts                      [dominant kernel]
+//   scan(count)    -> CSR offsets ; compact slots -> dense MEM array in read order
+//   tag_locate     -> per MEM run_nums + first item ; scan -> segment offsets
+//   tag_gather     -> values ; tag_sort_unique -> unique counts ; scan ; tag_compact -> positions
+// The only host synchronisations are the scalar read-backs that size the next buffer.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "pgx_device.h"
+#include "pgx_host.hpp"
+
+using namespace pgx;
+
+#define HIPCHECK(expr)                                                                              \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            throw Error(PGX_ERR_HIP, std::string(#expr) + " failed: " + hipGetErrorString(e_));    \
+    } while (0)
+
+#define PGX_GUARD_BEGIN try {
+#define PGX_GUARD_END                                                                               \
+    }                                                                                               \
+    catch (const pgx::Error &e) { pgx::set_last_error(e.what()); return e.code; }                   \
+    catch (const std::bad_alloc &) { pgx::set_last_error("out of host memory"); return PGX_ERR_NOMEM; } \
+    catch (const std::exception &e) { pgx::set_last_error(e.what()); return PGX_ERR_HIP; }
+
+static int checked_device_count() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        throw Error(PGX_ERR_NO_DEVICE, "no usable HIP device (libpgx has no CPU fallback)");
+    }
+    return n;
+}
+
+static void use_device(int device) {
+    int n = checked_device_count();
+    if (device < 0 || device >= n) throw Error(PGX_ERR_ARG, "device ordinal out of range");
+    HIPCHECK(hipSetDevice(device));
+}
+
+struct DevBuf { // grow-only device buffer
+    void *p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            (void)hipGetLastError();
+            throw Error(PGX_ERR_NOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed: " + hipGetErrorString(e));
+        }
+        cap = want;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct pgx_device_image {
+    int device = -1;
+    PgxDevImage img{};
+    DevBuf blocks, dir, bstart, consts, tstart, tvals, tdir;
+    size_t lds_bytes = 0; // dynamic LDS of the LDS-image kernels (0 = image stays in global memory)
+};
+
+void pgx_release_device_images(pgx_index *h) {
+    for (auto *d : h->dev) {
+        if (!d) continue;
+        if (hipSetDevice(d->device) == hipSuccess) {
+            d->blocks.release(); d->dir.release(); d->bstart.release(); d->consts.release();
+            d->tstart.release(); d->tvals.release(); d->tdir.release();
+        }
+        delete d;
+    }
+    h->dev.clear();
+}
+
+static void upload(DevBuf &b, const void *src, size_t bytes) {
+    b.ensure(bytes ? bytes : 16);
+    if (bytes) HIPCHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+}
+
+static pgx_device_image *device_image(pgx_index *h, int device) {
+    use_device(device);
+    if ((int)h->dev.size() <= device) h->dev.resize(device + 1, nullptr);
+    if (h->dev[device]) return h->dev[device];
+    std::unique_ptr<pgx_device_image> d(new pgx_device_image());
+    d->device = device;
+    const HostImage &m = h->img;
+    upload(d->blocks, m.blocks.data(), m.blocks.size());
+    upload(d->dir, m.dir.data(), m.dir.size() * 4);
+    upload(d->bstart, m.bstart.data(), m.bstart.size() * 8);
+    upload(d->consts, &m.consts, sizeof(PgxConsts));
+    upload(d->tstart, m.tstart.data(), m.tstart.size() * 8);
+    upload(d->tvals, m.tvals.data(), m.tvals.size() * 8);
+    upload(d->tdir, m.tdir.data(), m.tdir.size() * 4);
+    PgxDevImage &g = d->img;
+    g.blocks = d->blocks.as<uint4>();
+    g.dir = d->dir.as<uint32_t>();
+    g.bstart = d->bstart.as<uint64_t>();
+    g.consts = d->consts.as<PgxConsts>();
+    g.tstart = d->tstart.as<uint64_t>();
+    g.tvals = d->tvals.as<uint64_t>();
+    g.tdir = d->tdir.as<uint32_t>();
+    g.n = m.consts.n;
+    g.dir_entries = m.consts.dir_entries;
+    g.n_tag_runs = m.consts.n_tag_runs;
+    g.n_tag_items = m.tvals.size();
+    g.tag_dir_entries = m.consts.tag_dir_entries;
+    g.n_blocks = m.consts.n_blocks;
+    g.dir_shift = m.consts.dir_shift;
+    g.excl_mask = m.consts.excl_mask;
+    g.tag_dir_shift = m.consts.tag_dir_shift;
+    size_t img_bytes = m.blocks.size() + m.bstart.size() * 8 + m.dir.size() * 4;
+    d->lds_bytes = img_bytes <= 48 * 1024 ? ((img_bytes + 15) & ~(size_t)15) : 0;
+    h->dev[device] = d.release();
+    return h->dev[device];
+}
+
+extern "C" pgx_status pgx_index_to_device(pgx_index *h, int device) {
+    PGX_GUARD_BEGIN
+    if (!h) throw Error(PGX_ERR_ARG, "pgx_index_to_device: null index");
+    (void)device_image(h, device);
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_device_count(int *n) {
+    PGX_GUARD_BEGIN
+    if (!n) throw Error(PGX_ERR_ARG, "pgx_device_count: null argument");
+    *n = 0;
+    *n = checked_device_count();
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_device_name(int device, char *buf, size_t buflen) {
+    PGX_GUARD_BEGIN
+    if (!buf || !buflen) throw Error(PGX_ERR_ARG, "pgx_device_name: null argument");
+    use_device(device);
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDeviceProperties(&prop, device));
+    std::snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan helper: out[n+1] on device (out[n] = total); returns nothing, async on `s`
+static void scan_excl(int mode, const void *in, uint64_t n, uint64_t min_len, uint64_t *out, DevBuf &tmp, hipStream_t s) {
+    if (n == 0) {
+        HIPCHECK(hipMemsetAsync(out, 0, 8, s));
+        return;
+    }
+    const uint64_t nb = (n + PGX_SCAN_BLOCK_ITEMS - 1) / PGX_SCAN_BLOCK_ITEMS;
+    tmp.ensure((nb + 1) * 8);
+    uint64_t *sums = tmp.as<uint64_t>();
+    hipLaunchKernelGGL(pgx_scan_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, mode, in, n, min_len, sums);
+    hipLaunchKernelGGL(pgx_scan_sums_kernel, dim3(1), dim3(256), 0, s, sums, nb);
+    hipLaunchKernelGGL(pgx_scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, mode, in, n, min_len, (const uint64_t *)sums, nb, out);
+    HIPCHECK(hipGetLastError());
+}
+
+static uint64_t read_u64(const uint64_t *dptr, hipStream_t s) {
+    uint64_t v = 0;
+    HIPCHECK(hipMemcpyAsync(&v, dptr, 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    return v;
+}
+
+static inline unsigned grid_for(uint64_t n, unsigned per_block) {
+    uint64_t g = (n + per_block - 1) / per_block;
+    if (g == 0) g = 1;
+    if (g > 0x7FFFFFFFull) throw Error(PGX_ERR_UNSUPPORTED, "batch too large for one launch");
+    return (unsigned)g;
+}
+
+// ------------------------------------------------------------------------------------------
+struct pgx_batch {
+    pgx_index *h = nullptr;
+    pgx_device_image *dimg = nullptr;
+    int device = 0;
+    uint64_t n_reads = 0, read_bytes = 0;
+    DevBuf reads, offsets;
+    // run state
+    DevBuf slot_off, slots, mem_count, mem_off, mems, scan_tmp, counters;
+    DevBuf run_nums, first_item, seg_off, gbuf, need, scratch_off, scratch, ucount, pos_off, positions;
+    uint64_t n_mems = 0, n_positions = 0, n_ext = 0, n_tag_overflow = 0;
+    bool ran = false, ran_tags = false;
+    // host copies
+    std::vector<uint64_t> h_mem_off, h_run_nums, h_pos_off, h_positions;
+    std::vector<pgx_mem> h_mems;
+    // timing
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool timed = false;
+    pgx_timing timing{};
+};
+
+static void batch_release(pgx_batch *b) {
+    if (!b) return;
+    if (hipSetDevice(b->device) == hipSuccess) {
+        DevBuf *all[] = {&b->reads, &b->offsets, &b->slot_off, &b->slots, &b->mem_count, &b->mem_off, &b->mems, &b->scan_tmp,
+                         &b->counters, &b->run_nums, &b->first_item, &b->seg_off, &b->gbuf, &b->need, &b->scratch_off,
+                         &b->scratch, &b->ucount, &b->pos_off, &b->positions};
+        for (DevBuf *d : all) d->release();
+        for (auto &e : b->ev)
+            if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    }
+    delete b;
+}
+
+extern "C" void pgx_batch_free(pgx_batch *b) { batch_release(b); }
+
+extern "C" pgx_status pgx_batch_create(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets,
+                                       uint64_t n_reads, pgx_batch **out) {
+    PGX_GUARD_BEGIN
+    if (!h || !out || !offsets || (!reads && n_reads && offsets[n_reads] != offsets[0]))
+        throw Error(PGX_ERR_ARG, "pgx_batch_create: null argument");
+    *out = nullptr;
+    for (uint64_t i = 0; i < n_reads; i++) {
+        if (offsets[i + 1] < offsets[i]) throw Error(PGX_ERR_ARG, "pgx_batch_create: offsets must be non-decreasing");
+        if (offsets[i + 1] - offsets[i] >= (1ull << 31)) throw Error(PGX_ERR_UNSUPPORTED, "read longer than 2^31 bytes");
+    }
+    pgx_device_image *dimg = device_image(h, device);
+    std::unique_ptr<pgx_batch, void (*)(pgx_batch *)> b(new pgx_batch(), batch_release);
+    b->h = h;
+    b->dimg = dimg;
+    b->device = device;
+    b->n_reads = n_reads;
+    const uint64_t lo = offsets[0], hi = offsets[n_reads];
+    b->read_bytes = hi - lo;
+    // device offsets are rebased to 0; 16 bytes of zero padding after the last read
+    b->reads.ensure(b->read_bytes + 16);
+    HIPCHECK(hipMemset(b->reads.p, 0, b->read_bytes + 16));
+    if (b->read_bytes) HIPCHECK(hipMemcpy(b->reads.p, reads + lo, b->read_bytes, hipMemcpyHostToDevice));
+    std::vector<uint64_t> reb(n_reads + 1);
+    for (uint64_t i = 0; i <= n_reads; i++) reb[i] = offsets[i] - lo;
+    b->offsets.ensure((n_reads + 1) * 8);
+    HIPCHECK(hipMemcpy(b->offsets.p, reb.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice));
+    *out = b.release();
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+static void record(pgx_batch *b, int i, hipStream_t s) {
+    if (!b->timed) return;
+    if (!b->ev[i]) HIPCHECK(hipEventCreate(&b->ev[i]));
+    HIPCHECK(hipEventRecord(b->ev[i], s));
+}
+
+extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min_occ, uint32_t flags, void *stream) {
+    PGX_GUARD_BEGIN
+    if (!b) throw Error(PGX_ERR_ARG, "pgx_batch_run: null batch");
+    use_device(b->device);
+    hipStream_t s = (hipStream_t)stream;
+    const PgxDevImage &img = b->dimg->img;
+    const uint64_t n = b->n_reads;
+    const bool want_tags = (flags & PGX_RUN_TAGS) != 0;
+    if (want_tags && !b->h->has_tags) throw Error(PGX_ERR_ARG, "pgx_batch_run: PGX_RUN_TAGS without a tag array");
+    b->timed = (flags & PGX_RUN_TIMING) != 0;
+    b->ran = false;
+    b->ran_tags = false;
+    b->n_mems = b->n_positions = b->n_ext = b->n_tag_overflow = 0;
+    std::memset(&b->timing, 0, sizeof b->timing);
+
+    b->counters.ensure(64);
+    HIPCHECK(hipMemsetAsync(b->counters.p, 0, 64, s));
+    unsigned long long *d_next = b->counters.as<unsigned long long>();
+    unsigned long long *d_nover = d_next + 1;
+
+    record(b, 0, s);
+    // 1. worst-case MEM slots per read
+    b->slot_off.ensure((n + 1) * 8);
+    scan_excl(2, b->offsets.p, n, min_len, b->slot_off.as<uint64_t>(), b->scan_tmp, s);
+    const uint64_t total_slots = read_u64(b->slot_off.as<uint64_t>() + n, s);
+    b->slots.ensure((total_slots ? total_slots : 1) * sizeof(pgx_mem));
+    b->mem_count.ensure((n ? n : 1) * 4);
+    // 2. the hot kernel
+    record(b, 1, s);
+    if (n) {
+        const unsigned grid = grid_for(n, PGX_FM_THREADS);
+        if (b->dimg->lds_bytes)
+            hipLaunchKernelGGL(pgx_find_mems_kernel<true>, dim3(grid), dim3(PGX_FM_THREADS), b->dimg->lds_bytes, s, img,
+                               b->reads.as<uint8_t>(), b->offsets.as<uint64_t>(), n, min_len, min_occ, b->slot_off.as<uint64_t>(),
+                               b->slots.as<pgx_mem>(), b->mem_count.as<uint32_t>(), d_next);
+        else
+            hipLaunchKernelGGL(pgx_find_mems_kernel<false>, dim3(grid), dim3(PGX_FM_THREADS), 0, s, img, b->reads.as<uint8_t>(),
+                               b->offsets.as<uint64_t>(), n, min_len, min_occ, b->slot_off.as<uint64_t>(), b->slots.as<pgx_mem>(),
+                               b->mem_count.as<uint32_t>(), d_next);
+        HIPCHECK(hipGetLastError());
+        b->timing.find_mems_launches = 1;
+    }
+    record(b, 2, s);
+    // 3. CSR offsets + compaction
+    b->mem_off.ensure((n + 1) * 8);
+    scan_excl(0, b->mem_count.p, n, 0, b->mem_off.as<uint64_t>(), b->scan_tmp, s);
+    b->n_mems = read_u64(b->mem_off.as<uint64_t>() + n, s);
+    b->mems.ensure((b->n_mems ? b->n_mems : 1) * sizeof(pgx_mem));
+    if (n) {
+        hipLaunchKernelGGL(pgx_compact_mems_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, n, b->slot_off.as<uint64_t>(),
+                           b->slots.as<pgx_mem>(), b->mem_count.as<uint32_t>(), b->mem_off.as<uint64_t>(), b->mems.as<pgx_mem>());
+        HIPCHECK(hipGetLastError());
+    }
+    record(b, 3, s);
+    // 4. tag queries (find_mems.cpp:129)
+    if (want_tags) {
+        const uint64_t m = b->n_mems;
+        b->run_nums.ensure((m ? m : 1) * 8);
+        b->first_item.ensure((m ? m : 1) * 8);
+        b->seg_off.ensure((m + 1) * 8);
+        b->need.ensure((m ? m : 1) * 8);
+        b->scratch_off.ensure((m + 1) * 8);
+        b->ucount.ensure((m ? m : 1) * 8);
+        b->pos_off.ensure((m + 1) * 8);
+        if (m) {
+            hipLaunchKernelGGL(pgx_tag_locate_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, img, b->mems.as<pgx_mem>(),
+                               (const uint64_t *)nullptr, (const uint64_t *)nullptr, m, b->run_nums.as<uint64_t>(),
+                               b->first_item.as<uint64_t>());
+            hipLaunchKernelGGL(pgx_tag_scratch_need_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, m, b->run_nums.as<uint64_t>(),
+                               b->need.as<uint64_t>());
+            HIPCHECK(hipGetLastError());
+        }
+        scan_excl(1, b->run_nums.p, m, 0, b->seg_off.as<uint64_t>(), b->scan_tmp, s);
+        scan_excl(1, b->need.p, m, 0, b->scratch_off.as<uint64_t>(), b->scan_tmp, s);
+        const uint64_t G = read_u64(b->seg_off.as<uint64_t>() + m, s);
+        const uint64_t S = read_u64(b->scratch_off.as<uint64_t>() + m, s);
+        record(b, 4, s);
+        b->gbuf.ensure((G ? G : 1) * 8);
+        b->scratch.ensure((S ? S : 1) * 8);
+        if (m) {
+            hipLaunchKernelGGL(pgx_tag_gather_kernel, dim3(grid_for(m, 4)), dim3(256), 0, s, img, m, b->run_nums.as<uint64_t>(),
+                               b->first_item.as<uint64_t>(), b->seg_off.as<uint64_t>(), b->gbuf.as<uint64_t>(), d_nover);
+            HIPCHECK(hipGetLastError());
+        }
+        record(b, 5, s);
+        if (m) {
+            hipLaunchKernelGGL(pgx_tag_sort_unique_kernel, dim3(grid_for(m, 4)), dim3(256), 0, s, m, b->run_nums.as<uint64_t>(),
+                               b->seg_off.as<uint64_t>(), b->gbuf.as<uint64_t>(), b->scratch.as<uint64_t>(),
+                               b->scratch_off.as<uint64_t>(), b->ucount.as<uint64_t>());
+            HIPCHECK(hipGetLastError());
+        }
+        scan_excl(1, b->ucount.p, m, 0, b->pos_off.as<uint64_t>(), b->scan_tmp, s);
+        b->n_positions = read_u64(b->pos_off.as<uint64_t>() + m, s);
+        b->positions.ensure((b->n_positions ? b->n_positions : 1) * 8);
+        if (m) {
+            hipLaunchKernelGGL(pgx_tag_compact_kernel, dim3(grid_for(m, 4)), dim3(256), 0, s, m, b->ucount.as<uint64_t>(),
+                               b->seg_off.as<uint64_t>(), b->gbuf.as<uint64_t>(), b->pos_off.as<uint64_t>(),
+                               b->positions.as<uint64_t>());
+            HIPCHECK(hipGetLastError());
+        }
+        record(b, 6, s);
+        b->ran_tags = true;
+    }
+    record(b, 7, s);
+    unsigned long long cnt[2] = {0, 0};
+    HIPCHECK(hipMemcpyAsync(cnt, b->counters.p, 16, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    b->n_ext = cnt[0];
+    b->n_tag_overflow = cnt[1];
+    if (b->timed) {
+        auto el = [&](int a, int c) { float ms = 0; HIPCHECK(hipEventElapsedTime(&ms, b->ev[a], b->ev[c])); return ms; };
+        b->timing.ms_find_mems = el(1, 2);
+        b->timing.ms_compact = el(2, 3);
+        if (want_tags) {
+            b->timing.ms_tag_locate = el(3, 4);
+            b->timing.ms_tag_gather = el(4, 5);
+            b->timing.ms_tag_sort = el(5, 6);
+        }
+        b->timing.ms_total = el(0, 7);
+    }
+    b->ran = true;
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_batch_counts(pgx_batch *b, uint64_t *n_mems, uint64_t *n_positions, uint64_t *n_extensions) {
+    PGX_GUARD_BEGIN
+    if (!b || !b->ran) throw Error(PGX_ERR_ARG, "pgx_batch_counts: batch has not been run");
+    if (n_mems) *n_mems = b->n_mems;
+    if (n_positions) *n_positions = b->n_positions;
+    if (n_extensions) *n_extensions = b->n_ext;
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_batch_timing(pgx_batch *b, pgx_timing *out) {
+    PGX_GUARD_BEGIN
+    if (!b || !out || !b->ran) throw Error(PGX_ERR_ARG, "pgx_batch_timing: batch has not been run");
+    if (!b->timed) throw Error(PGX_ERR_ARG, "pgx_batch_timing: run without PGX_RUN_TIMING");
+    *out = b->timing;
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_batch_result(pgx_batch *b, pgx_result *out) {
+    PGX_GUARD_BEGIN
+    if (!b || !out || !b->ran) throw Error(PGX_ERR_ARG, "pgx_batch_result: batch has not been run");
+    use_device(b->device);
+    const uint64_t n = b->n_reads, m = b->n_mems;
+    b->h_mem_off.assign(n + 1, 0);
+    HIPCHECK(hipMemcpy(b->h_mem_off.data(), b->mem_off.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+    b->h_mems.resize(m);
+    if (m) HIPCHECK(hipMemcpy(b->h_mems.data(), b->mems.p, m * sizeof(pgx_mem), hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof *out);
+    out->n_reads = n;
+    out->n_mems = m;
+    out->mem_offsets = b->h_mem_off.data();
+    out->mems = b->h_mems.data();
+    out->n_extensions = b->n_ext;
+    if (b->ran_tags) {
+        b->h_run_nums.resize(m);
+        b->h_pos_off.assign(m + 1, 0);
+        b->h_positions.resize(b->n_positions);
+        if (m) HIPCHECK(hipMemcpy(b->h_run_nums.data(), b->run_nums.p, m * 8, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(b->h_pos_off.data(), b->pos_off.p, (m + 1) * 8, hipMemcpyDeviceToHost));
+        if (b->n_positions) HIPCHECK(hipMemcpy(b->h_positions.data(), b->positions.p, b->n_positions * 8, hipMemcpyDeviceToHost));
+        out->tag_run_counts = b->h_run_nums.data();
+        out->pos_offsets = b->h_pos_off.data();
+        out->positions = b->h_positions.data();
+        out->n_positions = b->n_positions;
+        out->n_tag_overflow = b->n_tag_overflow;
+    }
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_find_mems_batch(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets,
+                                          uint64_t n_reads, uint64_t min_len, uint64_t min_occ, uint32_t flags,
+                                          pgx_batch **batch_out, pgx_result *result_out) {
+    if (!batch_out || !result_out) { pgx::set_last_error("pgx_find_mems_batch: null argument"); return PGX_ERR_ARG; }
+    *batch_out = nullptr;
+    pgx_batch *b = nullptr;
+    pgx_status st = pgx_batch_create(h, device, reads, offsets, n_reads, &b);
+    if (st == PGX_OK) st = pgx_batch_run(b, min_len, min_occ, flags, nullptr);
+    if (st == PGX_OK) st = pgx_batch_result(b, result_out);
+    if (st != PGX_OK) { pgx_batch_free(b); return st; }
+    *batch_out = b;
+    return PGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// primitives (tests)
+extern "C" pgx_status pgx_rank_batch(pgx_index *h, int device, const uint64_t *pos, uint64_t n, int true_codes, uint64_t *out) {
+    PGX_GUARD_BEGIN
+    if (!h || (n && (!pos || !out))) throw Error(PGX_ERR_ARG, "pgx_rank_batch: null argument");
+    pgx_device_image *d = device_image(h, device);
+    if (!n) return PGX_OK;
+    DevBuf dp, dout;
+    try {
+        dp.ensure(n * 8);
+        dout.ensure(n * 48);
+        HIPCHECK(hipMemcpy(dp.p, pos, n * 8, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemset(dout.p, 0, n * 48));
+        hipLaunchKernelGGL(pgx_rank_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, d->img, dp.as<uint64_t>(), n, true_codes, dout.as<uint64_t>());
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpy(out, dout.p, n * 48, hipMemcpyDeviceToHost));
+    } catch (...) { dp.release(); dout.release(); throw; }
+    dp.release(); dout.release();
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_extend_batch(pgx_index *h, int device, const pgx_biint *in, const uint8_t *sym, const uint8_t *forward,
+                                       uint64_t n, pgx_biint *out) {
+    PGX_GUARD_BEGIN
+    if (!h || (n && (!in || !sym || !forward || !out))) throw Error(PGX_ERR_ARG, "pgx_extend_batch: null argument");
+    pgx_device_image *d = device_image(h, device);
+    if (!n) return PGX_OK;
+    DevBuf din, dsym, dfw, dout;
+    try {
+        din.ensure(n * sizeof(pgx_biint)); dsym.ensure(n); dfw.ensure(n); dout.ensure(n * sizeof(pgx_biint));
+        HIPCHECK(hipMemcpy(din.p, in, n * sizeof(pgx_biint), hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(dsym.p, sym, n, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(dfw.p, forward, n, hipMemcpyHostToDevice));
+        if (d->lds_bytes)
+            hipLaunchKernelGGL(pgx_extend_kernel<true>, dim3(grid_for(n, 256)), dim3(256), d->lds_bytes, 0, d->img, din.as<pgx_biint>(),
+                               dsym.as<uint8_t>(), dfw.as<uint8_t>(), n, dout.as<pgx_biint>());
+        else
+            hipLaunchKernelGGL(pgx_extend_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, 0, d->img, din.as<pgx_biint>(),
+                               dsym.as<uint8_t>(), dfw.as<uint8_t>(), n, dout.as<pgx_biint>());
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpy(out, dout.p, n * sizeof(pgx_biint), hipMemcpyDeviceToHost));
+    } catch (...) { din.release(); dsym.release(); dfw.release(); dout.release(); throw; }
+    din.release(); dsym.release(); dfw.release(); dout.release();
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_tag_query_batch(pgx_index *h, int device, const uint64_t *start, const uint64_t *end, uint64_t n,
+                                          uint64_t *run_nums, uint64_t *pos_offsets, uint64_t *positions, uint64_t positions_cap,
+                                          uint64_t *n_overflow) {
+    PGX_GUARD_BEGIN
+    if (!h || !pos_offsets || (n && (!start || !end || !run_nums))) throw Error(PGX_ERR_ARG, "pgx_tag_query_batch: null argument");
+    if (!h->has_tags) throw Error(PGX_ERR_ARG, "pgx_tag_query_batch: index opened without a tag array");
+    pgx_device_image *d = device_image(h, device);
+    pos_offsets[0] = 0;
+    if (n_overflow) *n_overflow = 0;
+    if (!n) return PGX_OK;
+    DevBuf ds, de, drn, dfi, dseg, dneed, dsoff, dscr, dg, duc, dpo, dpos, tmp, dctr;
+    DevBuf *all[] = {&ds, &de, &drn, &dfi, &dseg, &dneed, &dsoff, &dscr, &dg, &duc, &dpo, &dpos, &tmp, &dctr};
+    try {
+        hipStream_t s = nullptr;
+        ds.ensure(n * 8); de.ensure(n * 8); drn.ensure(n * 8); dfi.ensure(n * 8); dseg.ensure((n + 1) * 8);
+        dneed.ensure(n * 8); dsoff.ensure((n + 1) * 8); duc.ensure(n * 8); dpo.ensure((n + 1) * 8); dctr.ensure(16);
+        HIPCHECK(hipMemset(dctr.p, 0, 16));
+        HIPCHECK(hipMemcpy(ds.p, start, n * 8, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(de.p, end, n * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(pgx_tag_locate_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d->img, (const pgx_mem *)nullptr,
+                           ds.as<uint64_t>(), de.as<uint64_t>(), n, drn.as<uint64_t>(), dfi.as<uint64_t>());
+        hipLaunchKernelGGL(pgx_tag_scratch_need_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, n, drn.as<uint64_t>(), dneed.as<uint64_t>());
+        HIPCHECK(hipGetLastError());
+        scan_excl(1, drn.p, n, 0, dseg.as<uint64_t>(), tmp, s);
+        scan_excl(1, dneed.p, n, 0, dsoff.as<uint64_t>(), tmp, s);
+        const uint64_t G = read_u64(dseg.as<uint64_t>() + n, s), S = read_u64(dsoff.as<uint64_t>() + n, s);
+        dg.ensure((G ? G : 1) * 8);
+        dscr.ensure((S ? S : 1) * 8);
+        hipLaunchKernelGGL(pgx_tag_gather_kernel, dim3(grid_for(n, 4)), dim3(256), 0, s, d->img, n, drn.as<uint64_t>(), dfi.as<uint64_t>(),
+                           dseg.as<uint64_t>(), dg.as<uint64_t>(), dctr.as<unsigned long long>());
+        hipLaunchKernelGGL(pgx_tag_sort_unique_kernel, dim3(grid_for(n, 4)), dim3(256), 0, s, n, drn.as<uint64_t>(), dseg.as<uint64_t>(),
+                           dg.as<uint64_t>(), dscr.as<uint64_t>(), dsoff.as<uint64_t>(), duc.as<uint64_t>());
+        HIPCHECK(hipGetLastError());
+        scan_excl(1, duc.p, n, 0, dpo.as<uint64_t>(), tmp, s);
+        const uint64_t P = read_u64(dpo.as<uint64_t>() + n, s);
+        HIPCHECK(hipMemcpy(run_nums, drn.p, n * 8, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(pos_offsets, dpo.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+        if (positions) {
+            if (positions_cap < P) throw Error(PGX_ERR_ARG, "pgx_tag_query_batch: positions_cap too small");
+            dpos.ensure((P ? P : 1) * 8);
+            hipLaunchKernelGGL(pgx_tag_compact_kernel, dim3(grid_for(n, 4)), dim3(256), 0, s, n, duc.as<uint64_t>(), dseg.as<uint64_t>(),
+                               dg.as<uint64_t>(), dpo.as<uint64_t>(), dpos.as<uint64_t>());
+            HIPCHECK(hipGetLastError());
+            if (P) HIPCHECK(hipMemcpy(positions, dpos.p, P * 8, hipMemcpyDeviceToHost));
+        }
+        if (n_overflow) {
+            unsigned long long c = 0;
+            HIPCHECK(hipMemcpy(&c, dctr.p, 8, hipMemcpyDeviceToHost));
+            *n_overflow = c;
+        }
+    } catch (...) {
+        for (DevBuf *b : all) b->release();
+        throw;
+    }
+    for (DevBuf *b : all) b->release();
+    return PGX_OK;
+    PGX_GUARD_END
+}

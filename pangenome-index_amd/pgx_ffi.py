@@ -1,0 +1,261 @@
+"""ctypes binding of libpgx.so (include/pgx.h) -- the test / bench harness side of the C ABI.
+
+This module holds no algorithm: it only marshals numpy arrays across the C ABI.  The library has no
+CPU fallback; every compute call needs a gfx950 device and raises PgxError otherwise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "libpgx.so")
+
+OK, ERR_IO, ERR_FORMAT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_ARG, ERR_NOMEM = range(8)
+MODE_COMPAT, MODE_STRICT = 0, 1
+TAGS_AUTO, TAGS_BYTECODE, TAGS_COMPACT = 0, 1, 2
+RUN_TAGS, RUN_TIMING = 1, 2
+
+MEM_DTYPE = np.dtype([("start", "<u8"), ("end", "<u8"), ("bwt_start", "<u8"), ("size", "<i8")])
+BIINT_DTYPE = np.dtype([("forward", "<u8"), ("reverse", "<u8"), ("size", "<i8")])
+
+u64, u32, p = C.c_uint64, C.c_uint32, C.c_void_p
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [
+        ("bwt_size", u64), ("sigma", u64), ("n_sequences", u64), ("n_ref_blocks", u64), ("n_runs", u64),
+        ("n_dev_blocks", u64), ("dir_entries", u64), ("dir_shift", u32), ("is_encoded", u32), ("has_N", u32),
+        ("mode", u32), ("has_tags", u32), ("tag_format", u32), ("n_tag_runs", u64), ("tag_dir_entries", u64),
+        ("tag_dir_shift", u32), ("image_in_lds", u32), ("image_bytes", u64), ("tag_image_bytes", u64),
+        ("ref_block_mean_bytes", C.c_double),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("n_reads", u64), ("n_mems", u64), ("mem_offsets", C.POINTER(u64)), ("mems", p),
+        ("tag_run_counts", C.POINTER(u64)), ("pos_offsets", C.POINTER(u64)), ("positions", C.POINTER(u64)),
+        ("n_positions", u64), ("n_extensions", u64), ("n_tag_overflow", u64),
+    ]
+
+
+class Timing(C.Structure):
+    _fields_ = [
+        ("ms_find_mems", C.c_float), ("ms_compact", C.c_float), ("ms_tag_locate", C.c_float),
+        ("ms_tag_gather", C.c_float), ("ms_tag_sort", C.c_float), ("ms_total", C.c_float),
+        ("find_mems_launches", u32),
+    ]
+
+
+def _u64_array(ptr, n):
+    """copy n uint64 from a (possibly NULL) ctypes pointer"""
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=np.uint64)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).copy()
+
+
+class PgxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("pgx status %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def build():
+    """Compile libpgx.so in-tree (hipcc cross-compiles gfx950 without a GPU)."""
+    subprocess.run(["make", "-C", PKG_DIR, "-s", "-j4"], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PgxError(ERR_NO_DEVICE, "libpgx.so is not built (run __graft_entry__.build()); there is no fallback")
+    L = C.CDLL(LIB_PATH)
+    L.pgx_last_error.restype = C.c_char_p
+    L.pgx_abi_version.restype = C.c_int
+    L.pgx_index_open.argtypes = [C.c_char_p, C.c_char_p, u32, u32, C.POINTER(p)]
+    L.pgx_index_info_get.argtypes = [p, C.POINTER(IndexInfo)]
+    L.pgx_index_close.argtypes = [p]
+    L.pgx_index_close.restype = None
+    L.pgx_index_to_device.argtypes = [p, C.c_int]
+    L.pgx_index_image_view.argtypes = [p, C.c_int, C.POINTER(p), C.POINTER(u64)]
+    L.pgx_build_rindex.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    L.pgx_build_rlbwt.argtypes = [C.c_char_p, C.c_char_p]
+    L.pgx_write_compact_tags.argtypes = [C.c_char_p, p, p, u64]
+    L.pgx_rank_batch.argtypes = [p, C.c_int, p, u64, C.c_int, p]
+    L.pgx_extend_batch.argtypes = [p, C.c_int, p, p, p, u64, p]
+    L.pgx_tag_query_batch.argtypes = [p, C.c_int, p, p, u64, p, p, p, u64, C.POINTER(u64)]
+    L.pgx_batch_create.argtypes = [p, C.c_int, p, p, u64, C.POINTER(p)]
+    L.pgx_batch_run.argtypes = [p, u64, u64, u32, p]
+    L.pgx_batch_result.argtypes = [p, C.POINTER(Result)]
+    L.pgx_batch_counts.argtypes = [p, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    L.pgx_batch_timing.argtypes = [p, C.POINTER(Timing)]
+    L.pgx_batch_free.argtypes = [p]
+    L.pgx_batch_free.restype = None
+    L.pgx_find_mems_batch.argtypes = [p, C.c_int, p, p, u64, u64, u64, u32, C.POINTER(p), C.POINTER(Result)]
+    L.pgx_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.pgx_device_name.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+    _lib = L
+    return L
+
+
+def _check(st):
+    if st != OK:
+        raise PgxError(st, lib().pgx_last_error().decode(errors="replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(lib().pgx_device_count(C.byref(n)))
+    return n.value
+
+
+def device_name(device=0):
+    buf = C.create_string_buffer(256)
+    _check(lib().pgx_device_name(device, buf, 256))
+    return buf.value.decode()
+
+
+def build_rindex(rlbwt_path, out_path, encoded=True):
+    _check(lib().pgx_build_rindex(rlbwt_path.encode(), out_path.encode(), 1 if encoded else 0))
+
+
+def build_rlbwt(text_path, out_path):
+    _check(lib().pgx_build_rlbwt(text_path.encode(), out_path.encode()))
+
+
+def write_compact_tags(out_path, values, lengths):
+    v = np.ascontiguousarray(values, dtype=np.uint64)
+    l = np.ascontiguousarray(lengths, dtype=np.uint64)
+    assert len(v) == len(l)
+    _check(lib().pgx_write_compact_tags(out_path.encode(), v.ctypes.data, l.ctypes.data, len(v)))
+
+
+_VIEW_DTYPES = {0: np.uint8, 1: np.uint32, 2: np.uint64, 3: np.uint64, 4: np.uint64, 5: np.uint32, 6: np.uint8}
+
+
+class Index:
+    """FastLocate + TagArray behind the C ABI."""
+
+    def __init__(self, ri_path, tags_path=None, tags_format=TAGS_AUTO, mode=MODE_COMPAT):
+        self.L = lib()
+        self.h = p()
+        _check(self.L.pgx_index_open(ri_path.encode(), tags_path.encode() if tags_path else None, tags_format, mode,
+                                     C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pgx_index_close(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def info(self):
+        inf = IndexInfo()
+        _check(self.L.pgx_index_info_get(self.h, C.byref(inf)))
+        return inf
+
+    def to_device(self, device=0):
+        _check(self.L.pgx_index_to_device(self.h, device))
+
+    def image_view(self, which):
+        ptr, nbytes = p(), u64(0)
+        _check(self.L.pgx_index_image_view(self.h, which, C.byref(ptr), C.byref(nbytes)))
+        if nbytes.value == 0:
+            return np.zeros(0, dtype=_VIEW_DTYPES[which])
+        raw = C.string_at(ptr, nbytes.value)
+        return np.frombuffer(raw, dtype=_VIEW_DTYPES[which]).copy()
+
+    # ---- primitives -------------------------------------------------------------------------
+    def rank_batch(self, pos, true_codes=False, device=0):
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        out = np.zeros((len(pos), 6), dtype=np.uint64)
+        _check(self.L.pgx_rank_batch(self.h, device, pos.ctypes.data, len(pos), 1 if true_codes else 0, out.ctypes.data))
+        return out
+
+    def extend_batch(self, intervals, syms, forward, device=0):
+        iv = np.ascontiguousarray(intervals, dtype=BIINT_DTYPE)
+        sy = np.ascontiguousarray(syms, dtype=np.uint8)
+        fw = np.ascontiguousarray(forward, dtype=np.uint8)
+        out = np.zeros(len(iv), dtype=BIINT_DTYPE)
+        _check(self.L.pgx_extend_batch(self.h, device, iv.ctypes.data, sy.ctypes.data, fw.ctypes.data, len(iv), out.ctypes.data))
+        return out
+
+    def tag_query_batch(self, start, end, device=0):
+        st = np.ascontiguousarray(start, dtype=np.uint64)
+        en = np.ascontiguousarray(end, dtype=np.uint64)
+        n = len(st)
+        rn = np.zeros(n, dtype=np.uint64)
+        po = np.zeros(n + 1, dtype=np.uint64)
+        nover = u64(0)
+        _check(self.L.pgx_tag_query_batch(self.h, device, st.ctypes.data, en.ctypes.data, n, rn.ctypes.data, po.ctypes.data,
+                                          None, 0, C.byref(nover)))
+        P = int(po[-1])
+        pos = np.zeros(max(P, 1), dtype=np.uint64)
+        _check(self.L.pgx_tag_query_batch(self.h, device, st.ctypes.data, en.ctypes.data, n, rn.ctypes.data, po.ctypes.data,
+                                          pos.ctypes.data, len(pos), C.byref(nover)))
+        return rn, po, pos[:P], nover.value
+
+    # ---- hot path ---------------------------------------------------------------------------
+    def batch(self, reads_cat, offsets, device=0):
+        return Batch(self, reads_cat, offsets, device)
+
+    def find_mems(self, reads_cat, offsets, min_len, min_occ, tags=False, device=0):
+        b = Batch(self, reads_cat, offsets, device)
+        try:
+            b.run(min_len, min_occ, RUN_TAGS if tags else 0)
+            return b.result()
+        finally:
+            b.free()
+
+
+class Batch:
+    def __init__(self, index, reads_cat, offsets, device=0):
+        self.index = index
+        self.L = index.L
+        reads_cat = np.ascontiguousarray(reads_cat, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.n = len(offsets) - 1
+        self.b = p()
+        _check(self.L.pgx_batch_create(index.h, device, reads_cat.ctypes.data if len(reads_cat) else None,
+                                       offsets.ctypes.data, self.n, C.byref(self.b)))
+
+    def run(self, min_len, min_occ, flags=0, stream=None):
+        _check(self.L.pgx_batch_run(self.b, min_len, min_occ, flags, stream))
+
+    def counts(self):
+        a, b_, c = u64(0), u64(0), u64(0)
+        _check(self.L.pgx_batch_counts(self.b, C.byref(a), C.byref(b_), C.byref(c)))
+        return a.value, b_.value, c.value
+
+    def timing(self):
+        t = Timing()
+        _check(self.L.pgx_batch_timing(self.b, C.byref(t)))
+        return t
+
+    def result(self):
+        r = Result()
+        _check(self.L.pgx_batch_result(self.b, C.byref(r)))
+        n, m = int(r.n_reads), int(r.n_mems)
+        out = dict(n_extensions=int(r.n_extensions), n_tag_overflow=int(r.n_tag_overflow))
+        out["mem_offsets"] = _u64_array(r.mem_offsets, n + 1)
+        out["mems"] = (np.frombuffer(C.string_at(r.mems, m * 32), dtype=MEM_DTYPE).copy() if m else np.zeros(0, MEM_DTYPE))
+        if r.pos_offsets:
+            out["tag_run_counts"] = _u64_array(r.tag_run_counts, m)
+            out["pos_offsets"] = _u64_array(r.pos_offsets, m + 1)
+            out["positions"] = _u64_array(r.positions, int(r.n_positions))
+        return out
+
+    def free(self):
+        if getattr(self, "b", None):
+            self.L.pgx_batch_free(self.b)
+            self.b = None
+
+    __del__ = free

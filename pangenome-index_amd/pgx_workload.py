@@ -1,0 +1,148 @@
+"""Synthetic workloads for tests and bench.py (SURVEY section 8d "Read synthesis" / configs).
+
+No algorithm of the hot path lives here: this module only fabricates inputs (texts, reads, tag
+runs) and drives the build-side entry points of the C ABI to obtain index files.
+"""
+import os
+import struct
+
+import numpy as np
+
+from pgx_ffi import build_rindex, build_rlbwt, write_compact_tags
+
+_COMP = np.arange(256, dtype=np.uint8)
+for a, b in (("A", "T"), ("C", "G"), ("G", "C"), ("T", "A")):
+    _COMP[ord(a)] = ord(b)
+
+
+def read_rlbwt_runs(path):
+    """grlBWT run file -> (symbols uint8[], lengths uint64[])."""
+    d = open(path, "rb").read()
+    bs, bl = struct.unpack_from("<QQ", d, 0)
+    rec = np.frombuffer(d, dtype=np.uint8, offset=16).reshape(-1, bs + bl)
+    sym = rec[:, 0].copy()
+    ln = np.zeros(len(rec), dtype=np.uint64)
+    for b in range(bl):
+        ln |= rec[:, bs + b].astype(np.uint64) << np.uint64(8 * b)
+    return sym, ln
+
+
+def logical_runs(sym, ln):
+    """every endmarker is its own run (src/r-index.cpp:840-848)"""
+    rep = np.where(sym == 10, ln, 1).astype(np.int64)
+    s2 = np.repeat(sym, rep)
+    l2 = np.repeat(np.where(sym == 10, 1, ln).astype(np.uint64), rep)
+    return s2, l2
+
+
+def synthetic_tags_from_runs(rlbwt_path, out_tags_path):
+    """one tag run per logical BWT run, value = (run_id + 1) << 11."""
+    sym, ln = read_rlbwt_runs(rlbwt_path)
+    _, l2 = logical_runs(sym, ln)
+    vals = (np.arange(len(l2), dtype=np.uint64) + np.uint64(1)) << np.uint64(11)
+    write_compact_tags(out_tags_path, vals, l2)
+    return len(l2)
+
+
+def build_index_from_rlbwt(rlbwt_path, workdir, name, encoded=True, with_tags=True):
+    os.makedirs(workdir, exist_ok=True)
+    ri = os.path.join(workdir, name + (".ri" if encoded else ".legacy.ri"))
+    build_rindex(rlbwt_path, ri, encoded)
+    tags = None
+    if with_tags:
+        tags = os.path.join(workdir, name + ".compact.tags")
+        synthetic_tags_from_runs(rlbwt_path, tags)
+    return ri, tags
+
+
+def build_index_from_text(text_path, workdir, name, encoded=True, with_tags=True):
+    os.makedirs(workdir, exist_ok=True)
+    rl = os.path.join(workdir, name + ".rl_bwt")
+    build_rlbwt(text_path, rl)
+    return build_index_from_rlbwt(rl, workdir, name, encoded, with_tags) + (rl,)
+
+
+def load_sequences(text_path):
+    raw = open(text_path, "rb").read()
+    return [np.frombuffer(s, dtype=np.uint8) for s in raw.split(b"\n") if len(s)]
+
+
+def sample_reads(seqs, n_reads, read_len=150, seed=42, sub_rate=0.01, rc_frac=0.5):
+    """150-bp reads sampled from the indexed text, 1 % substitutions, 50 % reverse-complemented.
+
+    Returns (reads uint8[n_reads * read_len], offsets uint64[n_reads + 1])."""
+    rng = np.random.default_rng(seed)
+    ok = [s for s in seqs if len(s) >= read_len]
+    if not ok:
+        raise ValueError("no sequence is long enough for the requested read length")
+    lens = np.array([len(s) for s in ok], dtype=np.int64)
+    cat = np.concatenate(ok)
+    base = np.concatenate(([0], np.cumsum(lens)[:-1]))
+    # positions with >= read_len symbols ahead, uniformly
+    room = lens - read_len + 1
+    which = rng.choice(len(ok), size=n_reads, p=room / room.sum())
+    start = base[which] + (rng.random(n_reads) * room[which]).astype(np.int64)
+    out = np.empty((n_reads, read_len), dtype=np.uint8)
+    step = max(1, (1 << 24) // read_len)
+    ar = np.arange(read_len, dtype=np.int64)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for lo in range(0, n_reads, step):
+        hi = min(n_reads, lo + step)
+        r = cat[start[lo:hi, None] + ar[None, :]]
+        sub = rng.random(r.shape) < sub_rate
+        if sub.any():
+            # uniform over the other three bases (bytes outside ACGT get any base)
+            cur = r[sub]
+            idx = np.searchsorted(acgt, cur)
+            idx = np.where((idx < 4) & (acgt[np.minimum(idx, 3)] == cur), idx, rng.integers(0, 4, size=cur.shape))
+            r = r.copy()
+            r[sub] = acgt[(idx + rng.integers(1, 4, size=cur.shape)) % 4]
+        rc = rng.random(hi - lo) < rc_frac
+        if rc.any():
+            r = r.copy() if not sub.any() else r
+            r[rc] = _COMP[r[rc][:, ::-1]]
+        out[lo:hi] = r
+    offsets = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len)
+    return out.reshape(-1), offsets
+
+
+def synth_pangenome_text(path, base_len=4_000_000, n_hap=8, seed=45, gc=0.41, snp=1e-3, indel=1e-4, n_runs=4,
+                         n_run_len=(1000, 50000)):
+    """SURVEY 8d config 3 recipe, scaled by base_len: i.i.d. base sequence with N runs, n_hap
+    haplotypes with SNPs and indels, every haplotype in both orientations (so sigma = 6 and the
+    index is a proper FMD index).  Writes newline-terminated sequences; returns their count."""
+    rng = np.random.default_rng(seed)
+    p = np.array([(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2])
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    basev = acgt[rng.choice(4, size=base_len, p=p)].copy()
+    for _ in range(n_runs):
+        ln = int(rng.integers(n_run_len[0], n_run_len[1]))
+        ln = min(ln, base_len // (4 * n_runs) + 1)
+        st = int(rng.integers(0, max(1, base_len - ln)))
+        basev[st:st + ln] = ord("N")
+    with open(path, "wb") as f:
+        for _h in range(n_hap):
+            hap = basev.copy()
+            m = rng.random(base_len) < snp
+            hap[m] = acgt[rng.integers(0, 4, size=int(m.sum()))]
+            # indels: deletions drop 1..k bases, insertions add random bases
+            nind = rng.binomial(base_len, indel)
+            if nind:
+                pos = np.sort(rng.choice(base_len, size=nind, replace=False))
+                lens = rng.geometric(1 / 3.0, size=nind)
+                isdel = rng.random(nind) < 0.5
+                pieces, prev = [], 0
+                for q, ln, dl in zip(pos, lens, isdel):
+                    if q < prev:
+                        continue
+                    pieces.append(hap[prev:q])
+                    if dl:
+                        prev = min(base_len, q + int(ln))
+                    else:
+                        pieces.append(acgt[rng.integers(0, 4, size=int(ln))])
+                        prev = q
+                pieces.append(hap[prev:])
+                hap = np.concatenate(pieces)
+            f.write(hap.tobytes()); f.write(b"\n")
+            f.write(_COMP[hap[::-1]].tobytes()); f.write(b"\n")
+    return 2 * n_hap

@@ -1,0 +1,173 @@
+"""Pure-Python walk of the flat device image (pgx_image.h) -- TEST INFRASTRUCTURE ONLY.
+
+Lets the CPU-only test tier check the *image* (blocks, directory, extension tables) that
+pgx_index_open builds against the oracle, without a GPU.  It mirrors pgx_rank_ab / pgx_extend of
+pgx_kernels.hip line for line; it is never used by the product.
+"""
+import struct
+
+import numpy as np
+
+RUN_LEN_BITS, RUN_LEN_MAX, BLOCK_RUNS = 13, 8191, 16
+M64 = (1 << 64) - 1
+
+
+class Consts:
+    """PgxConsts of pgx_image.h"""
+
+    def __init__(self, raw):
+        raw = bytes(raw)
+        o = 0
+        self.n, = struct.unpack_from("<Q", raw, o); o += 8
+        self.C = struct.unpack_from("<8Q", raw, o); o += 64
+        self.ext_tab = struct.unpack_from("<512I", raw, o); o += 2048
+        self.slot_code = struct.unpack_from("<8I", raw, o); o += 32
+        self.sigma, self.excl_mask, self.dir_shift, self.n_blocks = struct.unpack_from("<4I", raw, o); o += 16
+        self.dir_entries, = struct.unpack_from("<Q", raw, o); o += 8
+        self.n_tag_runs, self.tag_dir_entries = struct.unpack_from("<2Q", raw, o); o += 16
+        self.tag_dir_shift, self.has_tags, self.mode, _ = struct.unpack_from("<4I", raw, o); o += 16
+        assert o == len(raw), (o, len(raw))
+
+
+class ImageEmu:
+    def __init__(self, index):
+        self.c = Consts(index.image_view(6))
+        self.blocks = index.image_view(0).view(np.uint32).reshape(-1, 16)
+        self.dir = index.image_view(1)
+        self.bstart = index.image_view(2)
+        self.tstart = index.image_view(3)
+        self.tvals = index.image_view(4)
+        self.tdir = index.image_view(5)
+
+    def block_counts(self, b):
+        dw = [int(x) for x in self.blocks[b]]
+        c = [dw[i] for i in range(6)]
+        for i in range(4):
+            c[i] |= ((dw[6] >> (8 * i)) & 0xFF) << 32
+        c[4] |= (dw[7] & 0xFF) << 32
+        c[5] |= ((dw[7] >> 8) & 0xFF) << 32
+        ents = []
+        for e in range(BLOCK_RUNS):
+            v = (dw[8 + e // 2] >> (16 * (e & 1))) & 0xFFFF
+            ents.append((v >> RUN_LEN_BITS, v & RUN_LEN_MAX))
+        return c, ents, (dw[7] >> 16) & 0x1F
+
+    def find_block(self, pos):
+        c = self.c
+        di = pos >> c.dir_shift
+        lo, hi = int(self.dir[di]), int(self.dir[di + 1])
+        while lo < hi:
+            mid = (lo + hi + 1) >> 1
+            if int(self.bstart[mid]) <= pos:
+                lo = mid
+            else:
+                hi = mid - 1
+        return lo
+
+    def rank_ab(self, pos, cv, mrow):
+        c = self.c
+        pos = min(pos, c.n)
+        b = self.find_block(pos)
+        cnt, ents, _ = self.block_counts(b)
+        start = sum(cnt[i] for i in range(6) if not (c.excl_mask >> i) & 1)
+        assert start == int(self.bstart[b]), (b, start, int(self.bstart[b]))
+        A = cnt[cv]
+        B = sum(cnt[i] * ((mrow >> (3 * i)) & 7) for i in range(6))
+        rel = pos - start
+        assert 0 <= rel <= BLOCK_RUNS * RUN_LEN_MAX
+        for code, ln in ents:
+            take = min(ln, rel)
+            rel -= take
+            if code == cv:
+                A += take
+            B += take * ((mrow >> (3 * code)) & 7)
+        return A & M64, B & M64
+
+    def rank6_true(self, pos):
+        return [self.rank_ab(pos, code, 0)[0] for code in range(6)]
+
+    def rank_cache(self, pos):
+        return [self.rank_ab(pos, self.c.slot_code[i], 0)[0] for i in range(self.c.sigma)]
+
+    def extend(self, tri, byte, fwd):
+        k, kp, s = tri
+        e = self.c.ext_tab[(256 if fwd else 0) + byte]
+        cv, v, mrow, kill = e & 7, (e >> 3) & 7, (e >> 6) & 0x3FFFF, (e >> 24) & 1
+        kk, kq = (kp, k) if fwd else (k, kp)
+        A1, B1 = self.rank_ab((kk + s) & M64, cv, mrow)
+        A0, B0 = self.rank_ab(kk, cv, mrow)
+        if kill or A0 >= A1:
+            return (0, 0, 0)
+        nk = (A0 + self.c.C[v]) & M64
+        nq = (kq + B1 - B0) & M64
+        ns = A1 - A0
+        return (nq, nk, ns) if fwd else (nk, nq, ns)
+
+    def find_all_mems(self, read, min_len, min_occ):
+        """state machine of pgx_find_mems_kernel, one read"""
+        b = read.encode() if isinstance(read, str) else bytes(read)
+        ln, n = len(b), self.c.n
+        out, x, next_ = [], 0, 0
+        while True:
+            if x >= ln or (ln - x) < min_len:
+                break
+            tri = (0, 0, n)
+            restart = None
+            if min_len > 0:
+                j = x + min_len - 1
+                while True:
+                    tri = self.extend(tri, b[j] if j < ln else 0, False); next_ += 1
+                    if tri[2] < min_occ or tri[2] == 0:
+                        restart = j + 1; break
+                    if j == x:
+                        break
+                    j -= 1
+            if restart is not None:
+                x = restart; continue
+            J = tri
+            j = x + min_len
+            while j < ln:
+                tri = self.extend(tri, b[j], True); next_ += 1
+                if tri[2] < min_occ or tri[2] == 0:
+                    break
+                J = tri; j += 1
+            e = j
+            out.append((x, e, J[0], J[2]))
+            tri = (0, 0, n)
+            j = e
+            nxt = x + 1
+            while j > x:
+                tri = self.extend(tri, b[j] if j < ln else 0, False); next_ += 1
+                if tri[2] < min_occ or tri[2] == 0:
+                    nxt = j + 1; break
+                j -= 1
+            x = nxt
+        return out, next_
+
+    # tags
+    def tag_rank(self, x):
+        c = self.c
+        di = x >> c.tag_dir_shift
+        if di + 1 >= c.tag_dir_entries:
+            return c.n_tag_runs
+        lo, hi = int(self.tdir[di]), int(self.tdir[di + 1])
+        while lo < hi:
+            mid = (lo + hi) >> 1
+            if int(self.tstart[mid]) <= x:
+                lo = mid + 1
+            else:
+                hi = mid
+        return lo
+
+    def tag_query(self, start, end):
+        f, g = self.tag_rank(start), self.tag_rank(end)
+        cnt = g - f + 1
+        first = f - 1 if f % 10 else f
+        vals, over = [], False
+        for t in range(cnt):
+            it = first + t
+            if it < len(self.tvals):
+                vals.append(int(self.tvals[it]))
+            else:
+                vals.append(0); over = True
+        return cnt, sorted(set(vals)), over

@@ -224,10 +224,10 @@ def find_mems_batch(ri, tags, reads_cat, offsets, min_len, min_occ, mode=MODE_CO
                seconds_mems=float(r.seconds_mems), seconds_tags=float(r.seconds_tags),
                n_tag_overflow=int(r.n_tag_overflow))
     if tags is not None:
-        out["tag_run_counts"] = np.ctypeslib.as_array(r.tag_run_counts, shape=(max(nm, 1),))[:nm].copy()
+        out["tag_run_counts"] = (np.ctypeslib.as_array(r.tag_run_counts, shape=(nm,)).copy() if nm else np.zeros(0, np.uint64))
         po = np.ctypeslib.as_array(r.pos_offsets, shape=(nm + 1,)).copy()
         out["pos_offsets"] = po
         npz = int(po[-1])
-        out["positions"] = (np.ctypeslib.as_array(r.positions, shape=(max(npz, 1),))[:npz].copy())
+        out["positions"] = (np.ctypeslib.as_array(r.positions, shape=(npz,)).copy() if npz else np.zeros(0, np.uint64))
     L.orc_batch_free(res)
     return out
