@@ -82,6 +82,9 @@ void RiFile::parse(const uint8_t *p, uint64_t n) {
             if (loc > end || end > nbytes) throw Error(PGX_ERR_FORMAT, "encoded block offsets not monotone");
             RefBlock blk;
             blk.cum.resize(sigma);
+            // a trailing never-filled block (total_runs % 10 == 0) holds 8 zero varints and no runs
+            // (Run_blocks() default, r-index.hpp:144); no query ever reaches it (quirk 9)
+            if (b >= blocks_start_pos.ones.size()) { blocks.push_back(std::move(blk)); continue; }
             for (uint64_t i = 0; i < sigma && loc < end; i++) blk.cum[i] = bytecode_read(s, end, loc, "encoded block header");
             while (loc < end) {
                 uint8_t h = s[loc++];

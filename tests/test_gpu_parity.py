@@ -195,3 +195,23 @@ def test_config2_one_million_reads(xenc, golden):
     ref = O.find_mems_batch(ri, tags, cat, offs, 20, 1, threads=O.lib().orc_max_threads())
     res = idx.find_mems(cat, offs, 20, 1, tags=True)
     _assert_same(res, ref, True)
+
+
+def test_sharded_equals_unsharded(xenc, golden):
+    """contiguous read slices processed independently and concatenated in rank order are
+    bit-identical to the unsharded batch (what bench.py --gpus N relies on)."""
+    import pgx_shard as S
+
+    idx, ri, tags = xenc
+    seqs = W.load_sequences(os.path.join(golden, "x.newline_separated"))
+    cat, offs = W.sample_reads(seqs, 30001, 150, seed=99)
+    whole = idx.find_mems(cat, offs, 10, 1, tags=True)
+    for world in (2, 3, 8):
+        parts = []
+        for rank in range(world):
+            c, o = S.shard_reads(cat, offs, rank, world)
+            parts.append(idx.find_mems(c, o, 10, 1, tags=True))
+        merged = S.merge_results(parts)
+        _assert_same(merged, whole, True)
+    ref = O.find_mems_batch(ri, tags, cat, offs, 10, 1, threads=O.lib().orc_max_threads())
+    _assert_same(whole, ref, True)
