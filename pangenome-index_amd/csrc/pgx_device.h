@@ -41,14 +41,20 @@ __global__ void pgx_scan_apply_kernel(int mode, const void *in, uint64_t n, uint
                                       uint64_t nb, uint64_t *out);
 __global__ void pgx_compact_mems_kernel(uint64_t n_reads, const uint64_t *slot_off, const pgx_mem *slots,
                                         const uint32_t *mem_count, const uint64_t *mem_off, pgx_mem *mems);
+#define PGX_SORT_LDS_CAP 2048 // values per wave sorted in an LDS slice (pgx_tag_sort_unique_kernel)
+#define PGX_TAG_SMALL 16      // queries with at most this many runs take the 16-lane path
+
 __global__ void pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *mems, const uint64_t *qstart, const uint64_t *qend,
-                                      uint64_t n, uint64_t *run_nums, uint64_t *first_item);
-__global__ void pgx_tag_gather_kernel(PgxDevImage img, uint64_t n, const uint64_t *run_nums, const uint64_t *first_item,
-                                      const uint64_t *seg_off, uint64_t *buf, unsigned long long *n_overflow);
-__global__ void pgx_tag_sort_unique_kernel(uint64_t n, const uint64_t *run_nums, const uint64_t *seg_off, uint64_t *buf,
-                                           uint64_t *scratch, const uint64_t *scratch_off, uint64_t *ucount);
+                                      uint64_t n, uint64_t *run_nums, uint64_t *first_item, uint64_t *need, uint64_t *big_list,
+                                      unsigned long long *n_big);
+__global__ void pgx_tag_small_kernel(PgxDevImage img, uint64_t n, const uint64_t *run_nums, const uint64_t *first_item,
+                                     const uint64_t *seg_off, uint64_t *buf, uint64_t *ucount, unsigned long long *n_overflow);
+__global__ void pgx_tag_gather_kernel(PgxDevImage img, const uint64_t *list, uint64_t n_list, const uint64_t *run_nums,
+                                      const uint64_t *first_item, const uint64_t *seg_off, uint64_t *buf,
+                                      unsigned long long *n_overflow);
+__global__ void pgx_tag_sort_unique_kernel(const uint64_t *list, uint64_t n_list, const uint64_t *run_nums, const uint64_t *seg_off,
+                                           uint64_t *buf, uint64_t *scratch, const uint64_t *scratch_off, uint64_t *ucount);
 __global__ void pgx_tag_compact_kernel(uint64_t n, const uint64_t *ucount, const uint64_t *seg_off, const uint64_t *buf,
                                        const uint64_t *pos_off, uint64_t *positions);
-__global__ void pgx_tag_scratch_need_kernel(uint64_t n, const uint64_t *run_nums, uint64_t *need);
 
 #define PGX_SCAN_BLOCK_ITEMS 2048 // 256 threads x 8 items (pgx_kernels.hip PGX_SCAN_ITEMS)

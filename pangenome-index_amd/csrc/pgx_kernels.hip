@@ -65,6 +65,72 @@ __device__ __forceinline__ void pgx_rank_ab(const PgxDevImage &img, const uint4 
     B = b + ib;
 }
 
+// The two rank probes of one extension, rank(pos0) and rank(pos1) with pos1 = pos0 + s.  Once the
+// interval is narrow (s ~ number of haplotypes) both positions fall into the same 64-byte block,
+// so the block of pos0 is decoded once for both; only when pos1 lies beyond it (or the interval
+// wrapped) are two independent probes made.  Outputs A0, A1 (counts of code cv) and B1 - B0.
+template <bool LDS_IMAGE>
+__device__ __forceinline__ void pgx_rank_pair(const PgxDevImage &img, const uint4 *__restrict__ lds_blocks,
+                                              const uint32_t *__restrict__ lds_dir, const uint64_t *__restrict__ lds_bstart,
+                                              uint64_t pos0, uint64_t pos1, uint32_t cv, uint32_t mrow, uint64_t &A0,
+                                              uint64_t &A1, uint64_t &dB) {
+    const uint64_t p0 = pos0 > img.n ? img.n : pos0, p1 = pos1 > img.n ? img.n : pos1;
+    const uint64_t di = p0 >> img.dir_shift;
+    uint32_t lo, hi;
+    if (LDS_IMAGE) { lo = lds_dir[di]; hi = lds_dir[di + 1]; }
+    else { lo = img.dir[di]; hi = img.dir[di + 1]; }
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        const uint64_t st = LDS_IMAGE ? lds_bstart[mid] : img.bstart[mid];
+        if (st <= p0) lo = mid; else hi = mid - 1;
+    }
+    const uint4 *bp = (LDS_IMAGE ? lds_blocks : img.blocks) + (size_t)lo * 4;
+    const uint4 h0 = bp[0], h1 = bp[1], r0 = bp[2], r1 = bp[3];
+    uint64_t c[6];
+    c[0] = (uint64_t)h0.x | ((uint64_t)(h1.z & 0xFFu) << 32);
+    c[1] = (uint64_t)h0.y | ((uint64_t)((h1.z >> 8) & 0xFFu) << 32);
+    c[2] = (uint64_t)h0.z | ((uint64_t)((h1.z >> 16) & 0xFFu) << 32);
+    c[3] = (uint64_t)h0.w | ((uint64_t)(h1.z >> 24) << 32);
+    c[4] = (uint64_t)h1.x | ((uint64_t)(h1.w & 0xFFu) << 32);
+    c[5] = (uint64_t)h1.y | ((uint64_t)((h1.w >> 8) & 0xFFu) << 32);
+    uint64_t start = 0, a = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        start += ((img.excl_mask >> i) & 1u) ? 0ull : c[i];
+        a = (cv == (uint32_t)i) ? c[i] : a;
+    }
+    uint32_t rel0 = (uint32_t)(p0 - start);
+    const uint64_t d1 = p1 - start; // wraps to a huge value when p1 < start
+    uint32_t rel1 = d1 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d1;
+    uint32_t ia0 = 0, ia1 = 0, idb = 0, total = 0;
+    const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+    for (int e = 0; e < PGX_BLOCK_RUNS; e++) {
+        const uint32_t v = (rw[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
+        const uint32_t code = v >> PGX_RUN_LEN_BITS, len = v & PGX_RUN_LEN_MAX;
+        const uint32_t t0 = min(len, rel0), t1 = min(len, rel1);
+        total += len;
+        rel0 -= t0;
+        rel1 -= t1;
+        const bool hit = (code == cv);
+        ia0 += hit ? t0 : 0u;
+        ia1 += hit ? t1 : 0u;
+        idb += (t1 - t0) * ((mrow >> (3 * code)) & 7u); // modulo 2^32; |true value| < 2^20
+    }
+    // pos1 is served by this block when it lies strictly inside it (a probe AT the block end belongs
+    // to the next block, whose header may carry a different quirk value), or at the end of the BWT
+    if (d1 < (uint64_t)total || (rel1 == 0 && lo + 1 == img.n_blocks)) {
+        A0 = a + ia0;
+        A1 = a + ia1;
+        dB = (uint64_t)(int64_t)(int32_t)idb;
+        return;
+    }
+    uint64_t B0, B1;
+    pgx_rank_ab<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_bstart, pos1, cv, mrow, A1, B1);
+    pgx_rank_ab<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_bstart, pos0, cv, mrow, A0, B0);
+    dB = B1 - B0;
+}
+
 // one FMD extension of (k, kp, s) by `byte` (backward, or forward = backward on the swapped
 // interval by the complement, folded into ext_tab[256 + byte]).  Returns the new size (0 = empty).
 template <bool LDS_IMAGE>
@@ -74,14 +140,13 @@ __device__ __forceinline__ void pgx_extend(const PgxDevImage &img, const uint4 *
     const uint32_t e = s_ext[(fwd ? 256u : 0u) + byte];
     const uint32_t cv = PGX_EXT_CV(e), mrow = PGX_EXT_M(e);
     const uint64_t kk = fwd ? kp : k, kq = fwd ? k : kp;
-    uint64_t A1, B1, A0, B0;
-    pgx_rank_ab<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_bstart, kk + s, cv, mrow, A1, B1);
-    pgx_rank_ab<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_bstart, kk, cv, mrow, A0, B0);
+    uint64_t A1, A0, dB;
+    pgx_rank_pair<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_bstart, kk, kk + s, cv, mrow, A0, A1, dB);
     if (PGX_EXT_KILL(e) || A0 >= A1) { // rank_k >= rank_ks -> bi_interval(0,0,0), src/r-index.cpp:751
         k = 0; kp = 0; s = 0;
         return;
     }
-    const uint64_t nk = A0 + s_C[PGX_EXT_V(e)], nq = kq + (B1 - B0);
+    const uint64_t nk = A0 + s_C[PGX_EXT_V(e)], nq = kq + dB;
     s = A1 - A0;
     k = fwd ? nq : nk;
     kp = fwd ? nk : nq;
@@ -336,156 +401,3 @@ pgx_compact_mems_kernel(uint64_t n_reads, const uint64_t *__restrict__ slot_off,
     for (uint32_t t = 0; t < c; t++) mems[dst + t] = slots[src + t];
 }
 
-// ------------------------------------------------------------------------------------------
-// tag array.  rank_1(bwt_intervals, x + 1) = number of run starts <= x  (src/tag_arrays.cpp:857-858)
-__device__ __forceinline__ uint64_t pgx_tag_rank(const PgxDevImage &img, uint64_t x) {
-    const uint64_t nr = img.n_tag_runs;
-    uint64_t di = x >> img.tag_dir_shift;
-    if (di + 1 >= img.tag_dir_entries) return nr; // beyond bwt_intervals.size(): all ones
-    uint64_t lo = img.tdir[di], hi = img.tdir[di + 1];
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (img.tstart[mid] <= x) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
-// per query: run_nums (number_of_runs, :860) and the index of the first item read (:862-874,
-// including the off-by-one when first_bit_index % 10 == 0)
-__global__ void __launch_bounds__(256)
-pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *__restrict__ mems, const uint64_t *__restrict__ qstart,
-                      const uint64_t *__restrict__ qend, uint64_t n, uint64_t *__restrict__ run_nums, uint64_t *__restrict__ first_item) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t st, en;
-    if (mems) { st = mems[i].bwt_start; en = st + (uint64_t)mems[i].size - 1; } // find_mems.cpp:129
-    else { st = qstart[i]; en = qend[i]; }
-    const uint64_t f = pgx_tag_rank(img, st), g = pgx_tag_rank(img, en);
-    run_nums[i] = g - f + 1;
-    first_item[i] = (f % 10) ? f - 1 : f;
-}
-
-// one wave per query: gather run values into its segment of `buf`
-__global__ void __launch_bounds__(256)
-pgx_tag_gather_kernel(PgxDevImage img, uint64_t n, const uint64_t *__restrict__ run_nums, const uint64_t *__restrict__ first_item,
-                      const uint64_t *__restrict__ seg_off, uint64_t *__restrict__ buf, unsigned long long *__restrict__ n_overflow) {
-    const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (q >= n) return;
-    const uint64_t cnt = run_nums[q], src = first_item[q], dst = seg_off[q];
-    bool over = false;
-    for (uint64_t t = lane; t < cnt; t += 64) {
-        const uint64_t it = src + t;
-        uint64_t v = 0;
-        if (it < img.n_tag_items) v = img.tvals[it]; else over = true; // reference reads past the end (UB): value 0
-        buf[dst + t] = v;
-    }
-    if (__any(over) && lane == 0) atomicAdd(n_overflow, 1ull);
-}
-
-__device__ __forceinline__ void pgx_cmpswap(uint64_t &a, uint64_t &b, bool up) {
-    if ((a > b) == up) { const uint64_t t = a; a = b; b = t; }
-}
-
-// bitonic sort of cnt values (padded to p2 with ~0) by ONE wave in `arr`, then duplicates dropped
-// and the unique prefix written back to `seg` in chunks of 64 (write index never passes read index)
-template <class Ptr>
-__device__ __forceinline__ uint64_t pgx_wave_sort_unique(Ptr arr, uint64_t *__restrict__ seg, uint64_t cnt, uint64_t p2, int lane) {
-    for (uint64_t t = lane; t < p2; t += 64) arr[t] = t < cnt ? seg[t] : ~0ull;
-    __threadfence_block();
-    __builtin_amdgcn_wave_barrier();
-    for (uint64_t k = 2; k <= p2; k <<= 1) {
-        for (uint64_t jj = k >> 1; jj > 0; jj >>= 1) {
-            for (uint64_t t = lane; t < p2 / 2; t += 64) {
-                // t-th compare-exchange pair of this stage
-                const uint64_t lo_i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
-                const uint64_t hi_i = lo_i | jj;
-                const uint64_t a = arr[lo_i], b = arr[hi_i];
-                const bool up = ((lo_i & k) == 0);
-                if ((a > b) == up) { arr[lo_i] = b; arr[hi_i] = a; }
-            }
-            __threadfence_block();
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    uint64_t outn = 0;
-    for (uint64_t b0 = 0; b0 < cnt; b0 += 64) {
-        const uint64_t t = b0 + lane;
-        const uint64_t v = t < cnt ? arr[t] : 0;
-        const uint64_t prev = (t > 0 && t < cnt) ? arr[t - 1] : 0;
-        const bool keep = t < cnt && (t == 0 || v != prev);
-        const unsigned long long mask = __ballot(keep);
-        const int at = __popcll(mask & ((1ull << lane) - 1ull));
-        if (keep) seg[outn + at] = v;
-        outn += (uint64_t)__popcll(mask);
-    }
-    return outn;
-}
-
-// one wave per query: sort its segment and drop duplicates in place; ucount[q] = #unique.
-//   cnt <= 64        bitonic network in registers (cross-lane shuffles)
-//   cnt <= LDS_CAP   bitonic in LDS (per-wave slice)
-//   otherwise        bitonic in global memory (rare: a short MEM with a huge SA interval)
-#define PGX_SORT_LDS_CAP 2048
-__global__ void __launch_bounds__(256)
-pgx_tag_sort_unique_kernel(uint64_t n, const uint64_t *__restrict__ run_nums, const uint64_t *__restrict__ seg_off,
-                           uint64_t *__restrict__ buf, uint64_t *__restrict__ scratch, const uint64_t *__restrict__ scratch_off,
-                           uint64_t *__restrict__ ucount) {
-    __shared__ uint64_t s_sort[4][PGX_SORT_LDS_CAP];
-    const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (q >= n) return;
-    const uint64_t cnt = run_nums[q];
-    uint64_t *seg = buf + seg_off[q];
-    if (cnt <= 64) {
-        uint64_t v = (uint64_t)lane < cnt ? seg[lane] : ~0ull;
-#pragma unroll
-        for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-            for (int jj = k >> 1; jj > 0; jj >>= 1) {
-                const uint64_t o = __shfl_xor(v, jj, 64);
-                const bool up = ((lane & k) == 0);
-                const bool lower = ((lane & jj) == 0);
-                const uint64_t mn = v < o ? v : o, mx = v < o ? o : v;
-                v = (lower == up) ? mn : mx;
-            }
-        }
-        const uint64_t prev = __shfl_up(v, 1, 64);
-        const bool keep = (uint64_t)lane < cnt && (lane == 0 || v != prev);
-        const unsigned long long mask = __ballot(keep);
-        const int at = __popcll(mask & ((1ull << lane) - 1ull));
-        if (keep) seg[at] = v;
-        if (lane == 0) ucount[q] = (uint64_t)__popcll(mask);
-        return;
-    }
-    // power-of-two padded bitonic sort by one wave (LDS slice or global scratch); the two calls are
-    // separate inlined copies so that each keeps a statically known address space
-    uint64_t p2 = 64;
-    while (p2 < cnt) p2 <<= 1;
-    uint64_t outn;
-    if (p2 <= PGX_SORT_LDS_CAP) outn = pgx_wave_sort_unique(&s_sort[w][0], seg, cnt, p2, lane);
-    else outn = pgx_wave_sort_unique(scratch + scratch_off[q], seg, cnt, p2, lane);
-    if (lane == 0) ucount[q] = outn;
-}
-
-// one wave per query: copy the unique prefix of its segment to the dense positions array
-__global__ void __launch_bounds__(256)
-pgx_tag_compact_kernel(uint64_t n, const uint64_t *__restrict__ ucount, const uint64_t *__restrict__ seg_off,
-                       const uint64_t *__restrict__ buf, const uint64_t *__restrict__ pos_off, uint64_t *__restrict__ positions) {
-    const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (q >= n) return;
-    const uint64_t c = ucount[q], src = seg_off[q], dst = pos_off[q];
-    for (uint64_t t = lane; t < c; t += 64) positions[dst + t] = buf[src + t];
-}
-
-// scratch requirement of the global bitonic path: next pow2 of cnt when it exceeds the LDS cap
-__global__ void __launch_bounds__(256)
-pgx_tag_scratch_need_kernel(uint64_t n, const uint64_t *__restrict__ run_nums, uint64_t *__restrict__ need) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t cnt = run_nums[i];
-    uint64_t p2 = 64;
-    while (p2 < cnt) p2 <<= 1;
-    need[i] = p2 > PGX_SORT_LDS_CAP ? p2 : 0;
-}

@@ -192,6 +192,72 @@ static inline unsigned grid_for(uint64_t n, unsigned per_block) {
 }
 
 // ------------------------------------------------------------------------------------------
+// tag pipeline shared by pgx_batch_run and pgx_tag_query_batch
+struct TagWork {
+    DevBuf run_nums, first_item, seg_off, gbuf, need, scratch_off, scratch, ucount, pos_off, positions, big_list, scan_tmp;
+    uint64_t n_positions = 0, n_big = 0;
+    void release() {
+        DevBuf *all[] = {&run_nums, &first_item, &seg_off, &gbuf, &need, &scratch_off, &scratch, &ucount, &pos_off, &positions,
+                         &big_list, &scan_tmp};
+        for (DevBuf *d : all) d->release();
+    }
+};
+
+// counters: [0] overflow count, [1] big-list length (both zeroed by the caller on the stream)
+template <class Rec>
+static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const uint64_t *d_qs, const uint64_t *d_qe, uint64_t m,
+                         TagWork &w, unsigned long long *d_nover, unsigned long long *d_nbig, hipStream_t s, Rec &&rec) {
+    w.run_nums.ensure((m ? m : 1) * 8);
+    w.first_item.ensure((m ? m : 1) * 8);
+    w.seg_off.ensure((m + 1) * 8);
+    w.need.ensure((m ? m : 1) * 8);
+    w.scratch_off.ensure((m + 1) * 8);
+    w.ucount.ensure((m ? m : 1) * 8);
+    w.pos_off.ensure((m + 1) * 8);
+    w.big_list.ensure((m ? m : 1) * 8);
+    if (m) {
+        hipLaunchKernelGGL(pgx_tag_locate_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, img, d_mems, d_qs, d_qe, m,
+                           w.run_nums.as<uint64_t>(), w.first_item.as<uint64_t>(), w.need.as<uint64_t>(), w.big_list.as<uint64_t>(), d_nbig);
+        HIPCHECK(hipGetLastError());
+    }
+    scan_excl(1, w.run_nums.p, m, 0, w.seg_off.as<uint64_t>(), w.scan_tmp, s);
+    scan_excl(1, w.need.p, m, 0, w.scratch_off.as<uint64_t>(), w.scan_tmp, s);
+    uint64_t hv[3] = {0, 0, 0};
+    HIPCHECK(hipMemcpyAsync(&hv[0], w.seg_off.as<uint64_t>() + m, 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(&hv[1], w.scratch_off.as<uint64_t>() + m, 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(&hv[2], d_nbig, 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    const uint64_t G = hv[0], S = hv[1], nbig = hv[2];
+    w.n_big = nbig;
+    rec(0);
+    w.gbuf.ensure((G ? G : 1) * 8);
+    w.scratch.ensure((S ? S : 1) * 8);
+    if (m) {
+        hipLaunchKernelGGL(pgx_tag_small_kernel, dim3(grid_for(m, 16)), dim3(256), 0, s, img, m, w.run_nums.as<uint64_t>(),
+                           w.first_item.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.ucount.as<uint64_t>(), d_nover);
+        HIPCHECK(hipGetLastError());
+    }
+    rec(1);
+    if (nbig) {
+        hipLaunchKernelGGL(pgx_tag_gather_kernel, dim3(grid_for(nbig, 4)), dim3(256), 0, s, img, w.big_list.as<uint64_t>(), nbig,
+                           w.run_nums.as<uint64_t>(), w.first_item.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), d_nover);
+        hipLaunchKernelGGL(pgx_tag_sort_unique_kernel, dim3(grid_for(nbig, 4)), dim3(256), 0, s, w.big_list.as<uint64_t>(), nbig,
+                           w.run_nums.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.scratch.as<uint64_t>(),
+                           w.scratch_off.as<uint64_t>(), w.ucount.as<uint64_t>());
+        HIPCHECK(hipGetLastError());
+    }
+    scan_excl(1, w.ucount.p, m, 0, w.pos_off.as<uint64_t>(), w.scan_tmp, s);
+    w.n_positions = read_u64(w.pos_off.as<uint64_t>() + m, s);
+    w.positions.ensure((w.n_positions ? w.n_positions : 1) * 8);
+    if (m) {
+        hipLaunchKernelGGL(pgx_tag_compact_kernel, dim3(grid_for(m, 16)), dim3(256), 0, s, m, w.ucount.as<uint64_t>(),
+                           w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.pos_off.as<uint64_t>(), w.positions.as<uint64_t>());
+        HIPCHECK(hipGetLastError());
+    }
+    rec(2);
+}
+
+// ------------------------------------------------------------------------------------------
 struct pgx_batch {
     pgx_index *h = nullptr;
     pgx_device_image *dimg = nullptr;
@@ -200,7 +266,7 @@ struct pgx_batch {
     DevBuf reads, offsets;
     // run state
     DevBuf slot_off, slots, mem_count, mem_off, mems, scan_tmp, counters;
-    DevBuf run_nums, first_item, seg_off, gbuf, need, scratch_off, scratch, ucount, pos_off, positions;
+    TagWork tw;
     uint64_t n_mems = 0, n_positions = 0, n_ext = 0, n_tag_overflow = 0;
     bool ran = false, ran_tags = false;
     // host copies
@@ -216,9 +282,9 @@ static void batch_release(pgx_batch *b) {
     if (!b) return;
     if (hipSetDevice(b->device) == hipSuccess) {
         DevBuf *all[] = {&b->reads, &b->offsets, &b->slot_off, &b->slots, &b->mem_count, &b->mem_off, &b->mems, &b->scan_tmp,
-                         &b->counters, &b->run_nums, &b->first_item, &b->seg_off, &b->gbuf, &b->need, &b->scratch_off,
-                         &b->scratch, &b->ucount, &b->pos_off, &b->positions};
+                         &b->counters};
         for (DevBuf *d : all) d->release();
+        b->tw.release();
         for (auto &e : b->ev)
             if (e) { (void)hipEventDestroy(e); e = nullptr; }
     }
@@ -320,51 +386,10 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     record(b, 3, s);
     // 4. tag queries (find_mems.cpp:129)
     if (want_tags) {
-        const uint64_t m = b->n_mems;
-        b->run_nums.ensure((m ? m : 1) * 8);
-        b->first_item.ensure((m ? m : 1) * 8);
-        b->seg_off.ensure((m + 1) * 8);
-        b->need.ensure((m ? m : 1) * 8);
-        b->scratch_off.ensure((m + 1) * 8);
-        b->ucount.ensure((m ? m : 1) * 8);
-        b->pos_off.ensure((m + 1) * 8);
-        if (m) {
-            hipLaunchKernelGGL(pgx_tag_locate_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, img, b->mems.as<pgx_mem>(),
-                               (const uint64_t *)nullptr, (const uint64_t *)nullptr, m, b->run_nums.as<uint64_t>(),
-                               b->first_item.as<uint64_t>());
-            hipLaunchKernelGGL(pgx_tag_scratch_need_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, m, b->run_nums.as<uint64_t>(),
-                               b->need.as<uint64_t>());
-            HIPCHECK(hipGetLastError());
-        }
-        scan_excl(1, b->run_nums.p, m, 0, b->seg_off.as<uint64_t>(), b->scan_tmp, s);
-        scan_excl(1, b->need.p, m, 0, b->scratch_off.as<uint64_t>(), b->scan_tmp, s);
-        const uint64_t G = read_u64(b->seg_off.as<uint64_t>() + m, s);
-        const uint64_t S = read_u64(b->scratch_off.as<uint64_t>() + m, s);
-        record(b, 4, s);
-        b->gbuf.ensure((G ? G : 1) * 8);
-        b->scratch.ensure((S ? S : 1) * 8);
-        if (m) {
-            hipLaunchKernelGGL(pgx_tag_gather_kernel, dim3(grid_for(m, 4)), dim3(256), 0, s, img, m, b->run_nums.as<uint64_t>(),
-                               b->first_item.as<uint64_t>(), b->seg_off.as<uint64_t>(), b->gbuf.as<uint64_t>(), d_nover);
-            HIPCHECK(hipGetLastError());
-        }
-        record(b, 5, s);
-        if (m) {
-            hipLaunchKernelGGL(pgx_tag_sort_unique_kernel, dim3(grid_for(m, 4)), dim3(256), 0, s, m, b->run_nums.as<uint64_t>(),
-                               b->seg_off.as<uint64_t>(), b->gbuf.as<uint64_t>(), b->scratch.as<uint64_t>(),
-                               b->scratch_off.as<uint64_t>(), b->ucount.as<uint64_t>());
-            HIPCHECK(hipGetLastError());
-        }
-        scan_excl(1, b->ucount.p, m, 0, b->pos_off.as<uint64_t>(), b->scan_tmp, s);
-        b->n_positions = read_u64(b->pos_off.as<uint64_t>() + m, s);
-        b->positions.ensure((b->n_positions ? b->n_positions : 1) * 8);
-        if (m) {
-            hipLaunchKernelGGL(pgx_tag_compact_kernel, dim3(grid_for(m, 4)), dim3(256), 0, s, m, b->ucount.as<uint64_t>(),
-                               b->seg_off.as<uint64_t>(), b->gbuf.as<uint64_t>(), b->pos_off.as<uint64_t>(),
-                               b->positions.as<uint64_t>());
-            HIPCHECK(hipGetLastError());
-        }
-        record(b, 6, s);
+        unsigned long long *d_nbig = d_next + 2;
+        tag_pipeline(img, b->mems.as<pgx_mem>(), nullptr, nullptr, b->n_mems, b->tw, d_nover, d_nbig, s,
+                     [&](int stage) { record(b, 4 + stage, s); });
+        b->n_positions = b->tw.n_positions;
         b->ran_tags = true;
     }
     record(b, 7, s);
@@ -378,9 +403,9 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         b->timing.ms_find_mems = el(1, 2);
         b->timing.ms_compact = el(2, 3);
         if (want_tags) {
-            b->timing.ms_tag_locate = el(3, 4);
-            b->timing.ms_tag_gather = el(4, 5);
-            b->timing.ms_tag_sort = el(5, 6);
+            b->timing.ms_tag_locate = el(3, 4); // locate + scans
+            b->timing.ms_tag_gather = el(4, 5); // 16-lane small path (gather + sort + unique)
+            b->timing.ms_tag_sort = el(5, 6);   // big path + final scan + compaction
         }
         b->timing.ms_total = el(0, 7);
     }
@@ -427,9 +452,9 @@ extern "C" pgx_status pgx_batch_result(pgx_batch *b, pgx_result *out) {
         b->h_run_nums.resize(m);
         b->h_pos_off.assign(m + 1, 0);
         b->h_positions.resize(b->n_positions);
-        if (m) HIPCHECK(hipMemcpy(b->h_run_nums.data(), b->run_nums.p, m * 8, hipMemcpyDeviceToHost));
-        HIPCHECK(hipMemcpy(b->h_pos_off.data(), b->pos_off.p, (m + 1) * 8, hipMemcpyDeviceToHost));
-        if (b->n_positions) HIPCHECK(hipMemcpy(b->h_positions.data(), b->positions.p, b->n_positions * 8, hipMemcpyDeviceToHost));
+        if (m) HIPCHECK(hipMemcpy(b->h_run_nums.data(), b->tw.run_nums.p, m * 8, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(b->h_pos_off.data(), b->tw.pos_off.p, (m + 1) * 8, hipMemcpyDeviceToHost));
+        if (b->n_positions) HIPCHECK(hipMemcpy(b->h_positions.data(), b->tw.positions.p, b->n_positions * 8, hipMemcpyDeviceToHost));
         out->tag_run_counts = b->h_run_nums.data();
         out->pos_offsets = b->h_pos_off.data();
         out->positions = b->h_positions.data();
@@ -512,40 +537,21 @@ extern "C" pgx_status pgx_tag_query_batch(pgx_index *h, int device, const uint64
     pos_offsets[0] = 0;
     if (n_overflow) *n_overflow = 0;
     if (!n) return PGX_OK;
-    DevBuf ds, de, drn, dfi, dseg, dneed, dsoff, dscr, dg, duc, dpo, dpos, tmp, dctr;
-    DevBuf *all[] = {&ds, &de, &drn, &dfi, &dseg, &dneed, &dsoff, &dscr, &dg, &duc, &dpo, &dpos, &tmp, &dctr};
+    DevBuf ds, de, dctr;
+    TagWork w;
     try {
         hipStream_t s = nullptr;
-        ds.ensure(n * 8); de.ensure(n * 8); drn.ensure(n * 8); dfi.ensure(n * 8); dseg.ensure((n + 1) * 8);
-        dneed.ensure(n * 8); dsoff.ensure((n + 1) * 8); duc.ensure(n * 8); dpo.ensure((n + 1) * 8); dctr.ensure(16);
-        HIPCHECK(hipMemset(dctr.p, 0, 16));
+        ds.ensure(n * 8); de.ensure(n * 8); dctr.ensure(32);
+        HIPCHECK(hipMemset(dctr.p, 0, 32));
         HIPCHECK(hipMemcpy(ds.p, start, n * 8, hipMemcpyHostToDevice));
         HIPCHECK(hipMemcpy(de.p, end, n * 8, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(pgx_tag_locate_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d->img, (const pgx_mem *)nullptr,
-                           ds.as<uint64_t>(), de.as<uint64_t>(), n, drn.as<uint64_t>(), dfi.as<uint64_t>());
-        hipLaunchKernelGGL(pgx_tag_scratch_need_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, n, drn.as<uint64_t>(), dneed.as<uint64_t>());
-        HIPCHECK(hipGetLastError());
-        scan_excl(1, drn.p, n, 0, dseg.as<uint64_t>(), tmp, s);
-        scan_excl(1, dneed.p, n, 0, dsoff.as<uint64_t>(), tmp, s);
-        const uint64_t G = read_u64(dseg.as<uint64_t>() + n, s), S = read_u64(dsoff.as<uint64_t>() + n, s);
-        dg.ensure((G ? G : 1) * 8);
-        dscr.ensure((S ? S : 1) * 8);
-        hipLaunchKernelGGL(pgx_tag_gather_kernel, dim3(grid_for(n, 4)), dim3(256), 0, s, d->img, n, drn.as<uint64_t>(), dfi.as<uint64_t>(),
-                           dseg.as<uint64_t>(), dg.as<uint64_t>(), dctr.as<unsigned long long>());
-        hipLaunchKernelGGL(pgx_tag_sort_unique_kernel, dim3(grid_for(n, 4)), dim3(256), 0, s, n, drn.as<uint64_t>(), dseg.as<uint64_t>(),
-                           dg.as<uint64_t>(), dscr.as<uint64_t>(), dsoff.as<uint64_t>(), duc.as<uint64_t>());
-        HIPCHECK(hipGetLastError());
-        scan_excl(1, duc.p, n, 0, dpo.as<uint64_t>(), tmp, s);
-        const uint64_t P = read_u64(dpo.as<uint64_t>() + n, s);
-        HIPCHECK(hipMemcpy(run_nums, drn.p, n * 8, hipMemcpyDeviceToHost));
-        HIPCHECK(hipMemcpy(pos_offsets, dpo.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+        unsigned long long *ctr = dctr.as<unsigned long long>();
+        tag_pipeline(d->img, nullptr, ds.as<uint64_t>(), de.as<uint64_t>(), n, w, ctr, ctr + 1, s, [](int) {});
+        HIPCHECK(hipMemcpy(run_nums, w.run_nums.p, n * 8, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(pos_offsets, w.pos_off.p, (n + 1) * 8, hipMemcpyDeviceToHost));
         if (positions) {
-            if (positions_cap < P) throw Error(PGX_ERR_ARG, "pgx_tag_query_batch: positions_cap too small");
-            dpos.ensure((P ? P : 1) * 8);
-            hipLaunchKernelGGL(pgx_tag_compact_kernel, dim3(grid_for(n, 4)), dim3(256), 0, s, n, duc.as<uint64_t>(), dseg.as<uint64_t>(),
-                               dg.as<uint64_t>(), dpo.as<uint64_t>(), dpos.as<uint64_t>());
-            HIPCHECK(hipGetLastError());
-            if (P) HIPCHECK(hipMemcpy(positions, dpos.p, P * 8, hipMemcpyDeviceToHost));
+            if (positions_cap < w.n_positions) throw Error(PGX_ERR_ARG, "pgx_tag_query_batch: positions_cap too small");
+            if (w.n_positions) HIPCHECK(hipMemcpy(positions, w.positions.p, w.n_positions * 8, hipMemcpyDeviceToHost));
         }
         if (n_overflow) {
             unsigned long long c = 0;
@@ -553,10 +559,10 @@ extern "C" pgx_status pgx_tag_query_batch(pgx_index *h, int device, const uint64
             *n_overflow = c;
         }
     } catch (...) {
-        for (DevBuf *b : all) b->release();
+        ds.release(); de.release(); dctr.release(); w.release();
         throw;
     }
-    for (DevBuf *b : all) b->release();
+    ds.release(); de.release(); dctr.release(); w.release();
     return PGX_OK;
     PGX_GUARD_END
 }

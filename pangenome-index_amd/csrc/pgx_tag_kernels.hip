@@ -1,0 +1,196 @@
+// pgx_tag_kernels.hip -- tag-array lookups of find_mems (TagArray::query_compressed{,_compact},
+// src/tag_arrays.cpp:780-890, minus the printing) as gfx950 kernels.
+//
+//   locate     per MEM: two rank_1 on bwt_intervals (= searches in the sorted run-start array via a
+//              sampled directory) -> run_nums, first item; MEMs with more than 16 runs go on a list
+//   small      <= 16 runs (the common case: a MEM's SA interval spans ~#haplotypes positions):
+//              16 lanes per MEM, four MEMs per wavefront; gather + bitonic network in registers +
+//              unique, no LDS, full occupancy
+//   big        listed MEMs only, one wavefront each: gather, then bitonic in registers (<= 64),
+//              in an LDS slice (<= 2048) or in global scratch (a short MEM with a huge SA interval)
+//   compact    16 lanes per MEM copy the unique prefix to the dense positions array
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pgx_device.h"
+
+// rank_1(bwt_intervals, x + 1) = number of run starts <= x  (src/tag_arrays.cpp:857-858)
+__device__ __forceinline__ uint64_t pgx_tag_rank(const PgxDevImage &img, uint64_t x) {
+    const uint64_t nr = img.n_tag_runs;
+    uint64_t di = x >> img.tag_dir_shift;
+    if (di + 1 >= img.tag_dir_entries) return nr; // beyond bwt_intervals.size(): all ones
+    uint64_t lo = img.tdir[di], hi = img.tdir[di + 1];
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (img.tstart[mid] <= x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// per query: run_nums (number_of_runs, :860) and the index of the first item read (:862-874,
+// including the off-by-one when first_bit_index % 10 == 0)
+__global__ void __launch_bounds__(256)
+pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *__restrict__ mems, const uint64_t *__restrict__ qstart,
+                      const uint64_t *__restrict__ qend, uint64_t n, uint64_t *__restrict__ run_nums,
+                      uint64_t *__restrict__ first_item, uint64_t *__restrict__ need, uint64_t *__restrict__ big_list,
+                      unsigned long long *__restrict__ n_big) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t st, en;
+    if (mems) { st = mems[i].bwt_start; en = st + (uint64_t)mems[i].size - 1; } // find_mems.cpp:129
+    else { st = qstart[i]; en = qend[i]; }
+    const uint64_t f = pgx_tag_rank(img, st), g = pgx_tag_rank(img, en);
+    const uint64_t cnt = g - f + 1;
+    run_nums[i] = cnt;
+    first_item[i] = (f % 10) ? f - 1 : f;
+    uint64_t p2 = 64;
+    while (p2 < cnt && p2 < (1ull << 62)) p2 <<= 1;
+    need[i] = p2 > PGX_SORT_LDS_CAP ? p2 : 0; // global scratch of the big path
+    if (cnt > PGX_TAG_SMALL) big_list[atomicAdd(n_big, 1ull)] = i;
+}
+
+// 16 lanes per query, <= 16 runs: gather, sort, unique -> seg, ucount
+__global__ void __launch_bounds__(256)
+pgx_tag_small_kernel(PgxDevImage img, uint64_t n, const uint64_t *__restrict__ run_nums, const uint64_t *__restrict__ first_item,
+                     const uint64_t *__restrict__ seg_off, uint64_t *__restrict__ buf, uint64_t *__restrict__ ucount,
+                     unsigned long long *__restrict__ n_overflow) {
+    const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
+    const bool valid = q < n;
+    const uint64_t cnt = valid ? run_nums[q] : 0;
+    const bool mine = valid && cnt <= PGX_TAG_SMALL;
+    uint64_t v = ~0ull;
+    bool over = false;
+    if (mine && (uint64_t)l16 < cnt) {
+        const uint64_t it = first_item[q] + (uint64_t)l16;
+        if (it < img.n_tag_items) v = img.tvals[it];
+        else { v = 0; over = true; } // the reference reads past the stored runs (UB): value 0
+    }
+#pragma unroll
+    for (int k = 2; k <= 16; k <<= 1) {
+#pragma unroll
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            const uint64_t o = __shfl_xor(v, jj, 64);
+            const bool up = ((l16 & k) == 0), lower = ((l16 & jj) == 0);
+            const uint64_t mn = v < o ? v : o, mx = v < o ? o : v;
+            v = (lower == up) ? mn : mx;
+        }
+    }
+    const uint64_t prev = __shfl_up(v, 1, 64);
+    const bool keep = mine && (uint64_t)l16 < cnt && (l16 == 0 || v != prev);
+    const unsigned long long mask = __ballot(keep);
+    const unsigned long long omask = __ballot(over);
+    const uint32_t gm = (uint32_t)(mask >> (16 * grp)) & 0xFFFFu;
+    if (keep) buf[seg_off[q] + (uint64_t)__popc(gm & ((1u << l16) - 1u))] = v;
+    if (mine && l16 == 0) {
+        ucount[q] = (uint64_t)__popc(gm);
+        if ((omask >> (16 * grp)) & 0xFFFFull) atomicAdd(n_overflow, 1ull);
+    }
+}
+
+// one wave per listed query: gather run values into its segment of `buf`
+__global__ void __launch_bounds__(256)
+pgx_tag_gather_kernel(PgxDevImage img, const uint64_t *__restrict__ list, uint64_t n_list, const uint64_t *__restrict__ run_nums,
+                      const uint64_t *__restrict__ first_item, const uint64_t *__restrict__ seg_off, uint64_t *__restrict__ buf,
+                      unsigned long long *__restrict__ n_overflow) {
+    const uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= n_list) return;
+    const uint64_t q = list[w];
+    const uint64_t cnt = run_nums[q], src = first_item[q], dst = seg_off[q];
+    bool over = false;
+    for (uint64_t t = lane; t < cnt; t += 64) {
+        const uint64_t it = src + t;
+        uint64_t v = 0;
+        if (it < img.n_tag_items) v = img.tvals[it]; else over = true;
+        buf[dst + t] = v;
+    }
+    if (__any(over) && lane == 0) atomicAdd(n_overflow, 1ull);
+}
+
+// bitonic sort of cnt values (padded to p2 with ~0) by ONE wave in `arr`, then duplicates dropped
+// and the unique prefix written back to `seg` in chunks of 64 (write index never passes read index).
+// Instantiated once per address space (LDS slice / global scratch): generic pointers that may
+// point into LDS are avoided on purpose (flat LDS accesses faulted on the gfx950 boxes).
+template <class Ptr>
+__device__ __forceinline__ uint64_t pgx_wave_sort_unique(Ptr arr, uint64_t *__restrict__ seg, uint64_t cnt, uint64_t p2, int lane) {
+    for (uint64_t t = lane; t < p2; t += 64) arr[t] = t < cnt ? seg[t] : ~0ull;
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    for (uint64_t k = 2; k <= p2; k <<= 1) {
+        for (uint64_t jj = k >> 1; jj > 0; jj >>= 1) {
+            for (uint64_t t = lane; t < p2 / 2; t += 64) {
+                const uint64_t lo_i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1)); // t-th pair of this stage
+                const uint64_t hi_i = lo_i | jj;
+                const uint64_t a = arr[lo_i], b = arr[hi_i];
+                const bool up = ((lo_i & k) == 0);
+                if ((a > b) == up) { arr[lo_i] = b; arr[hi_i] = a; }
+            }
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    uint64_t outn = 0;
+    for (uint64_t b0 = 0; b0 < cnt; b0 += 64) {
+        const uint64_t t = b0 + lane;
+        const uint64_t v = t < cnt ? arr[t] : 0;
+        const uint64_t prev = (t > 0 && t < cnt) ? arr[t - 1] : 0;
+        const bool keep = t < cnt && (t == 0 || v != prev);
+        const unsigned long long mask = __ballot(keep);
+        const int at = __popcll(mask & ((1ull << lane) - 1ull));
+        if (keep) seg[outn + at] = v;
+        outn += (uint64_t)__popcll(mask);
+    }
+    return outn;
+}
+
+// one wave per listed query: sort its segment and drop duplicates in place; ucount[q] = #unique
+__global__ void __launch_bounds__(256)
+pgx_tag_sort_unique_kernel(const uint64_t *__restrict__ list, uint64_t n_list, const uint64_t *__restrict__ run_nums,
+                           const uint64_t *__restrict__ seg_off, uint64_t *__restrict__ buf, uint64_t *__restrict__ scratch,
+                           const uint64_t *__restrict__ scratch_off, uint64_t *__restrict__ ucount) {
+    __shared__ uint64_t s_sort[4][PGX_SORT_LDS_CAP];
+    const uint64_t wi = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (wi >= n_list) return;
+    const uint64_t q = list[wi];
+    const uint64_t cnt = run_nums[q];
+    uint64_t *seg = buf + seg_off[q];
+    if (cnt <= 64) {
+        uint64_t v = (uint64_t)lane < cnt ? seg[lane] : ~0ull;
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+            for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                const uint64_t o = __shfl_xor(v, jj, 64);
+                const bool up = ((lane & k) == 0), lower = ((lane & jj) == 0);
+                const uint64_t mn = v < o ? v : o, mx = v < o ? o : v;
+                v = (lower == up) ? mn : mx;
+            }
+        }
+        const uint64_t prev = __shfl_up(v, 1, 64);
+        const bool keep = (uint64_t)lane < cnt && (lane == 0 || v != prev);
+        const unsigned long long mask = __ballot(keep);
+        const int at = __popcll(mask & ((1ull << lane) - 1ull));
+        if (keep) seg[at] = v;
+        if (lane == 0) ucount[q] = (uint64_t)__popcll(mask);
+        return;
+    }
+    uint64_t p2 = 64;
+    while (p2 < cnt) p2 <<= 1;
+    uint64_t outn;
+    if (p2 <= PGX_SORT_LDS_CAP) outn = pgx_wave_sort_unique(&s_sort[w][0], seg, cnt, p2, lane);
+    else outn = pgx_wave_sort_unique(scratch + scratch_off[q], seg, cnt, p2, lane);
+    if (lane == 0) ucount[q] = outn;
+}
+
+// 16 lanes per query: copy the unique prefix of its segment to the dense positions array
+__global__ void __launch_bounds__(256)
+pgx_tag_compact_kernel(uint64_t n, const uint64_t *__restrict__ ucount, const uint64_t *__restrict__ seg_off,
+                       const uint64_t *__restrict__ buf, const uint64_t *__restrict__ pos_off, uint64_t *__restrict__ positions) {
+    const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l16 = threadIdx.x & 15;
+    if (q >= n) return;
+    const uint64_t c = ucount[q], src = seg_off[q], dst = pos_off[q];
+    for (uint64_t t = l16; t < c; t += 16) positions[dst + t] = buf[src + t];
+}

@@ -83,6 +83,36 @@ class ImageEmu:
             B += take * ((mrow >> (3 * code)) & 7)
         return A & M64, B & M64
 
+    def rank_pair(self, pos0, pos1, cv, mrow):
+        """pgx_rank_pair: one decode of pos0's block serves both probes when it also covers pos1"""
+        c = self.c
+        p0, p1 = min(pos0, c.n), min(pos1, c.n)
+        b = self.find_block(p0)
+        cnt, ents, _ = self.block_counts(b)
+        start = sum(cnt[i] for i in range(6) if not (c.excl_mask >> i) & 1)
+        a = cnt[cv]
+        rel0 = p0 - start
+        d1 = (p1 - start) & M64
+        rel1 = min(d1, 0xFFFFFFFF)
+        ia0 = ia1 = idb = 0
+        for code, ln in ents:
+            t0, t1 = min(ln, rel0), min(ln, rel1)
+            rel0 -= t0
+            rel1 -= t1
+            if code == cv:
+                ia0 += t0
+                ia1 += t1
+            idb = (idb + (t1 - t0) * ((mrow >> (3 * code)) & 7)) & 0xFFFFFFFF
+        A0f, B0f = self.rank_ab(pos0, cv, mrow)
+        A1f, B1f = self.rank_ab(pos1, cv, mrow)
+        total = sum(ln for _, ln in ents)
+        if d1 < total or (rel1 == 0 and b + 1 == c.n_blocks):
+            dB = idb - (1 << 32) if idb >= (1 << 31) else idb
+            out = ((a + ia0) & M64, (a + ia1) & M64, dB & M64)
+            assert out == (A0f, A1f, (B1f - B0f) & M64), (pos0, pos1, cv, mrow)
+            return out
+        return A0f, A1f, (B1f - B0f) & M64
+
     def rank6_true(self, pos):
         return [self.rank_ab(pos, code, 0)[0] for code in range(6)]
 
@@ -94,12 +124,11 @@ class ImageEmu:
         e = self.c.ext_tab[(256 if fwd else 0) + byte]
         cv, v, mrow, kill = e & 7, (e >> 3) & 7, (e >> 6) & 0x3FFFF, (e >> 24) & 1
         kk, kq = (kp, k) if fwd else (k, kp)
-        A1, B1 = self.rank_ab((kk + s) & M64, cv, mrow)
-        A0, B0 = self.rank_ab(kk, cv, mrow)
+        A0, A1, dB = self.rank_pair(kk, (kk + s) & M64, cv, mrow)
         if kill or A0 >= A1:
             return (0, 0, 0)
         nk = (A0 + self.c.C[v]) & M64
-        nq = (kq + B1 - B0) & M64
+        nq = (kq + dB) & M64
         ns = A1 - A0
         return (nq, nk, ns) if fwd else (nk, nq, ns)
 
