@@ -68,7 +68,7 @@ typedef struct {
     uint64_t n_ref_blocks;  /* blocks in the file (10 runs each, r-index.hpp:312) */
     uint64_t n_runs;        /* logical BWT runs held by the image */
     uint64_t n_dev_blocks;  /* 64-byte device rank blocks */
-    uint64_t dir_entries;   /* directory entries (u32) */
+    uint64_t dir_entries;   /* directory entries (u64) */
     uint32_t dir_shift;
     uint32_t is_encoded;    /* FastLocate::is_encoded(), r-index.hpp:409 */
     uint32_t has_N;         /* encoded_has_N */
@@ -79,7 +79,7 @@ typedef struct {
     uint64_t tag_dir_entries;
     uint32_t tag_dir_shift;
     uint32_t image_in_lds;  /* 1 when the rank image fits the per-workgroup LDS budget */
-    uint64_t image_bytes;   /* device bytes of the rank image (blocks + directory + starts) */
+    uint64_t image_bytes;   /* device bytes of the rank image (blocks + directory + block lows) */
     uint64_t tag_image_bytes;
     double ref_block_mean_bytes; /* mean encoded block size of the reference layout (B_blk) */
 } pgx_index_info;
@@ -100,8 +100,8 @@ void pgx_index_close(pgx_index *h);
 pgx_status pgx_index_to_device(pgx_index *h, int device);
 
 /* Host views of the flat image (for tests that verify the layout without a GPU).  `which`:
- * 0 rank blocks (64 B each), 1 directory (u32), 2 block starts (u64), 3 tag run starts (u64),
- * 4 tag values (u64), 5 tag directory (u32), 6 constants table (see pgx_image.h). */
+ * 0 rank blocks (64 B each), 1 directory (u64), 2 block starts (u64, host only), 3 tag run starts (u64),
+ * 4 tag values (u64), 5 tag directory (u32), 6 constants table (see pgx_image.h), 7 block lows (u16). */
 pgx_status pgx_index_image_view(const pgx_index *h, int which, const void **ptr, uint64_t *bytes);
 
 /* ---- index construction (build side; CPU, run once) --------------------------------------- */

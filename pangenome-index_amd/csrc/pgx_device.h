@@ -8,12 +8,13 @@
 #include "pgx_image.h"
 
 #define PGX_FM_THREADS 256
+#define PGX_FM_WAVES_PER_SIMD 3 // __launch_bounds__ 2nd argument: caps the kernel at 128 VGPRs
 
 // passed by value to every kernel (all pointers are device pointers)
 struct PgxDevImage {
     const uint4 *blocks;      // n_blocks * 4 (64-byte rank blocks)
-    const uint32_t *dir;      // dir_entries
-    const uint64_t *bstart;   // n_blocks
+    const uint64_t *dir;      // dir_entries (64-bit entries, see pgx_image.h)
+    const uint16_t *blow;     // n_blocks (low dir_shift bits of each block start)
     const PgxConsts *consts;  // tables (ext_tab, C, slot_code)
     const uint64_t *tstart;   // n_tag_runs
     const uint64_t *tvals;    // n_tag_items
@@ -30,7 +31,7 @@ struct PgxDevImage {
 template <bool LDS_IMAGE>
 __global__ void pgx_find_mems_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
                                      uint64_t min_len, uint64_t min_occ, const uint64_t *slot_off, pgx_mem *slots,
-                                     uint32_t *mem_count, unsigned long long *n_ext_total);
+                                     uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor);
 __global__ void pgx_rank_kernel(PgxDevImage img, const uint64_t *pos, uint64_t n, int true_codes, uint64_t *out);
 template <bool LDS_IMAGE>
 __global__ void pgx_extend_kernel(PgxDevImage img, const pgx_biint *in, const uint8_t *sym, const uint8_t *forward, uint64_t n,

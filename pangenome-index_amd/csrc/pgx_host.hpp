@@ -109,8 +109,9 @@ void write_whole_file(const std::string &path, const std::vector<uint8_t> &bytes
 struct HostImage {
     PgxConsts consts;
     std::vector<uint8_t> blocks;   // n_blocks * 64
-    std::vector<uint32_t> dir;
-    std::vector<uint64_t> bstart;
+    std::vector<uint64_t> dir;
+    std::vector<uint64_t> bstart; // host only (tests): absolute block starts
+    std::vector<uint16_t> blow;   // device: low dir_shift bits of each block start
     std::vector<uint64_t> tstart, tvals;
     std::vector<uint32_t> tdir;
     uint64_t n_runs = 0;

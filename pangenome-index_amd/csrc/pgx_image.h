@@ -12,8 +12,14 @@
  *    dw 7      bits 0..15 high 8 bits of c6[4..5]; bits 16..20 number of run entries used
  *    dw 8..15  16 run entries of 16 bits: code << 13 | length (1..8191); length 0 = unused
  *    block_start = sum of the counts whose code is not in `excl_mask` (see PgxConsts)
- *  directory   u32 dir[i] = last block whose start <= (i << dir_shift); (n >> dir_shift) + 2 entries
- *  block starts u64 bstart[b]  (binary-searched only when dir[i] != dir[i+1])
+ *  directory   u64 dir[i], one bucket of 2^dir_shift positions each, about one bucket per block:
+ *                bits  0..31  lo  = number of blocks whose start is < (i << dir_shift)
+ *                bits 32..39  cnt = blocks starting inside bucket i (saturates at 255)
+ *                bits 40..51  low part of the 1st, bits 52..63 of the 2nd block start in the bucket
+ *              the block holding pos is lo - 1 + #{blocks of the bucket with low <= pos & mask}: one
+ *              8-byte load answers it when cnt <= 2 (the common case); (n >> dir_shift) + 2 entries
+ *  block lows  u16 blow[b] = block_start & ((1 << dir_shift) - 1), searched only when cnt > 2
+ *              (dir_shift <= 12 so that a low part fits the 12-bit fields)
  *
  *  tag image: u64 tstart[r] (first BWT position of tag run r, ascending), u64 tvals[r] (the
  *  graph position the reference prints: node << 11 | rev << 10 | offset), u32 tdir like dir.
@@ -31,6 +37,7 @@
 #define PGX_RUN_LEN_BITS 13
 #define PGX_RUN_LEN_MAX 8191u
 #define PGX_COUNT_BITS 40
+#define PGX_DIR_MAX_SHIFT 12
 
 /* ext_tab entry (one per byte value and direction): how to extend by that byte */
 #define PGX_EXT_CV(e) ((e) & 7u)            /* nuc code whose rank gives the new interval     */

@@ -345,17 +345,26 @@ void build_rank_image(const RiFile &ri, uint32_t mode, HostImage &img) {
     const uint64_t nb = img.bstart.size();
     if (nb >> 32) throw Error(PGX_ERR_UNSUPPORTED, "more than 2^32 device blocks");
     c.n_blocks = (uint32_t)nb;
-    // directory: ~4 buckets per block
+    // directory: about one bucket per block; a 64-bit entry resolves buckets holding at most two
+    // block starts by itself (one 8-byte load), denser buckets fall back to the 16-bit lows
     uint32_t shift = 0;
-    while (shift < 40 && ((c.n >> (shift + 1)) + 2) >= 4 * nb) shift++;
+    while (shift < PGX_DIR_MAX_SHIFT && ((c.n >> (shift + 1)) + 2) >= nb) shift++;
     c.dir_shift = shift;
     c.dir_entries = (c.n >> shift) + 2;
     img.dir.resize(c.dir_entries);
-    uint64_t bi = 0;
+    img.blow.resize(nb);
+    const uint64_t mask = (1ull << shift) - 1;
+    for (uint64_t b = 0; b < nb; b++) img.blow[b] = (uint16_t)(img.bstart[b] & mask);
+    uint64_t bi = 0; // number of blocks with start < (i << shift)
     for (uint64_t i = 0; i < c.dir_entries; i++) {
-        uint64_t p = i << shift;
-        while (bi + 1 < nb && img.bstart[bi + 1] <= p) bi++;
-        img.dir[i] = (uint32_t)bi;
+        const uint64_t p = i << shift;
+        while (bi < nb && img.bstart[bi] < p) bi++;
+        uint64_t e = bi, cnt = 0; // blocks starting inside bucket i
+        while (bi + cnt < nb && (img.bstart[bi + cnt] >> shift) == i) cnt++;
+        e |= (cnt > 255 ? 255 : cnt) << 32;
+        if (cnt >= 1) e |= (uint64_t)img.blow[bi] << 40;
+        if (cnt >= 2) e |= (uint64_t)img.blow[bi + 1] << 52;
+        img.dir[i] = e;
     }
 }
 
@@ -461,7 +470,7 @@ extern "C" pgx_status pgx_index_info_get(const pgx_index *h, pgx_index_info *inf
     info->n_tag_runs = c.n_tag_runs;
     info->tag_dir_entries = c.tag_dir_entries;
     info->tag_dir_shift = c.tag_dir_shift;
-    info->image_bytes = h->img.blocks.size() + h->img.dir.size() * 4 + h->img.bstart.size() * 8;
+    info->image_bytes = h->img.blocks.size() + h->img.dir.size() * 8 + h->img.blow.size() * 2;
     info->tag_image_bytes = h->img.tstart.size() * 8 + h->img.tvals.size() * 8 + h->img.tdir.size() * 4;
     info->image_in_lds = info->image_bytes <= 48 * 1024;
     info->ref_block_mean_bytes = h->ri.ref_block_mean_bytes;
@@ -475,12 +484,13 @@ extern "C" pgx_status pgx_index_image_view(const pgx_index *h, int which, const 
     const HostImage &m = h->img;
     switch (which) {
     case 0: *ptr = m.blocks.data(); *bytes = m.blocks.size(); break;
-    case 1: *ptr = m.dir.data(); *bytes = m.dir.size() * 4; break;
+    case 1: *ptr = m.dir.data(); *bytes = m.dir.size() * 8; break;
     case 2: *ptr = m.bstart.data(); *bytes = m.bstart.size() * 8; break;
     case 3: *ptr = m.tstart.data(); *bytes = m.tstart.size() * 8; break;
     case 4: *ptr = m.tvals.data(); *bytes = m.tvals.size() * 8; break;
     case 5: *ptr = m.tdir.data(); *bytes = m.tdir.size() * 4; break;
     case 6: *ptr = &m.consts; *bytes = sizeof(PgxConsts); break;
+    case 7: *ptr = m.blow.data(); *bytes = m.blow.size() * 2; break;
     default: throw Error(PGX_ERR_ARG, "pgx_index_image_view: unknown view");
     }
     return PGX_OK;

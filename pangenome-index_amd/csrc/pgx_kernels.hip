@@ -16,23 +16,38 @@
 
 #include "pgx_device.h"
 
+// block holding position pos (pos <= n).  One 8-byte directory entry resolves buckets with at most
+// two block starts; denser buckets search the 16-bit low parts of their blocks.
+template <bool LDS_IMAGE>
+__device__ __forceinline__ uint32_t pgx_find_block(const PgxDevImage &img, const uint64_t *__restrict__ lds_dir,
+                                                   const uint16_t *__restrict__ lds_blow, uint64_t pos) {
+    const uint64_t di = pos >> img.dir_shift; // <= (n >> shift) = dir_entries - 2
+    const uint64_t e = LDS_IMAGE ? lds_dir[di] : img.dir[di];
+    const uint32_t lowp = (uint32_t)pos & ((1u << img.dir_shift) - 1u);
+    uint32_t lo = (uint32_t)e;
+    const uint32_t cnt = (uint32_t)(e >> 32) & 0xFFu;
+    if (cnt <= 2) {
+        const uint32_t l0 = (uint32_t)(e >> 40) & 0xFFFu, l1 = (uint32_t)(e >> 52);
+        return lo - 1u + ((cnt >= 1 && l0 <= lowp) ? 1u : 0u) + ((cnt >= 2 && l1 <= lowp) ? 1u : 0u);
+    }
+    uint32_t hi = cnt < 255 ? lo + cnt : (uint32_t)(LDS_IMAGE ? lds_dir[di + 1] : img.dir[di + 1]);
+    while (lo < hi) { // upper bound over the blocks that start inside this bucket
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t v = LDS_IMAGE ? lds_blow[mid] : img.blow[mid];
+        if (v <= lowp) lo = mid + 1; else hi = mid;
+    }
+    return lo - 1; // block 0 starts at 0, so lo >= 1
+}
+
 // ------------------------------------------------------------------------------------------
 // rank probe: A = count of code `cv` in BWT[0,pos), B = sum over codes of mult[code] * count(code)
 // (both modulo 2^64; only differences of two probes are ever used).
 template <bool LDS_IMAGE>
 __device__ __forceinline__ void pgx_rank_ab(const PgxDevImage &img, const uint4 *__restrict__ lds_blocks,
-                                            const uint32_t *__restrict__ lds_dir, const uint64_t *__restrict__ lds_bstart,
+                                            const uint64_t *__restrict__ lds_dir, const uint16_t *__restrict__ lds_blow,
                                             uint64_t pos, uint32_t cv, uint32_t mrow, uint64_t &A, uint64_t &B) {
     if (pos > img.n) pos = img.n; // predecessor(pos >= size) = last block, rel past the end = totals
-    const uint64_t di = pos >> img.dir_shift; // <= (n >> shift) = dir_entries - 2
-    uint32_t lo, hi;
-    if (LDS_IMAGE) { lo = lds_dir[di]; hi = lds_dir[di + 1]; }
-    else { lo = img.dir[di]; hi = img.dir[di + 1]; }
-    while (lo < hi) { // rare: only when a block boundary falls inside this directory bucket
-        const uint32_t mid = (lo + hi + 1) >> 1;
-        const uint64_t st = LDS_IMAGE ? lds_bstart[mid] : img.bstart[mid];
-        if (st <= pos) lo = mid; else hi = mid - 1;
-    }
+    const uint32_t lo = pgx_find_block<LDS_IMAGE>(img, lds_dir, lds_blow, pos);
     const uint4 *bp = (LDS_IMAGE ? lds_blocks : img.blocks) + (size_t)lo * 4;
     const uint4 h0 = bp[0], h1 = bp[1], r0 = bp[2], r1 = bp[3];
     uint64_t c[6];
@@ -71,19 +86,11 @@ __device__ __forceinline__ void pgx_rank_ab(const PgxDevImage &img, const uint4 
 // wrapped) are two independent probes made.  Outputs A0, A1 (counts of code cv) and B1 - B0.
 template <bool LDS_IMAGE>
 __device__ __forceinline__ void pgx_rank_pair(const PgxDevImage &img, const uint4 *__restrict__ lds_blocks,
-                                              const uint32_t *__restrict__ lds_dir, const uint64_t *__restrict__ lds_bstart,
+                                              const uint64_t *__restrict__ lds_dir, const uint16_t *__restrict__ lds_blow,
                                               uint64_t pos0, uint64_t pos1, uint32_t cv, uint32_t mrow, uint64_t &A0,
                                               uint64_t &A1, uint64_t &dB) {
     const uint64_t p0 = pos0 > img.n ? img.n : pos0, p1 = pos1 > img.n ? img.n : pos1;
-    const uint64_t di = p0 >> img.dir_shift;
-    uint32_t lo, hi;
-    if (LDS_IMAGE) { lo = lds_dir[di]; hi = lds_dir[di + 1]; }
-    else { lo = img.dir[di]; hi = img.dir[di + 1]; }
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi + 1) >> 1;
-        const uint64_t st = LDS_IMAGE ? lds_bstart[mid] : img.bstart[mid];
-        if (st <= p0) lo = mid; else hi = mid - 1;
-    }
+    const uint32_t lo = pgx_find_block<LDS_IMAGE>(img, lds_dir, lds_blow, p0);
     const uint4 *bp = (LDS_IMAGE ? lds_blocks : img.blocks) + (size_t)lo * 4;
     const uint4 h0 = bp[0], h1 = bp[1], r0 = bp[2], r1 = bp[3];
     uint64_t c[6];
@@ -126,22 +133,22 @@ __device__ __forceinline__ void pgx_rank_pair(const PgxDevImage &img, const uint
         return;
     }
     uint64_t B0, B1;
-    pgx_rank_ab<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_bstart, pos1, cv, mrow, A1, B1);
-    pgx_rank_ab<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_bstart, pos0, cv, mrow, A0, B0);
+    pgx_rank_ab<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, pos1, cv, mrow, A1, B1);
+    pgx_rank_ab<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, pos0, cv, mrow, A0, B0);
     dB = B1 - B0;
 }
 
 // one FMD extension of (k, kp, s) by `byte` (backward, or forward = backward on the swapped
 // interval by the complement, folded into ext_tab[256 + byte]).  Returns the new size (0 = empty).
 template <bool LDS_IMAGE>
-__device__ __forceinline__ void pgx_extend(const PgxDevImage &img, const uint4 *lds_blocks, const uint32_t *lds_dir,
-                                           const uint64_t *lds_bstart, const uint32_t *s_ext, const uint64_t *s_C,
+__device__ __forceinline__ void pgx_extend(const PgxDevImage &img, const uint4 *lds_blocks, const uint64_t *lds_dir,
+                                           const uint16_t *lds_blow, const uint32_t *s_ext, const uint64_t *s_C,
                                            uint64_t &k, uint64_t &kp, uint64_t &s, uint32_t byte, bool fwd) {
     const uint32_t e = s_ext[(fwd ? 256u : 0u) + byte];
     const uint32_t cv = PGX_EXT_CV(e), mrow = PGX_EXT_M(e);
     const uint64_t kk = fwd ? kp : k, kq = fwd ? k : kp;
     uint64_t A1, A0, dB;
-    pgx_rank_pair<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_bstart, kk, kk + s, cv, mrow, A0, A1, dB);
+    pgx_rank_pair<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, kk, kk + s, cv, mrow, A0, A1, dB);
     if (PGX_EXT_KILL(e) || A0 >= A1) { // rank_k >= rank_ks -> bi_interval(0,0,0), src/r-index.cpp:751
         k = 0; kp = 0; s = 0;
         return;
@@ -154,63 +161,69 @@ __device__ __forceinline__ void pgx_extend(const PgxDevImage &img, const uint4 *
 
 template <bool LDS_IMAGE>
 __device__ __forceinline__ void pgx_stage_tables(const PgxDevImage &img, uint32_t *s_ext, uint64_t *s_C, uint4 *lds_blocks,
-                                                 uint32_t *lds_dir, uint64_t *lds_bstart) {
+                                                 uint64_t *lds_dir, uint16_t *lds_blow) {
     for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) s_ext[i] = img.consts->ext_tab[i];
     if (threadIdx.x < 8) s_C[threadIdx.x] = img.consts->C[threadIdx.x];
     if (LDS_IMAGE) {
         const uint32_t nb4 = img.n_blocks * 4;
         for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) lds_blocks[i] = img.blocks[i];
         for (uint64_t i = threadIdx.x; i < img.dir_entries; i += blockDim.x) lds_dir[i] = img.dir[i];
-        for (uint32_t i = threadIdx.x; i < img.n_blocks; i += blockDim.x) lds_bstart[i] = img.bstart[i];
+        for (uint32_t i = threadIdx.x; i < img.n_blocks; i += blockDim.x) lds_blow[i] = img.blow[i];
     }
     __syncthreads();
 }
 
-// dynamic LDS carve (16-byte aligned base): [blocks | bstart | dir]
+// dynamic LDS carve (16-byte aligned base): [blocks | dir | blow]
 #define PGX_LDS_CARVE(img)                                                                   \
     extern __shared__ __align__(16) unsigned char pgx_dyn_lds[];                              \
     uint4 *lds_blocks = reinterpret_cast<uint4 *>(pgx_dyn_lds);                               \
-    uint64_t *lds_bstart = reinterpret_cast<uint64_t *>(pgx_dyn_lds + (size_t)(img).n_blocks * PGX_BLOCK_BYTES); \
-    uint32_t *lds_dir = reinterpret_cast<uint32_t *>(pgx_dyn_lds + (size_t)(img).n_blocks * (PGX_BLOCK_BYTES + 8))
+    uint64_t *lds_dir = reinterpret_cast<uint64_t *>(pgx_dyn_lds + (size_t)(img).n_blocks * PGX_BLOCK_BYTES);    \
+    uint16_t *lds_blow = reinterpret_cast<uint16_t *>(pgx_dyn_lds + (size_t)(img).n_blocks * PGX_BLOCK_BYTES + (img).dir_entries * 8)
 
 // ------------------------------------------------------------------------------------------
 // find_all_mems for a batch.  State machine of find_mems_function (algorithm.hpp:653-736):
 //   phase 1  backward from j = x+min_len-1 down to x          (:666-676)
 //   phase 2  forward  from j = x+min_len   up to len-1        (:684-696)  -> emit MEM (:713)
 //   phase 3  backward from j = e down to x+1, fresh interval  (:718-735); pattern[len] reads 0
+//
+// Persistent work-queue kernel: one lane owns one live read; every trip of the main loop performs
+// exactly one extension for every live lane.  A lane whose read is finished is refilled at once
+// (reads differ 2-3x in their extension counts, so a static read->lane map leaves most lanes idle):
+// the wavefront keeps a private reservoir [rnext, rend) of read ids that lane 0 replenishes with
+// one atomicAdd of PGX_FM_BATCH on the global cursor, and idle lanes take ids from it in lane order
+// (ballot + prefix popcount).  Every wave leaves the loop once the cursor has passed n_reads and
+// all its lanes are idle.  MEMs go to per-read slots, so the output does not depend on scheduling.
+#define PGX_FM_BATCH 128u
 template <bool LDS_IMAGE>
-__global__ void __launch_bounds__(PGX_FM_THREADS)
+__global__ void __launch_bounds__(PGX_FM_THREADS, PGX_FM_WAVES_PER_SIMD)
 pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                      uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
-                     pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total) {
+                     pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
+                     unsigned long long *__restrict__ cursor) {
     __shared__ uint32_t s_ext[512];
     __shared__ uint64_t s_C[8];
     PGX_LDS_CARVE(img);
-    pgx_stage_tables<LDS_IMAGE>(img, s_ext, s_C, lds_blocks, lds_dir, lds_bstart);
+    pgx_stage_tables<LDS_IMAGE>(img, s_ext, s_C, lds_blocks, lds_dir, lds_blow);
 
-    const uint64_t rid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool have = rid < n_reads;
-    uint64_t base = 0, slot = 0;
-    int64_t len = 0;
-    if (have) {
-        base = offsets[rid];
-        len = (int64_t)(offsets[rid + 1] - base);
-        slot = slot_off[rid];
-    }
+    const int lane = threadIdx.x & 63;
     const uint64_t n = img.n;
-    int64_t x = 0, j = 0, e = 0;
+    uint64_t rid = 0, base = 0, slot = 0;
+    int32_t len = 0, x = 0, j = 0, e = 0;
     uint64_t k = 0, kp = 0, s = 0, Jk = 0, Js = 0;
     uint32_t nm = 0, next = 0;
-    int ph = 0; // 0 = done
+    int ph = 0;                      // 0 = idle (no read, or read finished)
+    uint64_t win = 0, win_at = ~0ull; // 8 read bytes cached in registers (absolute, 8-aligned offset)
+    uint64_t rnext = 0, rend = 0;    // wave-uniform reservoir of read ids
+    bool exhausted = false;          // wave-uniform: the global cursor has passed n_reads
 
-    // begin(x): entry of find_mems_function
+    // begin(x): entry of find_mems_function; finishing a read records its MEM count
     auto begin = [&]() {
-        if (x >= len || (uint64_t)(len - x) < min_len) { ph = 0; return; } // :745 / :658
+        if (x >= len || (uint64_t)(len - x) < min_len) { ph = 0; mem_count[rid] = nm; return; } // :745 / :658
         k = 0; kp = 0; s = n;
         if (min_len == 0) { // step 1 runs zero times (:666); step 2 starts at j = x
             Jk = 0; Js = n; j = x; ph = 2;
         } else {
-            j = x + (int64_t)min_len - 1; ph = 1;
+            j = x + (int32_t)min_len - 1; ph = 1;
         }
     };
     // emit the MEM [x, e) and set up step 3
@@ -223,19 +236,59 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
         if (j > x) ph = 3;
         else { x = x + 1; begin(); } // loop of :722 runs zero times, returns j + 1
     };
-    if (have) begin();
 
-    while (__any(ph != 0)) {
-        if (ph != 0) {
-            const uint32_t byte = (j < len) ? (uint32_t)reads[base + (uint64_t)j] : 0u;
+    for (;;) {
+        // ---- refill idle lanes ----
+        unsigned long long idle = __ballot(ph == 0);
+        while (idle) {
+            if (rnext == rend) {
+                if (exhausted) break;
+                unsigned long long got = 0;
+                if (lane == 0) got = atomicAdd(cursor, (unsigned long long)PGX_FM_BATCH);
+                got = __shfl(got, 0, 64);
+                if (got >= n_reads) { exhausted = true; break; }
+                rnext = got;
+                rend = got + PGX_FM_BATCH < n_reads ? got + PGX_FM_BATCH : n_reads;
+            }
+            const uint64_t avail = rend - rnext;
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (ph == 0 && (uint64_t)rank < avail) {
+                rid = rnext + rank;
+                base = offsets[rid];
+                len = (int32_t)(offsets[rid + 1] - base);
+                slot = slot_off[rid];
+                x = 0; nm = 0;
+                begin(); // may leave the lane idle again (read shorter than min_len)
+                if (ph == 0) ph = -1; // served in this round; becomes idle again below
+            }
+            const uint32_t want = (uint32_t)__popcll(idle);
+            rnext += (uint64_t)want < avail ? (uint64_t)want : avail;
+            idle = __ballot(ph == 0);
+        }
+        if (ph == -1) ph = 0;
+        if (!__any(ph > 0)) {
+            if (exhausted && rnext == rend) break; // nothing live, nothing left
+            continue;                               // only zero-work reads were handed out: refill again
+        }
+        // ---- one extension for every live lane ----
+        if (ph > 0) {
+            uint32_t byte = 0u; // pattern[len] reads as 0 (quirk 4)
+            if (j < len) {
+                const uint64_t at = base + (uint64_t)j;
+                if ((at & ~7ull) != win_at) { // reads are padded with 16 zero bytes: the window never overruns
+                    win_at = at & ~7ull;
+                    win = *reinterpret_cast<const uint64_t *>(reads + win_at);
+                }
+                byte = (uint32_t)(win >> (8u * (uint32_t)(at & 7ull))) & 0xFFu;
+            }
             const bool fwd = (ph == 2);
-            pgx_extend<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_bstart, s_ext, s_C, k, kp, s, byte, fwd);
+            pgx_extend<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, s_ext, s_C, k, kp, s, byte, fwd);
             next++;
             const bool small = (s < min_occ) || (s == 0); // :671 (unsigned compare) || size <= 0
             if (ph == 1) {
                 if (small) { x = j + 1; begin(); }
                 else if (j == x) {
-                    Jk = k; Js = s; j = x + (int64_t)min_len;
+                    Jk = k; Js = s; j = x + (int32_t)min_len;
                     if (j >= len) { e = j; emit(); } else ph = 2;
                 } else j--;
             } else if (ph == 2) {
@@ -253,18 +306,17 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
             }
         }
     }
-    if (have) mem_count[rid] = nm;
     // one atomic per wave for the extension counter
     unsigned long long tot = next;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
-    if ((threadIdx.x & 63) == 0 && tot) atomicAdd(n_ext_total, tot);
+    if (lane == 0 && tot) atomicAdd(n_ext_total, tot);
 }
 
 template __global__ void pgx_find_mems_kernel<false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                     const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *);
+                                                     const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *);
 template __global__ void pgx_find_mems_kernel<true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                    const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *);
+                                                    const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *);
 
 // ------------------------------------------------------------------------------------------
 // primitives for tests (mirror rank_at_cached_encoded / backward_extend_encoded / forward_...)
@@ -288,11 +340,11 @@ pgx_extend_kernel(PgxDevImage img, const pgx_biint *__restrict__ in, const uint8
     __shared__ uint32_t s_ext[512];
     __shared__ uint64_t s_C[8];
     PGX_LDS_CARVE(img);
-    pgx_stage_tables<LDS_IMAGE>(img, s_ext, s_C, lds_blocks, lds_dir, lds_bstart);
+    pgx_stage_tables<LDS_IMAGE>(img, s_ext, s_C, lds_blocks, lds_dir, lds_blow);
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint64_t k = in[i].forward, kp = in[i].reverse, s = (uint64_t)in[i].size;
-    pgx_extend<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_bstart, s_ext, s_C, k, kp, s, sym[i], forward[i] != 0);
+    pgx_extend<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, s_ext, s_C, k, kp, s, sym[i], forward[i] != 0);
     pgx_biint o;
     o.forward = k; o.reverse = kp; o.size = (int64_t)s;
     out[i] = o;

@@ -75,7 +75,7 @@ struct DevBuf { // grow-only device buffer
 struct pgx_device_image {
     int device = -1;
     PgxDevImage img{};
-    DevBuf blocks, dir, bstart, consts, tstart, tvals, tdir;
+    DevBuf blocks, dir, blow, consts, tstart, tvals, tdir;
     size_t lds_bytes = 0; // dynamic LDS of the LDS-image kernels (0 = image stays in global memory)
 };
 
@@ -83,7 +83,7 @@ void pgx_release_device_images(pgx_index *h) {
     for (auto *d : h->dev) {
         if (!d) continue;
         if (hipSetDevice(d->device) == hipSuccess) {
-            d->blocks.release(); d->dir.release(); d->bstart.release(); d->consts.release();
+            d->blocks.release(); d->dir.release(); d->blow.release(); d->consts.release();
             d->tstart.release(); d->tvals.release(); d->tdir.release();
         }
         delete d;
@@ -104,16 +104,16 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
     d->device = device;
     const HostImage &m = h->img;
     upload(d->blocks, m.blocks.data(), m.blocks.size());
-    upload(d->dir, m.dir.data(), m.dir.size() * 4);
-    upload(d->bstart, m.bstart.data(), m.bstart.size() * 8);
+    upload(d->dir, m.dir.data(), m.dir.size() * 8);
+    upload(d->blow, m.blow.data(), m.blow.size() * 2);
     upload(d->consts, &m.consts, sizeof(PgxConsts));
     upload(d->tstart, m.tstart.data(), m.tstart.size() * 8);
     upload(d->tvals, m.tvals.data(), m.tvals.size() * 8);
     upload(d->tdir, m.tdir.data(), m.tdir.size() * 4);
     PgxDevImage &g = d->img;
     g.blocks = d->blocks.as<uint4>();
-    g.dir = d->dir.as<uint32_t>();
-    g.bstart = d->bstart.as<uint64_t>();
+    g.dir = d->dir.as<uint64_t>();
+    g.blow = d->blow.as<uint16_t>();
     g.consts = d->consts.as<PgxConsts>();
     g.tstart = d->tstart.as<uint64_t>();
     g.tvals = d->tvals.as<uint64_t>();
@@ -127,7 +127,7 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
     g.dir_shift = m.consts.dir_shift;
     g.excl_mask = m.consts.excl_mask;
     g.tag_dir_shift = m.consts.tag_dir_shift;
-    size_t img_bytes = m.blocks.size() + m.bstart.size() * 8 + m.dir.size() * 4;
+    size_t img_bytes = m.blocks.size() + m.dir.size() * 8 + m.blow.size() * 2;
     d->lds_bytes = img_bytes <= 48 * 1024 ? ((img_bytes + 15) & ~(size_t)15) : 0;
     h->dev[device] = d.release();
     return h->dev[device];
@@ -360,15 +360,24 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     // 2. the hot kernel
     record(b, 1, s);
     if (n) {
-        const unsigned grid = grid_for(n, PGX_FM_THREADS);
+        // persistent grid: as many workgroups as the device keeps resident (no inter-workgroup
+        // dependency exists, so any grid size is correct; this one avoids a tail of late blocks)
+        unsigned long long *d_cursor = d_next + 3;
+        int occ = 0, cus = 0;
+        const void *kfn = b->dimg->lds_bytes ? (const void *)pgx_find_mems_kernel<true> : (const void *)pgx_find_mems_kernel<false>;
+        HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, PGX_FM_THREADS, b->dimg->lds_bytes));
+        HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
+        if (occ < 1) occ = 1;
+        unsigned grid = grid_for(n, 64);
+        if (grid > (unsigned)(occ * cus)) grid = (unsigned)(occ * cus);
         if (b->dimg->lds_bytes)
             hipLaunchKernelGGL(pgx_find_mems_kernel<true>, dim3(grid), dim3(PGX_FM_THREADS), b->dimg->lds_bytes, s, img,
                                b->reads.as<uint8_t>(), b->offsets.as<uint64_t>(), n, min_len, min_occ, b->slot_off.as<uint64_t>(),
-                               b->slots.as<pgx_mem>(), b->mem_count.as<uint32_t>(), d_next);
+                               b->slots.as<pgx_mem>(), b->mem_count.as<uint32_t>(), d_next, d_cursor);
         else
             hipLaunchKernelGGL(pgx_find_mems_kernel<false>, dim3(grid), dim3(PGX_FM_THREADS), 0, s, img, b->reads.as<uint8_t>(),
                                b->offsets.as<uint64_t>(), n, min_len, min_occ, b->slot_off.as<uint64_t>(), b->slots.as<pgx_mem>(),
-                               b->mem_count.as<uint32_t>(), d_next);
+                               b->mem_count.as<uint32_t>(), d_next, d_cursor);
         HIPCHECK(hipGetLastError());
         b->timing.find_mems_launches = 1;
     }

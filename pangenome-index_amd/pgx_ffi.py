@@ -138,7 +138,7 @@ def write_compact_tags(out_path, values, lengths):
     _check(lib().pgx_write_compact_tags(out_path.encode(), v.ctypes.data, l.ctypes.data, len(v)))
 
 
-_VIEW_DTYPES = {0: np.uint8, 1: np.uint32, 2: np.uint64, 3: np.uint64, 4: np.uint64, 5: np.uint32, 6: np.uint8}
+_VIEW_DTYPES = {0: np.uint8, 1: np.uint64, 2: np.uint64, 3: np.uint64, 4: np.uint64, 5: np.uint32, 6: np.uint8, 7: np.uint16}
 
 
 class Index:

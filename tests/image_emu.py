@@ -35,6 +35,7 @@ class ImageEmu:
         self.blocks = index.image_view(0).view(np.uint32).reshape(-1, 16)
         self.dir = index.image_view(1)
         self.bstart = index.image_view(2)
+        self.blow = index.image_view(7)
         self.tstart = index.image_view(3)
         self.tvals = index.image_view(4)
         self.tdir = index.image_view(5)
@@ -55,14 +56,21 @@ class ImageEmu:
     def find_block(self, pos):
         c = self.c
         di = pos >> c.dir_shift
-        lo, hi = int(self.dir[di]), int(self.dir[di + 1])
+        e = int(self.dir[di])
+        lo, cnt, l0, l1 = e & 0xFFFFFFFF, (e >> 32) & 0xFF, (e >> 40) & 0xFFF, e >> 52
+        lowp = pos & ((1 << c.dir_shift) - 1)
+        hi = lo + cnt if cnt < 255 else int(self.dir[di + 1]) & 0xFFFFFFFF
+        if cnt <= 2:
+            hi = lo = lo + (1 if cnt >= 1 and l0 <= lowp else 0) + (1 if cnt >= 2 and l1 <= lowp else 0)
         while lo < hi:
-            mid = (lo + hi + 1) >> 1
-            if int(self.bstart[mid]) <= pos:
-                lo = mid
+            mid = (lo + hi) >> 1
+            if int(self.blow[mid]) <= lowp:
+                lo = mid + 1
             else:
-                hi = mid - 1
-        return lo
+                hi = mid
+        b = lo - 1
+        assert int(self.bstart[b]) <= pos and (b + 1 == c.n_blocks or pos < int(self.bstart[b + 1])), (pos, b)
+        return b
 
     def rank_ab(self, pos, cv, mrow):
         c = self.c
