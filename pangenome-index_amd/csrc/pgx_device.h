@@ -44,17 +44,20 @@ __global__ void pgx_compact_mems_kernel(uint64_t n_reads, const uint64_t *slot_o
                                         const uint32_t *mem_count, const uint64_t *mem_off, pgx_mem *mems);
 #define PGX_SORT_LDS_CAP 2048 // values per wave sorted in an LDS slice (pgx_tag_sort_unique_kernel)
 #define PGX_TAG_SMALL 16      // queries with at most this many runs take the 16-lane path
+#define PGX_SORT_WG_LDS_CAP 16384 // values one workgroup sorts in (dynamic) LDS (pgx_tag_sort_large_kernel)
 
 __global__ void pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *mems, const uint64_t *qstart, const uint64_t *qend,
                                       uint64_t n, uint64_t *run_nums, uint64_t *first_item, uint64_t *need, uint64_t *big_list,
-                                      unsigned long long *n_big);
+                                      unsigned long long *n_big, unsigned long long *n_large);
 __global__ void pgx_tag_small_kernel(PgxDevImage img, uint64_t n, const uint64_t *run_nums, const uint64_t *first_item,
                                      const uint64_t *seg_off, uint64_t *buf, uint64_t *ucount, unsigned long long *n_overflow);
 __global__ void pgx_tag_gather_kernel(PgxDevImage img, const uint64_t *list, uint64_t n_list, const uint64_t *run_nums,
                                       const uint64_t *first_item, const uint64_t *seg_off, uint64_t *buf,
                                       unsigned long long *n_overflow);
 __global__ void pgx_tag_sort_unique_kernel(const uint64_t *list, uint64_t n_list, const uint64_t *run_nums, const uint64_t *seg_off,
-                                           uint64_t *buf, uint64_t *scratch, const uint64_t *scratch_off, uint64_t *ucount);
+                                           uint64_t *buf, uint64_t *ucount);
+__global__ void pgx_tag_sort_large_kernel(const uint64_t *list, uint64_t n_list, const uint64_t *run_nums, const uint64_t *seg_off,
+                                          uint64_t *buf, uint64_t *scratch, const uint64_t *scratch_off, uint64_t *ucount);
 __global__ void pgx_tag_compact_kernel(uint64_t n, const uint64_t *ucount, const uint64_t *seg_off, const uint64_t *buf,
                                        const uint64_t *pos_off, uint64_t *positions);
 

@@ -203,7 +203,8 @@ struct TagWork {
     }
 };
 
-// counters: [0] overflow count, [1] big-list length (both zeroed by the caller on the stream)
+// counters: d_nover overflow count, d_nbig[0] big-list length, d_nbig[1] large-list length, d_nbig[2] largest
+// run count on the large list (all zeroed by the caller)
 template <class Rec>
 static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const uint64_t *d_qs, const uint64_t *d_qe, uint64_t m,
                          TagWork &w, unsigned long long *d_nover, unsigned long long *d_nbig, hipStream_t s, Rec &&rec) {
@@ -217,17 +218,17 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
     w.big_list.ensure((m ? m : 1) * 8);
     if (m) {
         hipLaunchKernelGGL(pgx_tag_locate_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, img, d_mems, d_qs, d_qe, m,
-                           w.run_nums.as<uint64_t>(), w.first_item.as<uint64_t>(), w.need.as<uint64_t>(), w.big_list.as<uint64_t>(), d_nbig);
+                           w.run_nums.as<uint64_t>(), w.first_item.as<uint64_t>(), w.need.as<uint64_t>(), w.big_list.as<uint64_t>(), d_nbig, d_nbig + 1);
         HIPCHECK(hipGetLastError());
     }
     scan_excl(1, w.run_nums.p, m, 0, w.seg_off.as<uint64_t>(), w.scan_tmp, s);
     scan_excl(1, w.need.p, m, 0, w.scratch_off.as<uint64_t>(), w.scan_tmp, s);
-    uint64_t hv[3] = {0, 0, 0};
+    uint64_t hv[5] = {0, 0, 0, 0, 0};
     HIPCHECK(hipMemcpyAsync(&hv[0], w.seg_off.as<uint64_t>() + m, 8, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipMemcpyAsync(&hv[1], w.scratch_off.as<uint64_t>() + m, 8, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipMemcpyAsync(&hv[2], d_nbig, 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(&hv[2], d_nbig, 24, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
-    const uint64_t G = hv[0], S = hv[1], nbig = hv[2];
+    const uint64_t G = hv[0], S = hv[1], nbig = hv[2], nlarge = hv[3];
     w.n_big = nbig;
     rec(0);
     w.gbuf.ensure((G ? G : 1) * 8);
@@ -242,6 +243,23 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
         hipLaunchKernelGGL(pgx_tag_gather_kernel, dim3(grid_for(nbig, 4)), dim3(256), 0, s, img, w.big_list.as<uint64_t>(), nbig,
                            w.run_nums.as<uint64_t>(), w.first_item.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), d_nover);
         hipLaunchKernelGGL(pgx_tag_sort_unique_kernel, dim3(grid_for(nbig, 4)), dim3(256), 0, s, w.big_list.as<uint64_t>(), nbig,
+                           w.run_nums.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.ucount.as<uint64_t>());
+        HIPCHECK(hipGetLastError());
+    }
+    if (nlarge) {
+        const uint64_t *large = w.big_list.as<uint64_t>() + (m - nlarge); // the back of the shared list array
+        static bool lds_opt_in = false;
+        uint64_t p2max = 64;
+        while (p2max < hv[4] && p2max < PGX_SORT_WG_LDS_CAP) p2max <<= 1;
+        const size_t lds = (size_t)p2max * 8; // smaller segments -> more workgroups per CU
+        if (!lds_opt_in) {
+            HIPCHECK(hipFuncSetAttribute((const void *)pgx_tag_sort_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(PGX_SORT_WG_LDS_CAP * 8)));
+            lds_opt_in = true;
+        }
+        hipLaunchKernelGGL(pgx_tag_gather_kernel, dim3(grid_for(nlarge, 4)), dim3(256), 0, s, img, large, nlarge,
+                           w.run_nums.as<uint64_t>(), w.first_item.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), d_nover);
+        hipLaunchKernelGGL(pgx_tag_sort_large_kernel, dim3(grid_for(nlarge, 1)), dim3(1024), lds, s, large, nlarge,
                            w.run_nums.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.scratch.as<uint64_t>(),
                            w.scratch_off.as<uint64_t>(), w.ucount.as<uint64_t>());
         HIPCHECK(hipGetLastError());
@@ -362,7 +380,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     if (n) {
         // persistent grid: as many workgroups as the device keeps resident (no inter-workgroup
         // dependency exists, so any grid size is correct; this one avoids a tail of late blocks)
-        unsigned long long *d_cursor = d_next + 3;
+        unsigned long long *d_cursor = d_next + 5; // counters: [0] extensions [1] tag overflows [2] big [3] large [4] max large [5] read cursor
         int occ = 0, cus = 0;
         const void *kfn = b->dimg->lds_bytes ? (const void *)pgx_find_mems_kernel<true> : (const void *)pgx_find_mems_kernel<false>;
         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, PGX_FM_THREADS, b->dimg->lds_bytes));
@@ -550,8 +568,8 @@ extern "C" pgx_status pgx_tag_query_batch(pgx_index *h, int device, const uint64
     TagWork w;
     try {
         hipStream_t s = nullptr;
-        ds.ensure(n * 8); de.ensure(n * 8); dctr.ensure(32);
-        HIPCHECK(hipMemset(dctr.p, 0, 32));
+        ds.ensure(n * 8); de.ensure(n * 8); dctr.ensure(64);
+        HIPCHECK(hipMemset(dctr.p, 0, 64));
         HIPCHECK(hipMemcpy(ds.p, start, n * 8, hipMemcpyHostToDevice));
         HIPCHECK(hipMemcpy(de.p, end, n * 8, hipMemcpyHostToDevice));
         unsigned long long *ctr = dctr.as<unsigned long long>();

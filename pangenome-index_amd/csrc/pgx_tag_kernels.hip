@@ -6,8 +6,11 @@
 //   small      <= 16 runs (the common case: a MEM's SA interval spans ~#haplotypes positions):
 //              16 lanes per MEM, four MEMs per wavefront; gather + bitonic network in registers +
 //              unique, no LDS, full occupancy
-//   big        listed MEMs only, one wavefront each: gather, then bitonic in registers (<= 64),
-//              in an LDS slice (<= 2048) or in global scratch (a short MEM with a huge SA interval)
+//   big        listed MEMs with 17..2048 runs, one wavefront each: gather, then bitonic in registers
+//              (<= 64) or in a per-wave LDS slice
+//   large      listed MEMs with more runs (a MEM inside a repeat / an N run has a huge SA interval):
+//              one 1024-thread workgroup each, bitonic in 128 KiB of LDS (<= 16384 values) or in
+//              global scratch beyond that
 //   compact    16 lanes per MEM copy the unique prefix to the dense positions array
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,7 +36,7 @@ __global__ void __launch_bounds__(256)
 pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *__restrict__ mems, const uint64_t *__restrict__ qstart,
                       const uint64_t *__restrict__ qend, uint64_t n, uint64_t *__restrict__ run_nums,
                       uint64_t *__restrict__ first_item, uint64_t *__restrict__ need, uint64_t *__restrict__ big_list,
-                      unsigned long long *__restrict__ n_big) {
+                      unsigned long long *__restrict__ n_big, unsigned long long *__restrict__ n_large) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint64_t st, en;
@@ -45,8 +48,13 @@ pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *__restrict__ mems, const u
     first_item[i] = (f % 10) ? f - 1 : f;
     uint64_t p2 = 64;
     while (p2 < cnt && p2 < (1ull << 62)) p2 <<= 1;
-    need[i] = p2 > PGX_SORT_LDS_CAP ? p2 : 0; // global scratch of the big path
-    if (cnt > PGX_TAG_SMALL) big_list[atomicAdd(n_big, 1ull)] = i;
+    need[i] = p2 > PGX_SORT_WG_LDS_CAP ? p2 : 0; // global scratch of the large path
+    // one array, two lists: "big" grows from the front, "large" from the back (they cannot meet)
+    if (cnt > PGX_SORT_LDS_CAP) {
+        big_list[n - 1 - atomicAdd(n_large, 1ull)] = i;
+        atomicMax(n_large + 1, (unsigned long long)cnt); // sizes the LDS of the large-path launch
+    }
+    else if (cnt > PGX_TAG_SMALL) big_list[atomicAdd(n_big, 1ull)] = i;
 }
 
 // 16 lanes per query, <= 16 runs: gather, sort, unique -> seg, ucount
@@ -147,8 +155,7 @@ __device__ __forceinline__ uint64_t pgx_wave_sort_unique(Ptr arr, uint64_t *__re
 // one wave per listed query: sort its segment and drop duplicates in place; ucount[q] = #unique
 __global__ void __launch_bounds__(256)
 pgx_tag_sort_unique_kernel(const uint64_t *__restrict__ list, uint64_t n_list, const uint64_t *__restrict__ run_nums,
-                           const uint64_t *__restrict__ seg_off, uint64_t *__restrict__ buf, uint64_t *__restrict__ scratch,
-                           const uint64_t *__restrict__ scratch_off, uint64_t *__restrict__ ucount) {
+                           const uint64_t *__restrict__ seg_off, uint64_t *__restrict__ buf, uint64_t *__restrict__ ucount) {
     __shared__ uint64_t s_sort[4][PGX_SORT_LDS_CAP];
     const uint64_t wi = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -178,10 +185,69 @@ pgx_tag_sort_unique_kernel(const uint64_t *__restrict__ list, uint64_t n_list, c
     }
     uint64_t p2 = 64;
     while (p2 < cnt) p2 <<= 1;
-    uint64_t outn;
-    if (p2 <= PGX_SORT_LDS_CAP) outn = pgx_wave_sort_unique(&s_sort[w][0], seg, cnt, p2, lane);
-    else outn = pgx_wave_sort_unique(scratch + scratch_off[q], seg, cnt, p2, lane);
+    const uint64_t outn = pgx_wave_sort_unique(&s_sort[w][0], seg, cnt, p2, lane); // cnt <= PGX_SORT_LDS_CAP by construction
     if (lane == 0) ucount[q] = outn;
+}
+
+// bitonic sort of cnt values (padded to p2 with ~0) by ONE workgroup in `arr` (LDS or global
+// scratch; one instantiation per address space), duplicates dropped, unique prefix written to `seg`.
+template <class Ptr>
+__device__ __forceinline__ uint64_t pgx_block_sort_unique(Ptr arr, uint64_t *__restrict__ seg, uint64_t cnt, uint64_t p2,
+                                                          uint32_t *s_wsum) {
+    const uint32_t tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+    for (uint64_t t = tid; t < p2; t += nt) arr[t] = t < cnt ? seg[t] : ~0ull;
+    __syncthreads();
+    for (uint64_t k = 2; k <= p2; k <<= 1) {
+        for (uint64_t jj = k >> 1; jj > 0; jj >>= 1) {
+            for (uint64_t t = tid; t < p2 / 2; t += nt) {
+                const uint64_t lo_i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
+                const uint64_t hi_i = lo_i | jj;
+                const uint64_t a = arr[lo_i], b = arr[hi_i];
+                const bool up = ((lo_i & k) == 0);
+                if ((a > b) == up) { arr[lo_i] = b; arr[hi_i] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    uint64_t outn = 0;
+    for (uint64_t b0 = 0; b0 < cnt; b0 += nt) {
+        const uint64_t t = b0 + tid;
+        const uint64_t v = t < cnt ? arr[t] : 0;
+        const uint64_t prev = (t > 0 && t < cnt) ? arr[t - 1] : 0;
+        const bool keep = t < cnt && (t == 0 || v != prev);
+        const unsigned long long mask = __ballot(keep);
+        if (lane == 0) s_wsum[wv] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (uint32_t i = 0; i < nw; i++) {
+            const uint32_t c = s_wsum[i];
+            before += i < wv ? c : 0u;
+            total += c;
+        }
+        if (keep) seg[outn + before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = v;
+        outn += total;
+        __syncthreads();
+    }
+    return outn;
+}
+
+// one 1024-thread workgroup per listed query with more than PGX_SORT_LDS_CAP runs
+__global__ void __launch_bounds__(1024)
+pgx_tag_sort_large_kernel(const uint64_t *__restrict__ list, uint64_t n_list, const uint64_t *__restrict__ run_nums,
+                          const uint64_t *__restrict__ seg_off, uint64_t *__restrict__ buf, uint64_t *__restrict__ scratch,
+                          const uint64_t *__restrict__ scratch_off, uint64_t *__restrict__ ucount) {
+    extern __shared__ __align__(16) uint64_t pgx_sort_lds[]; // PGX_SORT_WG_LDS_CAP values
+    __shared__ uint32_t s_wsum[16];
+    if (blockIdx.x >= n_list) return;
+    const uint64_t q = list[blockIdx.x];
+    const uint64_t cnt = run_nums[q];
+    uint64_t *seg = buf + seg_off[q];
+    uint64_t p2 = 64;
+    while (p2 < cnt) p2 <<= 1;
+    uint64_t outn;
+    if (p2 <= PGX_SORT_WG_LDS_CAP) outn = pgx_block_sort_unique(&pgx_sort_lds[0], seg, cnt, p2, s_wsum);
+    else outn = pgx_block_sort_unique(scratch + scratch_off[q], seg, cnt, p2, s_wsum);
+    if (threadIdx.x == 0) ucount[q] = outn;
 }
 
 // 16 lanes per query: copy the unique prefix of its segment to the dense positions array
