@@ -93,6 +93,12 @@ int pgx_abi_version(void);
  * Host-only: parses the files and builds the flat device image in host memory. */
 pgx_status pgx_index_open(const char *ri_path, const char *tags_path, uint32_t tags_format,
                           uint32_t mode, pgx_index **out);
+/* Same from memory images of the files (what std::istream-based loaders hand over).  Either image
+ * may be NULL: a tags-only handle serves TagArray, an r-index-only handle serves FastLocate. */
+pgx_status pgx_index_open_memory(const void *ri_bytes, uint64_t ri_n, const void *tags_bytes, uint64_t tags_n,
+                                 uint32_t tags_format, uint32_t mode, pgx_index **out);
+/* FastLocate's public tables: sym_map (r-index.hpp:307), C (:310), complement_table (:347) */
+pgx_status pgx_index_tables(const pgx_index *h, uint8_t sym_map[256], uint64_t C[8], uint8_t complement[256]);
 pgx_status pgx_index_info_get(const pgx_index *h, pgx_index_info *info);
 void pgx_index_close(pgx_index *h);
 

@@ -128,7 +128,7 @@ struct pgx_device_image;
 struct pgx_index {
     pgx::RiFile ri;
     pgx::TagFile tags;
-    bool has_tags = false;
+    bool has_tags = false, has_rank = false;
     uint32_t mode = 0;
     pgx::HostImage img;
     std::vector<pgx_device_image *> dev; // one per device ordinal (lazily filled)

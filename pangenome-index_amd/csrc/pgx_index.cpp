@@ -417,28 +417,55 @@ extern "C" int pgx_abi_version(void) { return PGX_ABI_VERSION; }
 
 void pgx_release_device_images(pgx_index *h); // pgx_runtime.hip
 
+static pgx_index *open_impl(const uint8_t *ri, uint64_t ri_n, const uint8_t *tags, uint64_t tags_n, uint32_t tags_format, uint32_t mode) {
+    if (mode != PGX_MODE_COMPAT && mode != PGX_MODE_STRICT) throw Error(PGX_ERR_ARG, "pgx_index_open: bad mode");
+    if (!ri && !tags) throw Error(PGX_ERR_ARG, "pgx_index_open: neither an r-index nor a tag array given");
+    std::unique_ptr<pgx_index> h(new pgx_index());
+    h->mode = mode;
+    std::memset(&h->img.consts, 0, sizeof h->img.consts);
+    if (ri) {
+        h->ri.parse(ri, ri_n);
+        build_rank_image(h->ri, mode, h->img);
+        h->has_rank = true;
+    }
+    if (tags) {
+        h->tags.parse(tags, tags_n, tags_format);
+        build_tag_image(h->tags, h->img);
+        h->has_tags = true;
+    }
+    return h.release();
+}
+
 extern "C" pgx_status pgx_index_open(const char *ri_path, const char *tags_path, uint32_t tags_format,
                                      uint32_t mode, pgx_index **out) {
     PGX_GUARD_BEGIN
     if (!ri_path || !out) throw Error(PGX_ERR_ARG, "pgx_index_open: null argument");
-    if (mode != PGX_MODE_COMPAT && mode != PGX_MODE_STRICT) throw Error(PGX_ERR_ARG, "pgx_index_open: bad mode");
     *out = nullptr;
-    std::unique_ptr<pgx_index> h(new pgx_index());
-    h->mode = mode;
-    {
-        std::vector<uint8_t> f;
-        try { f = read_whole_file(ri_path); }
-        catch (const Error &) { throw Error(PGX_ERR_IO, std::string("Cannot open r-index: ") + ri_path); } // find_mems.cpp:30
-        h->ri.parse(f.data(), f.size());
-    }
-    build_rank_image(h->ri, mode, h->img);
-    if (tags_path) {
-        std::vector<uint8_t> f = read_whole_file(tags_path);
-        h->tags.parse(f.data(), f.size(), tags_format);
-        build_tag_image(h->tags, h->img);
-        h->has_tags = true;
-    }
-    *out = h.release();
+    std::vector<uint8_t> f, t;
+    try { f = read_whole_file(ri_path); }
+    catch (const Error &) { throw Error(PGX_ERR_IO, std::string("Cannot open r-index: ") + ri_path); } // find_mems.cpp:30
+    if (tags_path) t = read_whole_file(tags_path);
+    *out = open_impl(f.data(), f.size(), tags_path ? t.data() : nullptr, t.size(), tags_format, mode);
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_index_open_memory(const void *ri_bytes, uint64_t ri_n, const void *tags_bytes, uint64_t tags_n,
+                                            uint32_t tags_format, uint32_t mode, pgx_index **out) {
+    PGX_GUARD_BEGIN
+    if (!out) throw Error(PGX_ERR_ARG, "pgx_index_open_memory: null argument");
+    *out = nullptr;
+    *out = open_impl((const uint8_t *)ri_bytes, ri_n, (const uint8_t *)tags_bytes, tags_n, tags_format, mode);
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_index_tables(const pgx_index *h, uint8_t sym_map[256], uint64_t C[8], uint8_t complement[256]) {
+    PGX_GUARD_BEGIN
+    if (!h || !h->has_rank) throw Error(PGX_ERR_ARG, "pgx_index_tables: no r-index loaded");
+    if (sym_map) std::memcpy(sym_map, h->ri.sym_map, 256);
+    if (C) for (int i = 0; i < 8; i++) C[i] = i < (int)h->ri.C.size() ? h->ri.C[i] : 0;
+    if (complement) complement_table(complement);
     return PGX_OK;
     PGX_GUARD_END
 }

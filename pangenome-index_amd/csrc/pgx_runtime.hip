@@ -316,6 +316,7 @@ extern "C" pgx_status pgx_batch_create(pgx_index *h, int device, const uint8_t *
     PGX_GUARD_BEGIN
     if (!h || !out || !offsets || (!reads && n_reads && offsets[n_reads] != offsets[0]))
         throw Error(PGX_ERR_ARG, "pgx_batch_create: null argument");
+    if (!h->has_rank) throw Error(PGX_ERR_ARG, "pgx_batch_create: index opened without an r-index");
     *out = nullptr;
     for (uint64_t i = 0; i < n_reads; i++) {
         if (offsets[i + 1] < offsets[i]) throw Error(PGX_ERR_ARG, "pgx_batch_create: offsets must be non-decreasing");
@@ -511,6 +512,7 @@ extern "C" pgx_status pgx_find_mems_batch(pgx_index *h, int device, const uint8_
 extern "C" pgx_status pgx_rank_batch(pgx_index *h, int device, const uint64_t *pos, uint64_t n, int true_codes, uint64_t *out) {
     PGX_GUARD_BEGIN
     if (!h || (n && (!pos || !out))) throw Error(PGX_ERR_ARG, "pgx_rank_batch: null argument");
+    if (!h->has_rank) throw Error(PGX_ERR_ARG, "pgx_rank_batch: index opened without an r-index");
     pgx_device_image *d = device_image(h, device);
     if (!n) return PGX_OK;
     DevBuf dp, dout;
@@ -532,6 +534,7 @@ extern "C" pgx_status pgx_extend_batch(pgx_index *h, int device, const pgx_biint
                                        uint64_t n, pgx_biint *out) {
     PGX_GUARD_BEGIN
     if (!h || (n && (!in || !sym || !forward || !out))) throw Error(PGX_ERR_ARG, "pgx_extend_batch: null argument");
+    if (!h->has_rank) throw Error(PGX_ERR_ARG, "pgx_extend_batch: index opened without an r-index");
     pgx_device_image *d = device_image(h, device);
     if (!n) return PGX_OK;
     DevBuf din, dsym, dfw, dout;

@@ -1,0 +1,108 @@
+// pangenome_index/r-index.hpp -- drop-in host mirror of the query side of panindexer::FastLocate
+// (reference include/pangenome_index/r-index.hpp:44-716) implemented over the C ABI of libpgx.
+//
+// Same names, argument meaning and error behaviour as the reference for the find_mems path:
+//   load_encoded / load            throw std::runtime_error("FastLocate: Invalid tag" ...) like
+//                                  sdsl::simple_sds::InvalidData (src/r-index.cpp:412-419)
+//   backward/forward_extend[_encoded], bi_interval, complement, sym_map, C, bwt_size, tot_strings
+// Every query runs on the GPU; a per-call extension costs a kernel launch, so batch callers should
+// use panindexer::find_all_mems_batch (algorithm.hpp) or pgx_extend_batch directly.
+#ifndef PANGENOME_INDEX_R_INDEX_HPP
+#define PANGENOME_INDEX_R_INDEX_HPP
+
+#include <array>
+#include <cstdint>
+#include <istream>
+#include <iterator>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/pgx.h"
+#include "utils.hpp"
+
+namespace panindexer {
+
+typedef std::uint64_t size_type;
+
+class FastLocate {
+public:
+    // r-index.hpp:118-130
+    struct bi_interval {
+        size_t forward; // k
+        size_t reverse; // l
+        int64_t size;   // s
+        bi_interval() = default;
+        bi_interval(size_type fwd, size_type rev, size_type sz) : forward(fwd), reverse(rev), size((int64_t)sz) {}
+        bool operator==(const bi_interval &o) const { return forward == o.forward && reverse == o.reverse && size == o.size; }
+    };
+
+    std::array<uint8_t, 256> sym_map{}; // r-index.hpp:307
+    std::vector<size_t> C;              // r-index.hpp:310
+
+    FastLocate() { initialize_complement_table(); }
+    FastLocate(const FastLocate &) = delete;
+    FastLocate &operator=(const FastLocate &) = delete;
+    ~FastLocate() { if (h_) pgx_index_close(h_); }
+
+    // src/r-index.cpp:406-459: falls back to the legacy layout when the ENCODED_BLOCKS flag is clear
+    void load_encoded(std::istream &in) { open(in); }
+    void load(std::istream &in) { open(in); } // src/r-index.cpp:378-404
+
+    bool is_encoded() const { return info_.is_encoded != 0; }            // r-index.hpp:409
+    size_t bwt_size() const { return info_.bwt_size; }                   // r-index.hpp:568
+    size_t get_sequence_size() const { return info_.bwt_size; }
+    size_t tot_strings() const { return C.size() > 1 ? C[1] - C[0] : 0; } // r-index.hpp:484
+    size_t text_size() const { return bwt_size() - tot_strings(); }
+
+    void initialize_complement_table() { // src/r-index.cpp:1512-1529
+        for (size_t i = 0; i < 256; ++i) complement_table[i] = (uint8_t)i;
+        complement_table['A'] = 'T'; complement_table['C'] = 'G'; complement_table['G'] = 'C'; complement_table['T'] = 'A';
+        complement_table['a'] = 't'; complement_table['c'] = 'g'; complement_table['g'] = 'c'; complement_table['t'] = 'a';
+    }
+    inline size_t complement(size_t symbol) const { return complement_table[symbol & 0xFF]; }
+
+    // src/r-index.cpp:713-764 (legacy twins :1395-1428, :1500-1509: same entry points here, the
+    // layout difference is carried by the device image)
+    bi_interval backward_extend_encoded(const bi_interval &b, size_t symbol) { return extend(b, symbol, false); }
+    bi_interval forward_extend_encoded(const bi_interval &b, size_t symbol) { return extend(b, symbol, true); }
+    bi_interval backward_extend(const bi_interval &b, size_t symbol) { return extend(b, symbol, false); }
+    bi_interval forward_extend(const bi_interval &b, size_t symbol) { return extend(b, symbol, true); }
+
+    // library handle (for the batch entry points of algorithm.hpp)
+    pgx_index *handle() const { return h_; }
+    int device() const { return device_; }
+    void set_device(int d) { device_ = d; }
+    void set_mode(uint32_t m) { mode_ = m; } // PGX_MODE_COMPAT (default) / PGX_MODE_STRICT; before load
+
+private:
+    pgx_index *h_ = nullptr;
+    pgx_index_info info_{};
+    int device_ = 0;
+    uint32_t mode_ = PGX_MODE_COMPAT;
+    std::array<uint8_t, 256> complement_table{};
+
+    void open(std::istream &in) {
+        std::vector<char> bytes((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        if (h_) { pgx_index_close(h_); h_ = nullptr; }
+        if (pgx_index_open_memory(bytes.data(), bytes.size(), nullptr, 0, PGX_TAGS_AUTO, mode_, &h_) != PGX_OK)
+            throw std::runtime_error(pgx_last_error());
+        pgx_index_info_get(h_, &info_);
+        uint64_t c[8];
+        pgx_index_tables(h_, sym_map.data(), c, nullptr);
+        C.assign(c, c + info_.sigma);
+    }
+
+    bi_interval extend(const bi_interval &b, size_t symbol, bool fwd) {
+        if (!h_) throw std::runtime_error("FastLocate: no index loaded");
+        pgx_biint in{b.forward, b.reverse, b.size}, out{0, 0, 0};
+        const uint8_t sym = (uint8_t)symbol, f = fwd ? 1 : 0;
+        if (pgx_extend_batch(h_, device_, &in, &sym, &f, 1, &out) != PGX_OK) throw std::runtime_error(pgx_last_error());
+        return bi_interval(out.forward, out.reverse, (size_type)out.size);
+    }
+};
+
+} // namespace panindexer
+
+#endif // PANGENOME_INDEX_R_INDEX_HPP
