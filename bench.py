@@ -209,6 +209,30 @@ def main():
         shutil.rmtree(own_tmp, ignore_errors=True)
 
 
+def host_cores(omp_max):
+    """threads the CPU leg may really use: affinity mask, capped by the cgroup CPU quota of the box"""
+    n = omp_max
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(round(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(round(q / per))))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(args, ri, tags, cat, offs):
     """The oracle (kind "port": the reference cannot be built here) on a bounded sample of the same
     reads, all host cores via OpenMP over reads; timed regions = find_all_mems + tag queries."""
@@ -218,19 +242,22 @@ def cpu_baseline(args, ri, tags, cat, offs):
     r = O.RIndex(ri)
     t = None if args.no_tags else O.Tags(tags, O.TAGS_COMPACT)
     mode = O.MODE_COMPAT if args.mode == "compat" else O.MODE_STRICT
-    cores = O.lib().orc_max_threads()
+    cores = host_cores(O.lib().orc_max_threads())
     L = args.read_len
-    probe = min(args.reads, 20000)
-    res = O.find_mems_batch(r, t, cat[: probe * L], offs[: probe + 1], args.min_len, args.min_occ, mode=mode, threads=cores)
-    sec = max(res["seconds_mems"] + res["seconds_tags"], 1e-6)
-    sample = int(min(args.reads, max(probe, probe * (args.cpu_seconds / cores) / sec)))
-    res = O.find_mems_batch(r, t, cat[: sample * L], offs[: sample + 1], args.min_len, args.min_occ, mode=mode, threads=cores)
-    sec = res["seconds_mems"] + res["seconds_tags"]
-    one = min(sample, max(2000, sample // cores))
+    # one thread first (the reference's own execution model): calibrates the per-core rate
+    one = min(args.reads, 5000)
     res1 = O.find_mems_batch(r, t, cat[: one * L], offs[: one + 1], args.min_len, args.min_occ, mode=mode, threads=1)
-    sec1 = res1["seconds_mems"] + res1["seconds_tags"]
-    return {"value": sample / sec, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "first %d reads of the same batch, OpenMP over reads, compute only (%.2f s wall)" % (sample, sec),
+    sec1 = max(res1["seconds_mems"] + res1["seconds_tags"], 1e-6)
+    # all cores on a sample worth ~cpu_seconds core-seconds (bounded by the batch), best of 3
+    sample = int(min(args.reads, max(one, (one / sec1) * args.cpu_seconds)))
+    best = None
+    for _ in range(3):
+        res = O.find_mems_batch(r, t, cat[: sample * L], offs[: sample + 1], args.min_len, args.min_occ, mode=mode, threads=cores)
+        sec = res["seconds_mems"] + res["seconds_tags"]
+        best = sec if best is None else min(best, sec)
+    return {"value": sample / best, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": "first %d reads of the same batch (~%.0f core-seconds), OpenMP schedule(dynamic,256) over reads, "
+                      "find_all_mems + tag-query compute only, best of 3 (%.3f s wall)" % (sample, sample / (one / sec1), best),
             "single_thread_reads_per_s": one / sec1, "single_thread_sample": one}
 
 

@@ -1,0 +1,34 @@
+#!/bin/bash
+# usage (GPU box): bash scripts/profile_round.sh <tag>   -- rocprofv3 kernel stats + PMC traffic for both workloads
+tag=$1
+export TMPDIR=/tmp
+R=$PWD/gpurun_out/prof_$tag; mkdir -p $R
+for wl in x synth; do
+  steps=10; [ $wl = synth ] && steps=5
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/${wl}_stats -- python3 bench.py --workload $wl --steps $steps --warmup 2 --no-cpu-baseline --workdir /tmp/pgxwd_$wl > $R/${wl}_bench_under_rocprof.json 2> $R/${wl}_stats.err || echo FAIL stats $wl
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/${wl}_$C -- python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --workdir /tmp/pgxwd_$wl > /dev/null 2> $R/${wl}_$C.err || echo FAIL $C $wl
+  done
+done
+python3 - <<PY
+import csv, glob, json, collections
+R = "$R"
+for wl in ("x", "synth"):
+    out = {}
+    for C in ("FETCH_SIZE", "WRITE_SIZE"):
+        agg = collections.defaultdict(list)
+        for f in glob.glob("%s/%s_%s/*/*_counter_collection.csv" % (R, wl, C)):
+            for r in csv.DictReader(open(f)):
+                agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+        out[C] = {k: sum(v) / len(v) for k, v in agg.items() if k.startswith("pgx_")}
+    fm = [k for k in out["FETCH_SIZE"] if "find_mems" in k][0]
+    # FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1024 B (rocprofv3); FETCH_SIZE = TCC_EA0_RDREQ x 64 B, which is
+    # exact for this kernel's 64-byte random block reads (no 128-byte streaming requests to under-count; TCC_EA0_RDREQ_32B = 0)
+    rec = {"workload": wl, "kernel": fm, "FETCH_SIZE_KB_per_launch": out["FETCH_SIZE"][fm], "WRITE_SIZE_KB_per_launch": out["WRITE_SIZE"].get(fm, 0.0),
+           "find_mems_hbm_bytes_per_launch": (out["FETCH_SIZE"][fm] + out["WRITE_SIZE"].get(fm, 0.0)) * 1024.0,
+           "all_kernels_FETCH_KB": out["FETCH_SIZE"], "all_kernels_WRITE_KB": out["WRITE_SIZE"],
+           "note": "memory-side (fabric) bytes: Infinity-Cache hits are included, so this is an upper bound on HBM bytes"}
+    json.dump(rec, open("%s/traffic_%s.json" % (R, wl), "w"), indent=1)
+    print(wl, fm, rec["find_mems_hbm_bytes_per_launch"] / 1e9, "GB per launch")
+PY
+for wl in x synth; do cat $R/${wl}_stats/*/*_kernel_stats.csv | head -8; done
