@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target core-seconds of the CPU sample")
     ap.add_argument("--workdir", default=None)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --one-device rehearses the N>1 path on a single-GPU box")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses device 0 (rehearsal only)")
     return ap.parse_args()
 
 
@@ -95,9 +98,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libpgx has no CPU fallback")
+    if args.one_device:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
 
     def barrier():
         if world > 1:
@@ -137,11 +143,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     n_mems, n_pos, n_ext = batch.counts()
-    tot = torch.tensor([float(n_mems), float(n_pos), float(n_ext)], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(n_mems), float(n_pos), float(n_ext)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     tot = [float(v) for v in tot.tolist()]

@@ -83,58 +83,75 @@ __device__ __forceinline__ void pgx_rank_ab(const PgxDevImage &img, const uint4 
 // The two rank probes of one extension, rank(pos0) and rank(pos1) with pos1 = pos0 + s.  Once the
 // interval is narrow (s ~ number of haplotypes) both positions fall into the same 64-byte block,
 // so the block of pos0 is decoded once for both; only when pos1 lies beyond it (or the interval
-// wrapped) are two independent probes made.  Outputs A0, A1 (counts of code cv) and B1 - B0.
+// wrapped) is a second block decoded.  The decode exists once in the instruction stream (a rolled
+// two-trip loop) to keep code size and live registers down.  Outputs A0, A1 and B1 - B0.
 template <bool LDS_IMAGE>
 __device__ __forceinline__ void pgx_rank_pair(const PgxDevImage &img, const uint4 *__restrict__ lds_blocks,
                                               const uint64_t *__restrict__ lds_dir, const uint16_t *__restrict__ lds_blow,
                                               uint64_t pos0, uint64_t pos1, uint32_t cv, uint32_t mrow, uint64_t &A0,
                                               uint64_t &A1, uint64_t &dB) {
     const uint64_t p0 = pos0 > img.n ? img.n : pos0, p1 = pos1 > img.n ? img.n : pos1;
-    const uint32_t lo = pgx_find_block<LDS_IMAGE>(img, lds_dir, lds_blow, p0);
-    const uint4 *bp = (LDS_IMAGE ? lds_blocks : img.blocks) + (size_t)lo * 4;
-    const uint4 h0 = bp[0], h1 = bp[1], r0 = bp[2], r1 = bp[3];
-    uint64_t c[6];
-    c[0] = (uint64_t)h0.x | ((uint64_t)(h1.z & 0xFFu) << 32);
-    c[1] = (uint64_t)h0.y | ((uint64_t)((h1.z >> 8) & 0xFFu) << 32);
-    c[2] = (uint64_t)h0.z | ((uint64_t)((h1.z >> 16) & 0xFFu) << 32);
-    c[3] = (uint64_t)h0.w | ((uint64_t)(h1.z >> 24) << 32);
-    c[4] = (uint64_t)h1.x | ((uint64_t)(h1.w & 0xFFu) << 32);
-    c[5] = (uint64_t)h1.y | ((uint64_t)((h1.w >> 8) & 0xFFu) << 32);
-    uint64_t start = 0, a = 0;
+    uint64_t B0 = 0, B1 = 0;
+    A0 = 0; A1 = 0;
+    bool done = false;
+#pragma unroll 1
+    for (int it = 0; it < 2; ++it) {
+        if (!done) {
+            const uint64_t p = it ? p1 : p0;
+            const uint32_t lo = pgx_find_block<LDS_IMAGE>(img, lds_dir, lds_blow, p);
+            const uint4 *bp = (LDS_IMAGE ? lds_blocks : img.blocks) + (size_t)lo * 4;
+            const uint4 h0 = bp[0], h1 = bp[1], r0 = bp[2], r1 = bp[3];
+            uint64_t c[6];
+            c[0] = (uint64_t)h0.x | ((uint64_t)(h1.z & 0xFFu) << 32);
+            c[1] = (uint64_t)h0.y | ((uint64_t)((h1.z >> 8) & 0xFFu) << 32);
+            c[2] = (uint64_t)h0.z | ((uint64_t)((h1.z >> 16) & 0xFFu) << 32);
+            c[3] = (uint64_t)h0.w | ((uint64_t)(h1.z >> 24) << 32);
+            c[4] = (uint64_t)h1.x | ((uint64_t)(h1.w & 0xFFu) << 32);
+            c[5] = (uint64_t)h1.y | ((uint64_t)((h1.w >> 8) & 0xFFu) << 32);
+            uint64_t start = 0, a = 0, b = 0;
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        start += ((img.excl_mask >> i) & 1u) ? 0ull : c[i];
-        a = (cv == (uint32_t)i) ? c[i] : a;
-    }
-    uint32_t rel0 = (uint32_t)(p0 - start);
-    const uint64_t d1 = p1 - start; // wraps to a huge value when p1 < start
-    uint32_t rel1 = d1 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d1;
-    uint32_t ia0 = 0, ia1 = 0, idb = 0, total = 0;
-    const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            for (int i = 0; i < 6; i++) {
+                start += ((img.excl_mask >> i) & 1u) ? 0ull : c[i];
+                a = (cv == (uint32_t)i) ? c[i] : a;
+                b += c[i] * (uint64_t)((mrow >> (3 * i)) & 7u);
+            }
+            uint32_t relp = (uint32_t)(p - start);   // primary position of this trip (inside the block)
+            const uint64_t d1 = p1 - start;          // pos1 relative to this block; wraps when p1 < start
+            uint32_t rels = it ? 0u : (d1 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d1);
+            uint32_t iap = 0, ibp = 0, ias = 0, ibs = 0, total = 0;
+            const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-    for (int e = 0; e < PGX_BLOCK_RUNS; e++) {
-        const uint32_t v = (rw[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
-        const uint32_t code = v >> PGX_RUN_LEN_BITS, len = v & PGX_RUN_LEN_MAX;
-        const uint32_t t0 = min(len, rel0), t1 = min(len, rel1);
-        total += len;
-        rel0 -= t0;
-        rel1 -= t1;
-        const bool hit = (code == cv);
-        ia0 += hit ? t0 : 0u;
-        ia1 += hit ? t1 : 0u;
-        idb += (t1 - t0) * ((mrow >> (3 * code)) & 7u); // modulo 2^32; |true value| < 2^20
+            for (int e = 0; e < PGX_BLOCK_RUNS; e++) {
+                const uint32_t v = (rw[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
+                const uint32_t code = v >> PGX_RUN_LEN_BITS, len = v & PGX_RUN_LEN_MAX;
+                const uint32_t tp = min(len, relp), ts = min(len, rels);
+                const uint32_t m = (mrow >> (3 * code)) & 7u;
+                const bool hit = (code == cv);
+                total += len;
+                relp -= tp;
+                rels -= ts;
+                iap += hit ? tp : 0u;
+                ias += hit ? ts : 0u;
+                ibp += tp * m;
+                ibs += ts * m;
+            }
+            if (it == 0) {
+                A0 = a + iap;
+                B0 = b + ibp;
+                // pos1 is served by this block when it lies strictly inside it (a probe AT the block end
+                // belongs to the next block, whose header may carry a different quirk value), or at the
+                // end of the BWT
+                if (d1 < (uint64_t)total || (rels == 0 && lo + 1 == img.n_blocks)) {
+                    A1 = a + ias;
+                    B1 = b + ibs;
+                    done = true;
+                }
+            } else {
+                A1 = a + iap;
+                B1 = b + ibp;
+            }
+        }
     }
-    // pos1 is served by this block when it lies strictly inside it (a probe AT the block end belongs
-    // to the next block, whose header may carry a different quirk value), or at the end of the BWT
-    if (d1 < (uint64_t)total || (rel1 == 0 && lo + 1 == img.n_blocks)) {
-        A0 = a + ia0;
-        A1 = a + ia1;
-        dB = (uint64_t)(int64_t)(int32_t)idb;
-        return;
-    }
-    uint64_t B0, B1;
-    pgx_rank_ab<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, pos1, cv, mrow, A1, B1);
-    pgx_rank_ab<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, pos0, cv, mrow, A0, B0);
     dB = B1 - B0;
 }
 

@@ -92,34 +92,46 @@ class ImageEmu:
         return A & M64, B & M64
 
     def rank_pair(self, pos0, pos1, cv, mrow):
-        """pgx_rank_pair: one decode of pos0's block serves both probes when it also covers pos1"""
+        """pgx_rank_pair: a two-trip loop; trip 0 decodes pos0's block and serves pos1 too when it covers it"""
         c = self.c
         p0, p1 = min(pos0, c.n), min(pos1, c.n)
-        b = self.find_block(p0)
-        cnt, ents, _ = self.block_counts(b)
-        start = sum(cnt[i] for i in range(6) if not (c.excl_mask >> i) & 1)
-        a = cnt[cv]
-        rel0 = p0 - start
-        d1 = (p1 - start) & M64
-        rel1 = min(d1, 0xFFFFFFFF)
-        ia0 = ia1 = idb = 0
-        for code, ln in ents:
-            t0, t1 = min(ln, rel0), min(ln, rel1)
-            rel0 -= t0
-            rel1 -= t1
-            if code == cv:
-                ia0 += t0
-                ia1 += t1
-            idb = (idb + (t1 - t0) * ((mrow >> (3 * code)) & 7)) & 0xFFFFFFFF
+        A0 = A1 = B0 = B1 = 0
+        done = False
+        for it in (0, 1):
+            if done:
+                continue
+            p = p1 if it else p0
+            b = self.find_block(p)
+            cnt, ents, _ = self.block_counts(b)
+            start = sum(cnt[i] for i in range(6) if not (c.excl_mask >> i) & 1)
+            a = cnt[cv]
+            bw = sum(cnt[i] * ((mrow >> (3 * i)) & 7) for i in range(6))
+            relp = p - start
+            d1 = (p1 - start) & M64
+            rels = 0 if it else min(d1, 0xFFFFFFFF)
+            iap = ibp = ias = ibs = total = 0
+            for code, ln in ents:
+                tp, ts = min(ln, relp), min(ln, rels)
+                m = (mrow >> (3 * code)) & 7
+                total += ln
+                relp -= tp
+                rels -= ts
+                if code == cv:
+                    iap += tp
+                    ias += ts
+                ibp += tp * m
+                ibs += ts * m
+            if it == 0:
+                A0, B0 = a + iap, bw + ibp
+                if d1 < total or (rels == 0 and b + 1 == c.n_blocks):
+                    A1, B1, done = a + ias, bw + ibs, True
+            else:
+                A1, B1 = a + iap, bw + ibp
+        out = (A0 & M64, A1 & M64, (B1 - B0) & M64)
         A0f, B0f = self.rank_ab(pos0, cv, mrow)
         A1f, B1f = self.rank_ab(pos1, cv, mrow)
-        total = sum(ln for _, ln in ents)
-        if d1 < total or (rel1 == 0 and b + 1 == c.n_blocks):
-            dB = idb - (1 << 32) if idb >= (1 << 31) else idb
-            out = ((a + ia0) & M64, (a + ia1) & M64, dB & M64)
-            assert out == (A0f, A1f, (B1f - B0f) & M64), (pos0, pos1, cv, mrow)
-            return out
-        return A0f, A1f, (B1f - B0f) & M64
+        assert out == (A0f, A1f, (B1f - B0f) & M64), (pos0, pos1, cv, mrow)
+        return out
 
     def rank6_true(self, pos):
         return [self.rank_ab(pos, code, 0)[0] for code in range(6)]
