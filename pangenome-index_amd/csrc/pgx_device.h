@@ -8,7 +8,7 @@
 #include "pgx_image.h"
 
 #define PGX_FM_THREADS 256
-#define PGX_FM_WAVES_PER_SIMD 3 // __launch_bounds__ 2nd argument: caps the kernel at 128 VGPRs
+#define PGX_FM_WAVES_PER_SIMD 4 // __launch_bounds__ 2nd argument: caps the kernel at 128 VGPRs
 
 // passed by value to every kernel (all pointers are device pointers)
 struct PgxDevImage {
