@@ -136,6 +136,17 @@ pgx_status pgx_tag_query_batch(pgx_index *h, int device, const uint64_t *start, 
                                uint64_t n, uint64_t *run_nums, uint64_t *pos_offsets,
                                uint64_t *positions, uint64_t positions_cap, uint64_t *n_overflow);
 
+/* FastLocate::count / count_encoded (include/pangenome_index/r-index.hpp:540-556): backward search of
+ * every read; out[i] = final BWT range, {1, 0} when empty (the query_tags path, src/query_tags.cpp:88-96).
+ * PGX_ERR_UNSUPPORTED in COMPAT mode on an encoded index without N: the reference's rankAt_encoded
+ * mis-parses such blocks (it always reads six cumulative varints, src/r-index.cpp:578). */
+typedef struct {
+    uint64_t first;
+    uint64_t second;
+} pgx_range;
+pgx_status pgx_count_batch(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
+                           pgx_range *out);
+
 /* ---- the hot path: find_mems over a batch of reads ----------------------------------------- */
 #define PGX_RUN_TAGS 1u    /* also run the tag queries of find_mems.cpp:129 */
 #define PGX_RUN_TIMING 2u  /* record HIP events around each kernel (pgx_batch_timing)           */

@@ -498,6 +498,70 @@ orc_biint orc_forward_extend(const orc_ri *r, int mode, orc_biint in, uint8_t a)
     return out;
 }
 
+/* EncodedBlock::rank_of_code, src/r-index.cpp:114-131 */
+static uint64_t enc_rank_of_code(const orc_ri *r, uint64_t loc, uint64_t end_pos, int target_code, uint64_t rel) {
+    uint64_t rank = 0, cur = 0;
+    while (loc < end_pos) {
+        uint8_t header = r->stream[loc++];
+        int code = (header >> 5) & 7;
+        uint64_t prefix = header & 0x1F;
+        uint64_t run_length = prefix < 31 ? prefix + 1 : 32 + bytecode_read(r->stream, r->stream_n, &loc, NULL);
+        if (code == target_code) {
+            if (cur + run_length > rel) { rank += (rel - cur); break; }
+            rank += run_length;
+        }
+        cur += run_length;
+        if (cur > rel) break;
+    }
+    return rank;
+}
+
+/* FastLocate::rankAt_encoded, src/r-index.cpp:570-590 (legacy rankAt :558-568) */
+static uint64_t rankAt_literal(const orc_ri *r, uint64_t pos, uint8_t symbol) {
+    uint64_t bid = 0, bstart = 0;
+    ef_predecessor(&r->blocks_start_pos, pos, &bid, &bstart);
+    if (!r->encoded) {
+        const lblock_t *b = &r->blocks[bid];
+        return lblock_rankAt(b, pos - bstart, symbol) + b->cum[r->sym_map[symbol]];
+    }
+    uint64_t loc = iv_get(&r->enc_starts, bid);
+    uint64_t end_pos = (bid + 1 < r->enc_starts.n) ? iv_get(&r->enc_starts, bid + 1) : r->stream_n;
+    uint64_t cum[6];
+    enc_read_cumulative(r, &loc, 6, cum); /* EncodedBlock blk(..., 6, ...): always six entries (quirk 3) */
+    int target_code = 0;                  /* symbol_to_code, r-index.hpp:664-667: unknown -> 0 */
+    for (int i = 0; i < 6; i++) if (NUC[i] == symbol) target_code = i;
+    return enc_rank_of_code(r, loc, end_pos, target_code, pos - bstart) + cum[target_code];
+}
+
+void orc_count(const orc_ri *r, int mode, const uint8_t *read, uint64_t len, uint64_t *first, uint64_t *second) {
+    uint64_t lo = 0, hi = r->sequence_size - 1; /* {0, bwt_size() - 1}, r-index.hpp:541,551 */
+    for (uint64_t i = len; i > 0; i--) {
+        const uint8_t sym = read[i - 1];
+        if (mode == ORC_MODE_STRICT) {
+            int code = -1;
+            for (int c = 1; c < 6; c++) if (NUC[c] == sym && r->sym_map[sym] != 0) code = c;
+            if (code < 0 || lo > hi) { lo = 1; hi = 0; continue; }
+            uint64_t a[6], b[6];
+            orc_rank6_true(r, lo, a);
+            orc_rank6_true(r, hi + 1, b);
+            if (b[code] == a[code]) { lo = 1; hi = 0; continue; }
+            lo = a[code] + r->C[r->sym_map[sym]];
+            hi = lo + (b[code] - a[code]) - 1;
+            continue;
+        }
+        /* LF (src/r-index.cpp:650-687) / LF_encoded (:689-711) */
+        if (!r->encoded && !r->sym_map[sym]) { lo = 1; hi = 0; continue; } /* :653 */
+        if (lo > hi) { lo = 1; hi = 0; continue; }
+        uint64_t f = rankAt_literal(r, lo, sym);
+        uint64_t inside = rankAt_literal(r, hi + 1, sym) - f;
+        if (inside == 0) { lo = 1; hi = 0; continue; }
+        lo = f + r->C[r->sym_map[sym]];
+        hi = lo + inside - 1;
+    }
+    *first = lo;
+    *second = hi;
+}
+
 typedef struct { orc_mem *v; uint64_t n, cap, total; } memsink_t;
 static inline void sink_push(memsink_t *s, orc_mem m) {
     if (s->n < s->cap) s->v[s->n++] = m;

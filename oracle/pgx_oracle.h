@@ -90,6 +90,13 @@ uint64_t orc_find_all_mems(const orc_ri *r, int mode, const uint8_t *read, uint6
                            uint64_t min_len, uint64_t min_occ, orc_mem *out, uint64_t cap,
                            uint64_t *n_ext);
 
+/* ---- query_tags path: FastLocate::count / count_encoded, r-index.hpp:540-556 ---- */
+/* returns the final range; an empty range is (1, 0) like the reference's {1, 0}.
+ * COMPAT: literal LF (src/r-index.cpp:650-687, legacy: unknown symbols are rejected :653) or LF_encoded
+ * (:689-711 over rankAt_encoded :570-590, which always reads SIX cumulative varints: quirk 3 --
+ * wrong-but-deterministic on an encoded index without N).  STRICT: textbook backward search. */
+void orc_count(const orc_ri *r, int mode, const uint8_t *read, uint64_t len, uint64_t *first, uint64_t *second);
+
 /* ---- tag array ---- */
 orc_tags *orc_tags_load(const char *path, int format);
 void orc_tags_free(orc_tags *t);

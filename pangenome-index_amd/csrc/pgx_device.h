@@ -36,6 +36,8 @@ __global__ void pgx_rank_kernel(PgxDevImage img, const uint64_t *pos, uint64_t n
 template <bool LDS_IMAGE>
 __global__ void pgx_extend_kernel(PgxDevImage img, const pgx_biint *in, const uint8_t *sym, const uint8_t *forward, uint64_t n,
                                   pgx_biint *out);
+template <bool LDS_IMAGE>
+__global__ void pgx_count_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads, pgx_range *out);
 __global__ void pgx_scan_partial_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, uint64_t *block_sums);
 __global__ void pgx_scan_sums_kernel(uint64_t *block_sums, uint64_t nb);
 __global__ void pgx_scan_apply_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, const uint64_t *block_sums,

@@ -63,7 +63,10 @@ typedef struct {
     uint32_t tag_dir_shift;
     uint32_t has_tags;
     uint32_t mode;
-    uint32_t pad_;
+    uint32_t count_supported; /* 0: COMPAT count on an encoded index without N (the reference mis-parses it, quirk 3) */
+    /* unidirectional backward search (FastLocate::count / count_encoded): per read byte the nuc code
+     * ranked (bits 0..2), the C slot (bits 3..5) and a "no match" flag (bit 24) */
+    uint32_t cnt_tab[256];
 } PgxConsts;
 
 #endif

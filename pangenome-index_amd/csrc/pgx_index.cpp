@@ -270,6 +270,32 @@ void build_ext_tables(const RiFile &ri, uint32_t mode, PgxConsts &c) {
         }
 }
 
+// Unidirectional backward search tables (query_tags path).
+//   legacy  FastLocate::count -> LF (src/r-index.cpp:650-687): symbols with sym_map == 0 are rejected
+//           (:653); rankAt counts runs whose byte equals the symbol (r-index.hpp:180-221)
+//   encoded count_encoded -> LF_encoded (:689-711) -> rankAt_encoded (:570-590): no rejection, the ranked
+//           code is symbol_to_code(sym) (unknown -> 0).  rankAt_encoded always parses SIX cumulative
+//           varints (quirk 3): on an encoded index without N the reference mis-parses every block, which
+//           a rank image cannot (and should not) reproduce -> count_supported = 0 in COMPAT.
+static void build_count_table(const RiFile &ri, uint32_t mode, PgxConsts &c) {
+    c.count_supported = 1;
+    for (int byte = 0; byte < 256; byte++) {
+        const int code = code_of_byte((uint8_t)byte);
+        const uint32_t v = ri.sym_map[byte];
+        uint32_t e;
+        if (mode == PGX_MODE_STRICT) {
+            const bool ok = code >= 1 && v != 0;
+            e = ok ? PGX_EXT_MAKE(code, v, 0, 0) : PGX_EXT_MAKE(0, 0, 0, 1);
+        } else if (!ri.encoded) {
+            e = v != 0 ? PGX_EXT_MAKE(code, v, 0, 0) : PGX_EXT_MAKE(0, 0, 0, 1);
+        } else {
+            e = PGX_EXT_MAKE(code >= 0 ? code : 0, v, 0, 0);
+        }
+        c.cnt_tab[byte] = e;
+    }
+    if (mode != PGX_MODE_STRICT && ri.encoded && ri.C.size() != 6) c.count_supported = 0;
+}
+
 // ------------------------------------------------------------------------------------------
 static void put_block(std::vector<uint8_t> &blocks, const uint64_t c6[6], const std::vector<std::pair<uint8_t, uint32_t>> &ent) {
     uint32_t dw[16] = {0};
@@ -290,6 +316,7 @@ void build_rank_image(const RiFile &ri, uint32_t mode, HostImage &img) {
     c.n = ri.sequence_size;
     c.mode = mode;
     build_ext_tables(ri, mode, c);
+    build_count_table(ri, mode, c);
     // Device blocks must refine the reference's blocks only when a header slot carries the
     // reference-block cumulative endmarker count (legacy layout, absent symbol, COMPAT).
     const bool refine = c.excl_mask != 0;
@@ -440,6 +467,7 @@ extern "C" pgx_status pgx_index_open(const char *ri_path, const char *tags_path,
                                      uint32_t mode, pgx_index **out) {
     PGX_GUARD_BEGIN
     if (!ri_path || !out) throw Error(PGX_ERR_ARG, "pgx_index_open: null argument");
+    if (mode != PGX_MODE_COMPAT && mode != PGX_MODE_STRICT) throw Error(PGX_ERR_ARG, "pgx_index_open: bad mode");
     *out = nullptr;
     std::vector<uint8_t> f, t;
     try { f = read_whole_file(ri_path); }

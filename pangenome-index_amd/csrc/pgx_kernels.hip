@@ -470,3 +470,44 @@ pgx_compact_mems_kernel(uint64_t n_reads, const uint64_t *__restrict__ slot_off,
     for (uint32_t t = 0; t < c; t++) mems[dst + t] = slots[src + t];
 }
 
+
+// ------------------------------------------------------------------------------------------
+// query_tags path: FastLocate::count / count_encoded (r-index.hpp:540-556), one lane
+// per read: range = {0, n-1}; for each symbol from the end: LF (src/r-index.cpp:650-711).  An empty
+// range is {1, 0} and stays empty.
+template <bool LDS_IMAGE>
+__global__ void __launch_bounds__(256)
+pgx_count_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets, uint64_t n_reads,
+                 pgx_range *__restrict__ out) {
+    __shared__ uint32_t s_cnt[256];
+    __shared__ uint64_t s_C[8];
+    PGX_LDS_CARVE(img);
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_cnt[i] = img.consts->cnt_tab[i];
+    if (threadIdx.x < 8) s_C[threadIdx.x] = img.consts->C[threadIdx.x];
+    if (LDS_IMAGE) {
+        const uint32_t nb4 = img.n_blocks * 4;
+        for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) lds_blocks[i] = img.blocks[i];
+        for (uint64_t i = threadIdx.x; i < img.dir_entries; i += blockDim.x) lds_dir[i] = img.dir[i];
+        for (uint32_t i = threadIdx.x; i < img.n_blocks; i += blockDim.x) lds_blow[i] = img.blow[i];
+    }
+    __syncthreads();
+    const uint64_t rid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (rid >= n_reads) return;
+    const uint64_t base = offsets[rid], len = offsets[rid + 1] - base;
+    uint64_t lo = 0, hi = img.n - 1;
+    if (img.n == 0) { lo = 1; hi = 0; }
+    for (uint64_t i = len; i > 0 && lo <= hi; i--) {
+        const uint32_t e = s_cnt[reads[base + i - 1]];
+        if (PGX_EXT_KILL(e)) { lo = 1; hi = 0; break; }
+        uint64_t A0, A1, dB;
+        pgx_rank_pair<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, lo, hi + 1, PGX_EXT_CV(e), 0u, A0, A1, dB);
+        if (A1 == A0) { lo = 1; hi = 0; break; } // sym_inside == 0 -> {1, 0}
+        lo = A0 + s_C[PGX_EXT_V(e)];
+        hi = lo + (A1 - A0) - 1;
+    }
+    pgx_range r;
+    r.first = lo; r.second = hi;
+    out[rid] = r;
+}
+template __global__ void pgx_count_kernel<false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, pgx_range *);
+template __global__ void pgx_count_kernel<true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, pgx_range *);

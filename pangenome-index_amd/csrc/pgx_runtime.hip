@@ -557,6 +557,42 @@ extern "C" pgx_status pgx_extend_batch(pgx_index *h, int device, const pgx_biint
     PGX_GUARD_END
 }
 
+extern "C" pgx_status pgx_count_batch(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
+                                      pgx_range *out) {
+    PGX_GUARD_BEGIN
+    if (!h || !offsets || (n_reads && (!out || (!reads && offsets[n_reads] != offsets[0]))))
+        throw Error(PGX_ERR_ARG, "pgx_count_batch: null argument");
+    if (!h->has_rank) throw Error(PGX_ERR_ARG, "pgx_count_batch: index opened without an r-index");
+    if (!h->img.consts.count_supported)
+        throw Error(PGX_ERR_UNSUPPORTED, "count_encoded on an encoded index without N mis-parses block headers in the reference "
+                                         "(rankAt_encoded reads six cumulative varints); open the index in PGX_MODE_STRICT");
+    pgx_device_image *d = device_image(h, device);
+    if (!n_reads) return PGX_OK;
+    DevBuf dr, doff, dout;
+    try {
+        const uint64_t lo = offsets[0], bytes = offsets[n_reads] - lo;
+        std::vector<uint64_t> reb(n_reads + 1);
+        for (uint64_t i = 0; i <= n_reads; i++) {
+            if (i && offsets[i] < offsets[i - 1]) throw Error(PGX_ERR_ARG, "pgx_count_batch: offsets must be non-decreasing");
+            reb[i] = offsets[i] - lo;
+        }
+        dr.ensure(bytes + 16); doff.ensure((n_reads + 1) * 8); dout.ensure(n_reads * sizeof(pgx_range));
+        if (bytes) HIPCHECK(hipMemcpy(dr.p, reads + lo, bytes, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(doff.p, reb.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice));
+        if (d->lds_bytes)
+            hipLaunchKernelGGL(pgx_count_kernel<true>, dim3(grid_for(n_reads, 256)), dim3(256), d->lds_bytes, 0, d->img, dr.as<uint8_t>(),
+                               doff.as<uint64_t>(), n_reads, dout.as<pgx_range>());
+        else
+            hipLaunchKernelGGL(pgx_count_kernel<false>, dim3(grid_for(n_reads, 256)), dim3(256), 0, 0, d->img, dr.as<uint8_t>(),
+                               doff.as<uint64_t>(), n_reads, dout.as<pgx_range>());
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpy(out, dout.p, n_reads * sizeof(pgx_range), hipMemcpyDeviceToHost));
+    } catch (...) { dr.release(); doff.release(); dout.release(); throw; }
+    dr.release(); doff.release(); dout.release();
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
 extern "C" pgx_status pgx_tag_query_batch(pgx_index *h, int device, const uint64_t *start, const uint64_t *end, uint64_t n,
                                           uint64_t *run_nums, uint64_t *pos_offsets, uint64_t *positions, uint64_t positions_cap,
                                           uint64_t *n_overflow) {

@@ -17,6 +17,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../../include/pgx.h"
@@ -70,6 +71,10 @@ public:
     bi_interval backward_extend(const bi_interval &b, size_t symbol) { return extend(b, symbol, false); }
     bi_interval forward_extend(const bi_interval &b, size_t symbol) { return extend(b, symbol, true); }
 
+    // r-index.hpp:540-556: unidirectional backward search; the empty range is {1, 0}
+    std::pair<size_t, size_t> count_encoded(std::string &pattern) const { return count_impl(pattern); }
+    std::pair<size_t, size_t> count(std::string &pattern) { return count_impl(pattern); }
+
     // library handle (for the batch entry points of algorithm.hpp)
     pgx_index *handle() const { return h_; }
     int device() const { return device_; }
@@ -92,6 +97,15 @@ private:
         uint64_t c[8];
         pgx_index_tables(h_, sym_map.data(), c, nullptr);
         C.assign(c, c + info_.sigma);
+    }
+
+    std::pair<size_t, size_t> count_impl(const std::string &pattern) const {
+        if (!h_) throw std::runtime_error("FastLocate: no index loaded");
+        const uint64_t offs[2] = {0, pattern.size()};
+        pgx_range r{1, 0};
+        if (pgx_count_batch(h_, device_, reinterpret_cast<const uint8_t *>(pattern.data()), offs, 1, &r) != PGX_OK)
+            throw std::runtime_error(pgx_last_error());
+        return {(size_t)r.first, (size_t)r.second};
     }
 
     bi_interval extend(const bi_interval &b, size_t symbol, bool fwd) {

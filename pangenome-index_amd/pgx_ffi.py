@@ -91,6 +91,7 @@ def lib():
     L.pgx_write_compact_tags.argtypes = [C.c_char_p, p, p, u64]
     L.pgx_rank_batch.argtypes = [p, C.c_int, p, u64, C.c_int, p]
     L.pgx_extend_batch.argtypes = [p, C.c_int, p, p, p, u64, p]
+    L.pgx_count_batch.argtypes = [p, C.c_int, p, p, u64, p]
     L.pgx_tag_query_batch.argtypes = [p, C.c_int, p, p, u64, p, p, p, u64, C.POINTER(u64)]
     L.pgx_batch_create.argtypes = [p, C.c_int, p, p, u64, C.POINTER(p)]
     L.pgx_batch_run.argtypes = [p, u64, u64, u32, p]
@@ -186,6 +187,16 @@ class Index:
         fw = np.ascontiguousarray(forward, dtype=np.uint8)
         out = np.zeros(len(iv), dtype=BIINT_DTYPE)
         _check(self.L.pgx_extend_batch(self.h, device, iv.ctypes.data, sy.ctypes.data, fw.ctypes.data, len(iv), out.ctypes.data))
+        return out
+
+    def count_batch(self, reads_cat, offsets, device=0):
+        """FastLocate::count / count_encoded for every read -> uint64[n, 2] (first, second); empty = (1, 0)"""
+        reads_cat = np.ascontiguousarray(reads_cat, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        out = np.zeros((n, 2), dtype=np.uint64)
+        _check(self.L.pgx_count_batch(self.h, device, reads_cat.ctypes.data if len(reads_cat) else None, offsets.ctypes.data, n,
+                                      out.ctypes.data))
         return out
 
     def tag_query_batch(self, start, end, device=0):

@@ -25,7 +25,8 @@ class Consts:
         self.sigma, self.excl_mask, self.dir_shift, self.n_blocks = struct.unpack_from("<4I", raw, o); o += 16
         self.dir_entries, = struct.unpack_from("<Q", raw, o); o += 8
         self.n_tag_runs, self.tag_dir_entries = struct.unpack_from("<2Q", raw, o); o += 16
-        self.tag_dir_shift, self.has_tags, self.mode, _ = struct.unpack_from("<4I", raw, o); o += 16
+        self.tag_dir_shift, self.has_tags, self.mode, self.count_supported = struct.unpack_from("<4I", raw, o); o += 16
+        self.cnt_tab = struct.unpack_from("<256I", raw, o); o += 1024
         assert o == len(raw), (o, len(raw))
 
 
@@ -192,6 +193,23 @@ class ImageEmu:
                 j -= 1
             x = nxt
         return out, next_
+
+    def count(self, read):
+        """pgx_count_kernel, one read"""
+        b = read.encode() if isinstance(read, str) else bytes(read)
+        lo, hi = 0, self.c.n - 1
+        for ch in reversed(b):
+            if lo > hi:
+                break
+            e = self.c.cnt_tab[ch]
+            if (e >> 24) & 1:
+                return (1, 0)
+            A0, A1, _ = self.rank_pair(lo, hi + 1, e & 7, 0)
+            if A1 == A0:
+                return (1, 0)
+            lo = A0 + self.c.C[(e >> 3) & 7]
+            hi = lo + (A1 - A0) - 1
+        return (lo, hi)
 
     # tags
     def tag_rank(self, x):

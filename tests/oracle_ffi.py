@@ -81,6 +81,7 @@ def lib():
     L.orc_forward_extend.argtypes = [p, C.c_int, BiInt, C.c_uint8]
     L.orc_find_all_mems.restype = u64
     L.orc_find_all_mems.argtypes = [p, C.c_int, C.c_char_p, u64, u64, u64, C.POINTER(Mem), u64, C.POINTER(u64)]
+    L.orc_count.argtypes = [p, C.c_int, C.c_char_p, u64, C.POINTER(u64), C.POINTER(u64)]
     L.orc_tags_load.restype, L.orc_tags_load.argtypes = p, [C.c_char_p, C.c_int]
     L.orc_tags_free.argtypes = [p]
     for name in ("n_runs", "bwt_intervals_size", "n_items", "n_starts", "file_bytes_consumed"):
@@ -166,6 +167,12 @@ class RIndex:
         for ch in reversed(pat):
             tri = self.bwd(tri, ch, mode)
         return tri
+
+    def count(self, read, mode=MODE_COMPAT):
+        b = read.encode() if isinstance(read, str) else bytes(read)
+        lo, hi = C.c_uint64(0), C.c_uint64(0)
+        self.L.orc_count(self.h, mode, b, len(b), C.byref(lo), C.byref(hi))
+        return lo.value, hi.value
 
     def find_all_mems(self, read, min_len, min_occ, mode=MODE_COMPAT, with_ext=False):
         b = read.encode() if isinstance(read, str) else bytes(read)
