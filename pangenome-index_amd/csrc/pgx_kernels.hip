@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(PGX_FM_THREADS, PGX_FM_WAVES_PER_SIMD)
 pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                      uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
                      pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
-                     unsigned long long *__restrict__ cursor) {
+                     unsigned long long *__restrict__ cursor, uint64_t slot_base) {
     __shared__ uint32_t s_ext[512];
     __shared__ uint64_t s_C[8];
     PGX_LDS_CARVE(img);
@@ -273,7 +273,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                 rid = rnext + rank;
                 base = offsets[rid];
                 len = (int32_t)(offsets[rid + 1] - base);
-                slot = slot_off[rid];
+                slot = slot_off[rid] - slot_base; // slots are reused per chunk of reads (pgx_batch_run)
                 x = 0; nm = 0;
                 begin(); // may leave the lane idle again (read shorter than min_len)
                 if (ph == 0) ph = -1; // served in this round; becomes idle again below
@@ -331,9 +331,9 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
 }
 
 template __global__ void pgx_find_mems_kernel<false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                     const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *);
+                                                     const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t);
 template __global__ void pgx_find_mems_kernel<true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                    const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *);
+                                                    const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t);
 
 // ------------------------------------------------------------------------------------------
 // primitives for tests (mirror rank_at_cached_encoded / backward_extend_encoded / forward_...)
@@ -461,12 +461,14 @@ pgx_scan_apply_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, co
 // ------------------------------------------------------------------------------------------
 // MEM compaction: slots (worst-case capacity per read) -> dense CSR in read order
 __global__ void __launch_bounds__(256)
-pgx_compact_mems_kernel(uint64_t n_reads, const uint64_t *__restrict__ slot_off, const pgx_mem *__restrict__ slots,
-                        const uint32_t *__restrict__ mem_count, const uint64_t *__restrict__ mem_off, pgx_mem *__restrict__ mems) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_reads) return;
+pgx_compact_mems_kernel(uint64_t first_read, uint64_t n_reads, const uint64_t *__restrict__ slot_off, uint64_t slot_base,
+                        const pgx_mem *__restrict__ slots, const uint32_t *__restrict__ mem_count,
+                        const uint64_t *__restrict__ local_off, uint64_t mem_base, pgx_mem *__restrict__ mems) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // read first_read + t of this chunk
+    if (t >= n_reads) return;
+    const uint64_t i = first_read + t;
     const uint32_t c = mem_count[i];
-    const uint64_t src = slot_off[i], dst = mem_off[i];
+    const uint64_t src = slot_off[i] - slot_base, dst = mem_base + local_off[t];
     for (uint32_t t = 0; t < c; t++) mems[dst + t] = slots[src + t];
 }
 

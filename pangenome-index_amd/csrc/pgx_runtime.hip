@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <vector>
@@ -64,6 +65,24 @@ struct DevBuf { // grow-only device buffer
             throw Error(PGX_ERR_NOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed: " + hipGetErrorString(e));
         }
         cap = want;
+    }
+    // grow while keeping the first `keep` bytes (device-to-device copy)
+    void ensure_keep(size_t bytes, size_t keep) {
+        if (bytes <= cap) return;
+        void *old = p;
+        size_t want = bytes + bytes / 2 + 256;
+        void *np = nullptr;
+        hipError_t e = hipMalloc(&np, want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            throw Error(PGX_ERR_NOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed: " + hipGetErrorString(e));
+        }
+        if (old && keep) {
+            e = hipMemcpy(np, old, keep, hipMemcpyDeviceToDevice);
+            if (e != hipSuccess) { (void)hipFree(np); throw Error(PGX_ERR_HIP, std::string("hipMemcpy failed: ") + hipGetErrorString(e)); }
+        }
+        if (old) (void)hipFree(old);
+        p = np; cap = want;
     }
     void release() {
         if (p) (void)hipFree(p);
@@ -276,11 +295,17 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
 }
 
 // ------------------------------------------------------------------------------------------
+struct pgx_chunk { uint64_t r0, r1, slot_base, slots; }; // consecutive reads sharing one pass over the slot buffer
+
 struct pgx_batch {
     pgx_index *h = nullptr;
     pgx_device_image *dimg = nullptr;
     int device = 0;
     uint64_t n_reads = 0, read_bytes = 0;
+    std::vector<uint64_t> h_offsets; // rebased host copy (chunk planning)
+    std::vector<pgx_chunk> chunks;   // plan of the last run (reused while min_len / budget are unchanged)
+    bool plan_valid = false;
+    uint64_t plan_min_len = 0, plan_budget = 0;
     DevBuf reads, offsets;
     // run state
     DevBuf slot_off, slots, mem_count, mem_off, mems, scan_tmp, counters;
@@ -338,6 +363,7 @@ extern "C" pgx_status pgx_batch_create(pgx_index *h, int device, const uint8_t *
     for (uint64_t i = 0; i <= n_reads; i++) reb[i] = offsets[i] - lo;
     b->offsets.ensure((n_reads + 1) * 8);
     HIPCHECK(hipMemcpy(b->offsets.p, reb.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice));
+    b->h_offsets = std::move(reb);
     *out = b.release();
     return PGX_OK;
     PGX_GUARD_END
@@ -370,46 +396,87 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     unsigned long long *d_nover = d_next + 1;
 
     record(b, 0, s);
-    // 1. worst-case MEM slots per read
+    // 1. worst-case MEM slots per read: cap = min(len, len - min_len + 1).  The slot buffer is bounded by
+    //    a budget; batches whose worst case exceeds it are processed in chunks of consecutive reads.
     b->slot_off.ensure((n + 1) * 8);
     scan_excl(2, b->offsets.p, n, min_len, b->slot_off.as<uint64_t>(), b->scan_tmp, s);
-    const uint64_t total_slots = read_u64(b->slot_off.as<uint64_t>() + n, s);
-    b->slots.ensure((total_slots ? total_slots : 1) * sizeof(pgx_mem));
     b->mem_count.ensure((n ? n : 1) * 4);
-    // 2. the hot kernel
-    record(b, 1, s);
+    b->mem_off.ensure((n + 1) * 8);
+    uint64_t budget_slots = (16ull << 30) / sizeof(pgx_mem);
+    if (const char *e = std::getenv("PGX_SLOT_BUDGET_MB")) budget_slots = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10)) * (1ull << 20) / sizeof(pgx_mem);
+    if (!b->plan_valid || b->plan_min_len != min_len || b->plan_budget != budget_slots) { // cached across runs
+        b->chunks.clear();
+        uint64_t r0 = 0, base = 0, acc = 0;
+        for (uint64_t i = 0; i < n; i++) {
+            const uint64_t len = b->h_offsets[i + 1] - b->h_offsets[i];
+            const uint64_t cap = len < min_len ? 0 : std::min<uint64_t>(len, len - min_len + 1);
+            if (acc && acc + cap > budget_slots) { b->chunks.push_back({r0, i, base, acc}); r0 = i; base += acc; acc = 0; }
+            acc += cap;
+        }
+        if (n) b->chunks.push_back({r0, n, base, acc});
+        b->plan_valid = true; b->plan_min_len = min_len; b->plan_budget = budget_slots;
+    }
+    const std::vector<pgx_chunk> &chunks = b->chunks;
+    uint64_t max_slots = 1;
+    for (auto &c : chunks) max_slots = std::max(max_slots, c.slots);
+    b->slots.ensure(max_slots * sizeof(pgx_mem));
+    // 2. the hot kernel, 3. CSR offsets + compaction (per chunk)
+    float ms_fm = 0, ms_cp = 0;
+    uint64_t mem_base = 0;
+    int occ = 0, cus = 0;
     if (n) {
         // persistent grid: as many workgroups as the device keeps resident (no inter-workgroup
         // dependency exists, so any grid size is correct; this one avoids a tail of late blocks)
-        unsigned long long *d_cursor = d_next + 5; // counters: [0] extensions [1] tag overflows [2] big [3] large [4] max large [5] read cursor
-        int occ = 0, cus = 0;
         const void *kfn = b->dimg->lds_bytes ? (const void *)pgx_find_mems_kernel<true> : (const void *)pgx_find_mems_kernel<false>;
         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, PGX_FM_THREADS, b->dimg->lds_bytes));
         HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
         if (occ < 1) occ = 1;
-        unsigned grid = grid_for(n, 64);
+    }
+    unsigned long long *d_cursor = d_next + 5; // counters: [0] extensions [1] tag overflows [2] big [3] large [4] max large [5] read cursor
+    for (size_t ci = 0; ci < chunks.size(); ci++) {
+        const pgx_chunk &c = chunks[ci];
+        const uint64_t cn = c.r1 - c.r0;
+        unsigned long long start = c.r0;
+        HIPCHECK(hipMemcpyAsync(d_cursor, &start, 8, hipMemcpyHostToDevice, s));
+        record(b, 1, s);
+        unsigned grid = grid_for(cn, 64);
         if (grid > (unsigned)(occ * cus)) grid = (unsigned)(occ * cus);
         if (b->dimg->lds_bytes)
             hipLaunchKernelGGL(pgx_find_mems_kernel<true>, dim3(grid), dim3(PGX_FM_THREADS), b->dimg->lds_bytes, s, img,
-                               b->reads.as<uint8_t>(), b->offsets.as<uint64_t>(), n, min_len, min_occ, b->slot_off.as<uint64_t>(),
-                               b->slots.as<pgx_mem>(), b->mem_count.as<uint32_t>(), d_next, d_cursor);
+                               b->reads.as<uint8_t>(), b->offsets.as<uint64_t>(), c.r1, min_len, min_occ, b->slot_off.as<uint64_t>(),
+                               b->slots.as<pgx_mem>(), b->mem_count.as<uint32_t>(), d_next, d_cursor, c.slot_base);
         else
             hipLaunchKernelGGL(pgx_find_mems_kernel<false>, dim3(grid), dim3(PGX_FM_THREADS), 0, s, img, b->reads.as<uint8_t>(),
-                               b->offsets.as<uint64_t>(), n, min_len, min_occ, b->slot_off.as<uint64_t>(), b->slots.as<pgx_mem>(),
-                               b->mem_count.as<uint32_t>(), d_next, d_cursor);
+                               b->offsets.as<uint64_t>(), c.r1, min_len, min_occ, b->slot_off.as<uint64_t>(), b->slots.as<pgx_mem>(),
+                               b->mem_count.as<uint32_t>(), d_next, d_cursor, c.slot_base);
         HIPCHECK(hipGetLastError());
-        b->timing.find_mems_launches = 1;
+        b->timing.find_mems_launches++;
+        record(b, 2, s);
+        // local CSR offsets of this chunk (mem_off[r0 .. r1] is scratch until the global scan below)
+        uint64_t *local = b->mem_off.as<uint64_t>() + c.r0;
+        scan_excl(0, b->mem_count.as<uint32_t>() + c.r0, cn, 0, local, b->scan_tmp, s);
+        const uint64_t cm = read_u64(local + cn, s);
+        b->mems.ensure_keep((mem_base + cm ? mem_base + cm : 1) * sizeof(pgx_mem), mem_base * sizeof(pgx_mem));
+        hipLaunchKernelGGL(pgx_compact_mems_kernel, dim3(grid_for(cn, 256)), dim3(256), 0, s, c.r0, cn, b->slot_off.as<uint64_t>(),
+                           c.slot_base, b->slots.as<pgx_mem>(), b->mem_count.as<uint32_t>(), (const uint64_t *)local, mem_base,
+                           b->mems.as<pgx_mem>());
+        HIPCHECK(hipGetLastError());
+        record(b, 3, s);
+        mem_base += cm;
+        if (b->timed && chunks.size() > 1) { // events are reused per chunk: accumulate now
+            HIPCHECK(hipStreamSynchronize(s));
+            float t1 = 0, t2 = 0;
+            HIPCHECK(hipEventElapsedTime(&t1, b->ev[1], b->ev[2]));
+            HIPCHECK(hipEventElapsedTime(&t2, b->ev[2], b->ev[3]));
+            ms_fm += t1; ms_cp += t2;
+        }
     }
-    record(b, 2, s);
-    // 3. CSR offsets + compaction
-    b->mem_off.ensure((n + 1) * 8);
-    scan_excl(0, b->mem_count.p, n, 0, b->mem_off.as<uint64_t>(), b->scan_tmp, s);
-    b->n_mems = read_u64(b->mem_off.as<uint64_t>() + n, s);
-    b->mems.ensure((b->n_mems ? b->n_mems : 1) * sizeof(pgx_mem));
-    if (n) {
-        hipLaunchKernelGGL(pgx_compact_mems_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, n, b->slot_off.as<uint64_t>(),
-                           b->slots.as<pgx_mem>(), b->mem_count.as<uint32_t>(), b->mem_off.as<uint64_t>(), b->mems.as<pgx_mem>());
-        HIPCHECK(hipGetLastError());
+    b->n_mems = mem_base;
+    if (chunks.size() != 1) { // global CSR offsets (a single chunk's local offsets already are global)
+        if (chunks.empty()) { record(b, 1, s); record(b, 2, s); }
+        scan_excl(0, b->mem_count.p, n, 0, b->mem_off.as<uint64_t>(), b->scan_tmp, s);
+        b->mems.ensure_keep((b->n_mems ? b->n_mems : 1) * sizeof(pgx_mem), b->n_mems * sizeof(pgx_mem));
+        record(b, 3, s);
     }
     record(b, 3, s);
     // 4. tag queries (find_mems.cpp:129)
@@ -428,8 +495,8 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     b->n_tag_overflow = cnt[1];
     if (b->timed) {
         auto el = [&](int a, int c) { float ms = 0; HIPCHECK(hipEventElapsedTime(&ms, b->ev[a], b->ev[c])); return ms; };
-        b->timing.ms_find_mems = el(1, 2);
-        b->timing.ms_compact = el(2, 3);
+        b->timing.ms_find_mems = chunks.size() > 1 ? ms_fm : el(1, 2);
+        b->timing.ms_compact = chunks.size() > 1 ? ms_cp : el(2, 3);
         if (want_tags) {
             b->timing.ms_tag_locate = el(3, 4); // locate + scans
             b->timing.ms_tag_gather = el(4, 5); // 16-lane small path (gather + sort + unique)

@@ -197,6 +197,24 @@ def test_config2_one_million_reads(xenc, golden):
     _assert_same(res, ref, True)
 
 
+def test_chunked_batches_equal_unchunked(xenc, xy, golden, monkeypatch):
+    """batches whose worst-case MEM slots exceed the slot budget run in chunks of consecutive reads"""
+    for (idx, ri, tags), text, params in ((xenc, "x.newline_separated", (5, 1)), (xy, "bidirectional_test/contigs_xy", (10, 1))):
+        seqs = W.load_sequences(os.path.join(golden, text))
+        cat, offs = W.sample_reads(seqs, 30000, 150, seed=123)
+        whole = idx.find_mems(cat, offs, *params, tags=True)
+        monkeypatch.setenv("PGX_SLOT_BUDGET_MB", "1")  # 32768 slots -> ~130 chunks
+        b = idx.batch(cat, offs)
+        b.run(params[0], params[1], P.RUN_TAGS | P.RUN_TIMING)
+        chunked, launches = b.result(), b.timing().find_mems_launches
+        b.free()
+        monkeypatch.delenv("PGX_SLOT_BUDGET_MB")
+        assert launches > 50
+        _assert_same(chunked, whole, True)
+        ref = O.find_mems_batch(ri, tags, cat, offs, *params, threads=O.lib().orc_max_threads())
+        _assert_same(chunked, ref, True)
+
+
 def test_sharded_equals_unsharded(xenc, golden):
     """contiguous read slices processed independently and concatenated in rank order are
     bit-identical to the unsharded batch (what bench.py --gpus N relies on)."""
