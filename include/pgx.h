@@ -122,6 +122,10 @@ pgx_status pgx_build_rlbwt(const char *text_path, const char *out_rlbwt_path);
 pgx_status pgx_write_compact_tags(const char *out_path, const uint64_t *values,
                                   const uint64_t *lengths, uint64_t n_runs);
 
+/* convert_tags equivalent (src/convert_tags.cpp): build_tags' "algorithm format" -> a query format.
+ * compact = 0: ByteCode format (load_compressed_tags, tag_arrays.cpp:739); 1: sdsl-compact (find_mems.cpp:79). */
+pgx_status pgx_convert_tags(const char *in_path, const char *out_path, int compact);
+
 /* ---- primitives (tests; mirror the public FastLocate / TagArray query API) ----------------- */
 /* FastLocate::rank_at_cached_encoded (src/r-index.cpp:619-641): out[i*6 .. i*6+sigma) per position;
  * entries >= sigma are zero.  true_codes!=0 returns the six true code ranks instead. */

@@ -8,8 +8,11 @@
 //   pgx_write_compact_tags append_compact_run_streamed + merge_compressed_files_sdsl,
 //                          src/tag_arrays.cpp:940-974, 622-654
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <memory>
+#include <mutex>
+#include <thread>
 
 #include "pgx_host.hpp"
 
@@ -214,13 +217,107 @@ extern "C" pgx_status pgx_build_rindex(const char *rlbwt_path, const char *out_r
     std::vector<uint8_t> out;
     put<uint32_t>(out, 0x6B3741D8u);
     put<uint32_t>(out, 1);
-    put<uint64_t>(out, 1);                    // max_length (SA samples are not built here yet)
+    // ---- SA samples (src/r-index.cpp:993-1130): walk every sequence backwards with psi, record the text
+    //      position at the first (head) and last (tail) BWT position of every logical run
+    std::vector<uint64_t> run_start, run_cum;
+    std::vector<uint8_t> run_sym;
+    {
+        std::vector<uint64_t> seen(256, 0);
+        for (auto &b : blocks)
+            for (auto &ru : b.runs) {
+                run_start.push_back(run_start.empty() ? 0 : 0); // patched below
+                run_sym.push_back(ru.first);
+                run_cum.push_back(seen[ru.first]);
+                seen[ru.first] += ru.second;
+            }
+        uint64_t p = 0, k = 0;
+        for (auto &b : blocks)
+            for (auto &ru : b.runs) { run_start[k++] = p; p += ru.second; }
+    }
+    auto run_of = [&](uint64_t p) { return (uint64_t)(std::upper_bound(run_start.begin(), run_start.end(), p) - run_start.begin()) - 1; };
+    auto run_len = [&](uint64_t r) { return (r + 1 < run_start.size() ? run_start[r + 1] : n) - run_start[r]; };
+    auto psi = [&](uint64_t p, uint64_t r) { return C[sym_map[run_sym[r]]] + run_cum[r] + (p - run_start[r]); }; // r-index.cpp:529-532
+    const uint64_t n_seq = freq[(uint8_t)'\n']; // tot_strings()
+    struct Sample { uint64_t seq_id, seq_offset, run_id; };
+    std::vector<Sample> heads, tails;
+    uint64_t max_length = 1; // Header(): max_length(1)
+    {
+        // run ids of the first n_seq BWT positions by symbol change (src/r-index.cpp:993-1008)
+        std::vector<uint64_t> endmarker_runs(n_seq, 0);
+        {
+            uint64_t rid = 0;
+            uint8_t prev = n_seq ? run_sym[run_of(0)] : 0;
+            for (uint64_t i = 1; i < n_seq; i++) {
+                const uint8_t cur = run_sym[run_of(i)];
+                if (cur == '\n' || cur != prev) { rid++; prev = cur; }
+                endmarker_runs[i] = rid;
+            }
+        }
+        std::mutex mu;
+        std::atomic<uint64_t> next_seq{0};
+        std::atomic<bool> bad{false};
+        auto worker = [&]() {
+            for (;;) {
+                const uint64_t i = next_seq.fetch_add(1);
+                if (i >= n_seq) break;
+                std::vector<Sample> hb, tb;
+                uint64_t seq_offset = 0, rid = endmarker_runs[i];
+                if (i == 0 || rid != endmarker_runs[i - 1]) hb.push_back({i, seq_offset, rid});
+                if (i + 1 >= n_seq || rid != endmarker_runs[i + 1]) tb.push_back({i, seq_offset, rid});
+                uint64_t r = run_of(i);
+                uint8_t sym = run_sym[r];
+                uint64_t pos = psi(i, r);
+                seq_offset++;
+                while (sym != '\n') {
+                    r = run_of(pos);
+                    const uint64_t first = run_start[r], last = first + run_len(r) - 1;
+                    if (pos == first) hb.push_back({i, seq_offset, r});
+                    if (pos == last) tb.push_back({i, seq_offset, r});
+                    sym = run_sym[r];
+                    pos = psi(pos, r);
+                    seq_offset++;
+                    if (seq_offset > n + 1) { bad.store(true); break; } // not a BWT of terminated sequences
+                }
+                for (auto &x : hb) x.seq_offset = seq_offset - 1 - x.seq_offset;
+                for (auto &x : tb) x.seq_offset = seq_offset - 1 - x.seq_offset;
+                std::lock_guard<std::mutex> lk(mu);
+                max_length = std::max(max_length, seq_offset);
+                heads.insert(heads.end(), hb.begin(), hb.end());
+                tails.insert(tails.end(), tb.begin(), tb.end());
+            }
+        };
+        unsigned nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 16u));
+        if (nt > n_seq) nt = (unsigned)std::max<uint64_t>(1, n_seq);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(worker);
+        for (auto &t : th) t.join();
+        if (bad.load()) throw Error(PGX_ERR_FORMAT, "rl_bwt is not the BWT of a newline-terminated collection (psi walk does not end)");
+    }
+    if (heads.size() < total_runs || tails.size() < total_runs)
+        throw Error(PGX_ERR_FORMAT, "rl_bwt is not the BWT of a newline-terminated collection (sampling walk incomplete)");
+    std::stable_sort(heads.begin(), heads.end(), [](const Sample &a, const Sample &b) { return a.run_id < b.run_id; });
+    std::sort(tails.begin(), tails.end(), [](const Sample &a, const Sample &b) {
+        return a.seq_id < b.seq_id || (a.seq_id == b.seq_id && a.seq_offset < b.seq_offset);
+    });
+    auto bits_length = [](uint64_t x) { return (uint8_t)(x ? hi_bit(x) + 1 : 0); }; // sdsl::bits::length
+    auto pack = [&](uint64_t id, uint64_t off) { return id * max_length + off; };   // r-index.hpp:420-422
+    put<uint64_t>(out, max_length);
     put<uint64_t>(out, encoded ? 1ull : 0ull); // flags
-    IntVector empty_iv;                        // samples
-    empty_iv.write(out, true);
-    SdVector empty_sd;                         // last
-    empty_sd.write(out);
-    empty_iv.write(out, true);                 // last_to_run
+    {
+        std::vector<uint64_t> sv(total_runs), l2r(total_runs);
+        SdVector last;
+        last.size = n_seq * max_length; // sd_vector_builder(n_seq * max_length, total_runs)
+        for (uint64_t i = 0; i < total_runs; i++) {
+            sv[i] = pack(heads[i].seq_id, heads[i].seq_offset);
+            last.ones.push_back(pack(tails[i].seq_id, tails[i].seq_offset));
+            l2r[i] = tails[i].run_id;
+        }
+        uint8_t w = bits_length(pack(n_seq - 1, max_length - 1));
+        IntVector::pack(sv, w ? w : 64).write(out, true);
+        last.write(out);
+        uint8_t w2 = bits_length(total_runs - 1);
+        IntVector::pack(l2r, w2 ? w2 : 64).write(out, true);
+    }
     {
         std::vector<uint64_t> sm(256);
         for (int c = 0; c < 256; c++) sm[c] = sym_map[c];
@@ -297,6 +394,58 @@ extern "C" pgx_status pgx_write_compact_tags(const char *out_path, const uint64_
     intervals.size = bwt_pos + 1;                                   // builder(cumulative_run_bwt_position + 1, runs), :635
     std::vector<uint8_t> out;
     IntVector::pack(items, (uint8_t)width).write(out, true);
+    starts.write(out);
+    intervals.write(out);
+    write_whole_file(out_path, out);
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+// ------------------------------------------------------------------------------------------
+// convert_tags equivalent: "algorithm format" (bare ByteCode stream of
+// offset:10 | rev:1 | len:9 | node<<20, written by build_tags, src/tag_arrays.cpp:28-36,104-127) ->
+//   compact = 0: ByteCode query format  = compressed_serialize (src/tag_arrays.cpp:656-734) +
+//                merge_compressed_files (:558-620); reproduces the reference's fixture
+//                bidirectional_test/xy_bidirectional_compressed.tags byte for byte
+//   compact = 1: sdsl-compact query format (what find_mems.cpp loads): as pgx_write_compact_tags.
+// (HEAD's convert_tags.cpp writes compact values into the ByteCode container, which no HEAD loader/query
+//  pair decodes consistently -- SURVEY section 5 format 4; that combination is deliberately not offered.)
+extern "C" pgx_status pgx_convert_tags(const char *in_path, const char *out_path, int compact) {
+    PGX_GUARD_BEGIN
+    if (!in_path || !out_path) throw Error(PGX_ERR_ARG, "pgx_convert_tags: null argument");
+    std::vector<uint8_t> in = read_whole_file(in_path);
+    std::vector<uint64_t> vals, lens;
+    uint64_t loc = 0;
+    while (loc < in.size()) {
+        const uint64_t d = bytecode_read(in.data(), in.size(), loc, "tag run");
+        vals.push_back(d);
+        lens.push_back((d >> 11) & 0x1FF); // decode_run, length_bits = 9
+    }
+    if (compact) {
+        std::vector<uint64_t> cv(vals.size());
+        for (size_t i = 0; i < vals.size(); i++) cv[i] = (vals[i] & 0x7FF) | ((vals[i] >> 20) << 11);
+        return pgx_write_compact_tags(out_path, cv.data(), lens.data(), vals.size());
+    }
+    std::vector<uint8_t> stream;
+    SdVector starts, intervals;
+    uint64_t bwt_pos = 0, nruns = 0, last_start = 0;
+    auto emit = [&](uint64_t v, uint64_t len) {
+        intervals.ones.push_back(bwt_pos);
+        bwt_pos += len;
+        if (nruns % 10 == 0) { last_start = stream.size(); starts.ones.push_back(last_start); }
+        bytecode_write(stream, (v & ~(0x1FFull << 11)) | (len << 11)); // encode_run_length with this chunk's length
+        nruns++;
+    };
+    for (size_t i = 0; i < vals.size(); i++) {
+        uint64_t len = lens[i];
+        while (len >= 512) { emit(vals[i], 511); len -= 511; }
+        if (len > 0) emit(vals[i], len);
+    }
+    starts.size = last_start + 1;  // sd_vector_builder(start_pos + 1, encoded_start_ones), :565
+    intervals.size = bwt_pos + 1;  // sd_vector_builder(cumulative_run_bwt_position + 1, runs), :590
+    std::vector<uint8_t> out;
+    put<uint64_t>(out, stream.size()); // size header patched in by merge_compressed_files (:613-617)
+    out.insert(out.end(), stream.begin(), stream.end());
     starts.write(out);
     intervals.write(out);
     write_whole_file(out_path, out);

@@ -191,9 +191,9 @@ void SdVector::write(std::vector<uint8_t> &out) const {
     put<uint64_t>(out, size);
     put<uint8_t>(out, wl);
     std::vector<uint64_t> lowv(m);
-    // vgteam/sdsl-lite sizes the high part as m + (n >> wl) + 1 bits (pinned by the fixtures:
-    // blocks_start_pos of xy.ri has 162 ones, n = 8022, wl = 5 -> 413 bits)
-    uint64_t high_bits = m + (size >> wl) + 1;
+    // vgteam/sdsl-lite sizes the high part as m + ceil(n / 2^wl) bits (pinned by the fixtures of xy.ri:
+    // blocks_start_pos: 162 ones, n = 8022, wl = 5 -> 413 bits; last: 1620 ones, n = 8024, wl = 2 -> 3626)
+    uint64_t high_bits = m + ((size + (1ULL << wl) - 1) >> wl);
     std::vector<uint64_t> high((high_bits + 63) / 64 + 1, 0);
     for (uint64_t i = 0; i < m; i++) {
         lowv[i] = ones[i];

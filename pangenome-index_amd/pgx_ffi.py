@@ -89,6 +89,7 @@ def lib():
     L.pgx_build_rindex.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     L.pgx_build_rlbwt.argtypes = [C.c_char_p, C.c_char_p]
     L.pgx_write_compact_tags.argtypes = [C.c_char_p, p, p, u64]
+    L.pgx_convert_tags.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     L.pgx_rank_batch.argtypes = [p, C.c_int, p, u64, C.c_int, p]
     L.pgx_extend_batch.argtypes = [p, C.c_int, p, p, p, u64, p]
     L.pgx_count_batch.argtypes = [p, C.c_int, p, p, u64, p]
@@ -137,6 +138,10 @@ def write_compact_tags(out_path, values, lengths):
     l = np.ascontiguousarray(lengths, dtype=np.uint64)
     assert len(v) == len(l)
     _check(lib().pgx_write_compact_tags(out_path.encode(), v.ctypes.data, l.ctypes.data, len(v)))
+
+
+def convert_tags(in_path, out_path, compact=False):
+    _check(lib().pgx_convert_tags(in_path.encode(), out_path.encode(), 1 if compact else 0))
 
 
 _VIEW_DTYPES = {0: np.uint8, 1: np.uint64, 2: np.uint64, 3: np.uint64, 4: np.uint64, 5: np.uint32, 6: np.uint8, 7: np.uint16}

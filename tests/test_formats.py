@@ -58,13 +58,15 @@ def _tail_from_sym_map(raw):
     ("bidirectional_test/contigs_xy.rl_bwt", "bidirectional_test/xy.ri"),
     ("two_contig_graph/contigs_XY.rl_bwt", "two_contig_graph/xy.ri"),
 ])
-def test_legacy_ri_writer_is_byte_exact_from_sym_map_on(workdir, rlbwt, fixture):
+def test_legacy_ri_writer_reproduces_reference_files_byte_for_byte(workdir, rlbwt, fixture):
+    """the WHOLE file: header (max_length), SA samples, last (sd_vector + both select supports),
+    last_to_run, sym_map, C, blocks_start_pos, sequence_size, every block"""
     out = os.path.join(workdir, "legacy.ri")
     P.build_rindex(os.path.join(G, rlbwt), out, False)
     mine, ref = open(out, "rb").read(), open(os.path.join(G, fixture), "rb").read()
     a, b = _tail_from_sym_map(mine), _tail_from_sym_map(ref)
     assert mine[a:] == ref[b:]
-    assert mine[:8] == ref[:8]  # tag + version
+    assert mine == ref
 
 
 def test_encoded_ri_layout_fields(workdir):
@@ -131,3 +133,23 @@ def test_synthetic_pangenome_small(workdir):
             assert cnt == int(m["size"])
             k += 1
     assert k > 0
+
+
+def test_convert_tags_reproduces_reference_fixture_byte_for_byte(workdir):
+    """build_tags' algorithm format (xy_bidirectional.tags) -> ByteCode query format ==
+    the reference's own xy_bidirectional_compressed.tags (ByteCode runs, both sd_vectors with their
+    select supports incl. a two-superblock one)"""
+    src = os.path.join(G, "bidirectional_test", "xy_bidirectional.tags")
+    out = os.path.join(workdir, "conv.tags")
+    P.convert_tags(src, out, compact=False)
+    assert open(out, "rb").read() == open(os.path.join(G, "bidirectional_test", "xy_bidirectional_compressed.tags"), "rb").read()
+    # and the sdsl-compact conversion answers every query identically
+    outc = os.path.join(workdir, "conv_compact.tags")
+    P.convert_tags(src, outc, compact=True)
+    a, b = O.Tags(out, O.TAGS_BYTECODE), O.Tags(outc, O.TAGS_COMPACT)
+    assert a.n_runs == b.n_runs == 6031
+    rng = np.random.default_rng(4)
+    for _ in range(300):
+        s = int(rng.integers(0, 8022))
+        e = int(min(8021, s + rng.integers(0, 100)))
+        assert a.query(s, e) == b.query(s, e)
