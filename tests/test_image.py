@@ -82,25 +82,31 @@ def test_image_reference_two_contig_fixture(built):
 
 def test_long_runs_split_and_merge(workdir):
     """runs longer than the 13-bit entry limit are split; adjacent equal symbols are merged"""
-    import struct
-
-    runs = [(ord("A"), 70000), (ord("C"), 1), (ord("C"), 9000), (10, 3), (ord("G"), 8191), (ord("G"), 8192), (ord("T"), 5),
-            (ord("N"), 40000), (ord("A"), 1)] * 3
-    path = os.path.join(workdir, "long.rl_bwt")
-    with open(path, "wb") as f:
-        f.write(struct.pack("<QQ", 1, 4))
-        for s, l in runs:
-            f.write(struct.pack("<BI", s, l))
+    text = os.path.join(workdir, "long.txt")
+    with open(text, "w") as f:
+        f.write("A" * 70000 + "C" * 9001 + "G" * 16383 + "T" * 5 + "N" * 40000 + "A\n")
+        f.write("T" * 30000 + "G" * 8192 + "ACGT" * 10 + "C" * 8191 + "\n")
+    rl = os.path.join(workdir, "long.rl_bwt")
+    P.build_rlbwt(text, rl)
+    _, lens = W.read_rlbwt_runs(rl)
+    assert int(lens.max()) > 60000
     ri_path = os.path.join(workdir, "long.ri")
-    P.build_rindex(path, ri_path, True)
+    P.build_rindex(rl, ri_path, True)
     idx, ri = P.Index(ri_path), O.RIndex(ri_path)
     assert ri.sigma == 6 and ri.has_N
     emu = ImageEmu(idx)
     n = ri.n
     rng = np.random.default_rng(9)
-    for pos in [0, 1, 69999, 70000, 70001, n - 1, n] + [int(v) for v in rng.integers(0, n, 400)]:
+    for pos in [0, 1, 2, 69999, 70000, 70001, n - 1, n] + [int(v) for v in rng.integers(0, n, 400)]:
         assert emu.rank6_true(pos) == ri.rank6_true(pos)
         assert emu.rank_cache(pos) == ri.rank_at_cached(pos)
+    raw = open(text).read()
+    for p in ["A" * 100, "N" * 39999, "GACGT", "CCCC", "TTTTTG"]:
+        exp = sum(1 for i in range(len(raw) - len(p) + 1) if raw.startswith(p, i)) if len(p) < 200 else None
+        tri = ri.bwd_pattern(p, O.MODE_STRICT)
+        if exp is not None:
+            assert tri[2] == exp, p
+        assert emu.count(p) == ri.count(p)
 
 
 def test_tag_image_both_formats(workdir):
