@@ -10,7 +10,9 @@
  *              (code order = nuc = \n A C G N T, include/pangenome_index/utils.hpp:11)
  *    dw 6      high 8 bits of c6[0..3]  (counts are 40-bit: n < 2^40)
  *    dw 7      bits 0..15 high 8 bits of c6[4..5]; bits 16..20 number of run entries used
- *    dw 8..15  16 run entries of 16 bits: code << 13 | length (1..8191); length 0 = unused
+ *    dw 8..15  16 run entries of 16 bits: (3 * code) << 12 | length (1..4095); length 0 = unused.  The
+ *              stored 4-bit field is the bit offset of the code's 3-bit weight in the per-extension
+ *              weight rows, so a decode step is two bit-field extracts and two multiply-adds per sum
  *    block_start = sum of the counts whose code is not in `excl_mask` (see PgxConsts)
  *  directory   u64 dir[i], one bucket of 2^dir_shift positions each, about one bucket per block:
  *                bits  0..31  lo  = number of blocks whose start is < (i << dir_shift)
@@ -34,8 +36,8 @@
 
 #define PGX_BLOCK_BYTES 64
 #define PGX_BLOCK_RUNS 16
-#define PGX_RUN_LEN_BITS 13
-#define PGX_RUN_LEN_MAX 8191u
+#define PGX_RUN_LEN_BITS 12
+#define PGX_RUN_LEN_MAX 4095u
 #define PGX_COUNT_BITS 40
 #define PGX_DIR_MAX_SHIFT 12
 

@@ -303,7 +303,7 @@ static void put_block(std::vector<uint8_t> &blocks, const uint64_t c6[6], const 
     for (int i = 0; i < 4; i++) dw[6] |= (uint32_t)((c6[i] >> 32) & 0xFF) << (8 * i);
     dw[7] = (uint32_t)((c6[4] >> 32) & 0xFF) | ((uint32_t)((c6[5] >> 32) & 0xFF) << 8) | ((uint32_t)ent.size() << 16);
     for (size_t e = 0; e < ent.size(); e++) {
-        uint32_t v = ((uint32_t)ent[e].first << PGX_RUN_LEN_BITS) | ent[e].second;
+        uint32_t v = ((3u * (uint32_t)ent[e].first) << PGX_RUN_LEN_BITS) | ent[e].second;
         dw[8 + e / 2] |= v << (16 * (e & 1));
     }
     const uint8_t *p = reinterpret_cast<const uint8_t *>(dw);

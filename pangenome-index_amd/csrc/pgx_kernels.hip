@@ -64,17 +64,19 @@ __device__ __forceinline__ void pgx_rank_ab(const PgxDevImage &img, const uint4 
         a = (cv == (uint32_t)i) ? c[i] : a;
         b += c[i] * (uint64_t)((mrow >> (3 * i)) & 7u);
     }
-    uint32_t rel = (uint32_t)(pos - start); // block extent <= 16 * 8191
+    uint32_t rel = (uint32_t)(pos - start); // block extent <= 16 * 4095
     uint32_t ia = 0, ib = 0;
+    const uint32_t arow = 1u << (3 * cv);   // one-hot weight row selecting code cv
     const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
     for (int e = 0; e < PGX_BLOCK_RUNS; e++) {
-        const uint32_t v = (rw[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
-        const uint32_t code = v >> PGX_RUN_LEN_BITS, len = v & PGX_RUN_LEN_MAX;
+        const uint32_t w = rw[e >> 1];
+        const uint32_t sh = (e & 1) ? (w >> 28) : __builtin_amdgcn_ubfe(w, 12, 4);          // 3 * code
+        const uint32_t len = (e & 1) ? __builtin_amdgcn_ubfe(w, 16, 12) : (w & PGX_RUN_LEN_MAX);
         const uint32_t take = min(len, rel);
         rel -= take;
-        ia += (code == cv) ? take : 0u;
-        ib += take * ((mrow >> (3 * code)) & 7u);
+        ia += take * __builtin_amdgcn_ubfe(arow, sh, 3);
+        ib += take * __builtin_amdgcn_ubfe(mrow, sh, 3);
     }
     A = a + ia;
     B = b + ib;
@@ -119,21 +121,23 @@ __device__ __forceinline__ void pgx_rank_pair(const PgxDevImage &img, const uint
             const uint64_t d1 = p1 - start;          // pos1 relative to this block; wraps when p1 < start
             uint32_t rels = it ? 0u : (d1 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d1);
             uint32_t iap = 0, ibp = 0, ias = 0, ibs = 0, total = 0;
+            const uint32_t arow = 1u << (3 * cv); // one-hot weight row selecting code cv
             const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
             for (int e = 0; e < PGX_BLOCK_RUNS; e++) {
-                const uint32_t v = (rw[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
-                const uint32_t code = v >> PGX_RUN_LEN_BITS, len = v & PGX_RUN_LEN_MAX;
+                // entry = (3 * code) << 12 | len: the stored shift indexes the 3-bit weight rows directly
+                const uint32_t w = rw[e >> 1];
+                const uint32_t sh = (e & 1) ? (w >> 28) : __builtin_amdgcn_ubfe(w, 12, 4);
+                const uint32_t len = (e & 1) ? __builtin_amdgcn_ubfe(w, 16, 12) : (w & PGX_RUN_LEN_MAX);
                 const uint32_t tp = min(len, relp), ts = min(len, rels);
-                const uint32_t m = (mrow >> (3 * code)) & 7u;
-                const bool hit = (code == cv);
+                const uint32_t wa = __builtin_amdgcn_ubfe(arow, sh, 3), wm = __builtin_amdgcn_ubfe(mrow, sh, 3);
                 total += len;
                 relp -= tp;
                 rels -= ts;
-                iap += hit ? tp : 0u;
-                ias += hit ? ts : 0u;
-                ibp += tp * m;
-                ibs += ts * m;
+                iap += tp * wa;
+                ias += ts * wa;
+                ibp += tp * wm;
+                ibs += ts * wm;
             }
             if (it == 0) {
                 A0 = a + iap;
@@ -225,7 +229,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     const int lane = threadIdx.x & 63;
     const uint64_t n = img.n;
     uint64_t rid = 0, base = 0, slot = 0;
-    int32_t len = 0, x = 0, j = 0, e = 0;
+    int32_t len = 0, x = 0, j = 0;
     uint64_t k = 0, kp = 0, s = 0, Jk = 0, Js = 0;
     uint32_t nm = 0, next = 0;
     int ph = 0;                      // 0 = idle (no read, or read finished)
@@ -246,10 +250,10 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     // emit the MEM [x, e) and set up step 3
     auto emit = [&]() {
         pgx_mem m;
-        m.start = (uint64_t)x; m.end = (uint64_t)e; m.bwt_start = Jk; m.size = (int64_t)Js;
+        m.start = (uint64_t)x; m.end = (uint64_t)j; m.bwt_start = Jk; m.size = (int64_t)Js; // e == j at every emit
         slots[slot + nm] = m;
         nm++;
-        k = 0; kp = 0; s = n; j = e;
+        k = 0; kp = 0; s = n;
         if (j > x) ph = 3;
         else { x = x + 1; begin(); } // loop of :722 runs zero times, returns j + 1
     };
@@ -262,7 +266,9 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                 if (exhausted) break;
                 unsigned long long got = 0;
                 if (lane == 0) got = atomicAdd(cursor, (unsigned long long)PGX_FM_BATCH);
-                got = __shfl(got, 0, 64);
+                // wave-uniform values are moved to scalar registers explicitly
+                got = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(got >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)got);
                 if (got >= n_reads) { exhausted = true; break; }
                 rnext = got;
                 rend = got + PGX_FM_BATCH < n_reads ? got + PGX_FM_BATCH : n_reads;
@@ -306,13 +312,13 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                 if (small) { x = j + 1; begin(); }
                 else if (j == x) {
                     Jk = k; Js = s; j = x + (int32_t)min_len;
-                    if (j >= len) { e = j; emit(); } else ph = 2;
+                    if (j >= len) emit(); else ph = 2;
                 } else j--;
             } else if (ph == 2) {
-                if (small) { e = j; emit(); }
+                if (small) emit();
                 else {
                     Jk = k; Js = s; j++;
-                    if (j >= len) { e = j; emit(); }
+                    if (j >= len) emit();
                 }
             } else { // ph == 3
                 if (small) { x = j + 1; begin(); }

@@ -8,7 +8,7 @@ import struct
 
 import numpy as np
 
-RUN_LEN_BITS, RUN_LEN_MAX, BLOCK_RUNS = 13, 8191, 16
+RUN_LEN_BITS, RUN_LEN_MAX, BLOCK_RUNS = 12, 4095, 16
 M64 = (1 << 64) - 1
 
 
@@ -51,7 +51,8 @@ class ImageEmu:
         ents = []
         for e in range(BLOCK_RUNS):
             v = (dw[8 + e // 2] >> (16 * (e & 1))) & 0xFFFF
-            ents.append((v >> RUN_LEN_BITS, v & RUN_LEN_MAX))
+            assert (v >> RUN_LEN_BITS) % 3 == 0 and (v >> RUN_LEN_BITS) <= 15
+            ents.append(((v >> RUN_LEN_BITS) // 3, v & RUN_LEN_MAX))
         return c, ents, (dw[7] >> 16) & 0x1F
 
     def find_block(self, pos):
