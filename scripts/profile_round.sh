@@ -22,10 +22,12 @@ for wl in ("x", "synth"):
                 agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
         out[C] = {k: sum(v) / len(v) for k, v in agg.items() if k.startswith("pgx_")}
     fm = [k for k in out["FETCH_SIZE"] if "find_mems" in k][0]
-    # FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1024 B (rocprofv3); FETCH_SIZE = TCC_EA0_RDREQ x 64 B, which is
-    # exact for this kernel's 64-byte random block reads (no 128-byte streaming requests to under-count; TCC_EA0_RDREQ_32B = 0)
+    # FETCH_SIZE / WRITE_SIZE are in units of 1024 B (rocprofv3).  FETCH_SIZE = TCC_EA0_RDREQ x 64 B, but every read
+    # request of this kernel moves a whole 128-byte line (MI355X_MICROARCH.md "HBM": FETCH_SIZE tallies 128-B requests
+    # at 64 B; confirmed for THIS access pattern by profiles/r01_ubench_random_gather.txt: random 64-B and 128-B
+    # records are served at the same record rate), so the read side is doubled.  WRITE_SIZE is exact.
     rec = {"workload": wl, "kernel": fm, "FETCH_SIZE_KB_per_launch": out["FETCH_SIZE"][fm], "WRITE_SIZE_KB_per_launch": out["WRITE_SIZE"].get(fm, 0.0),
-           "find_mems_hbm_bytes_per_launch": (out["FETCH_SIZE"][fm] + out["WRITE_SIZE"].get(fm, 0.0)) * 1024.0,
+           "find_mems_hbm_bytes_per_launch": (2.0 * out["FETCH_SIZE"][fm] + out["WRITE_SIZE"].get(fm, 0.0)) * 1024.0,
            "all_kernels_FETCH_KB": out["FETCH_SIZE"], "all_kernels_WRITE_KB": out["WRITE_SIZE"],
            "note": "memory-side (fabric) bytes: Infinity-Cache hits are included, so this is an upper bound on HBM bytes"}
     json.dump(rec, open("%s/traffic_%s.json" % (R, wl), "w"), indent=1)
