@@ -1,0 +1,102 @@
+"""Chromosome-sharded mode (SURVEY 8e row 2 / BASELINE configs[4]): per-read concatenation, in shard order,
+of per-shard MEM lists, exchanged with all_gather.  CPU tier: gloo world-size 2 with the oracle as the
+per-shard engine; GPU tier: the HIP path as the engine (single process, no collective)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import pgx_shard as S
+import pgx_workload as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = O.GOLDEN
+CHROMS = [("bidirectional_test/contigs_xy.rl_bwt", "bidirectional_test/contigs_xy"), ("x.rl_bwt", "x.newline_separated"),
+          ("two_contig_graph/contigs_XY.rl_bwt", "two_contig_graph/contigs_XY.txt")]
+
+
+def _expected(indexes, cat, offs, min_len, min_occ):
+    """definition of the mode: for every read, shard 0's MEMs, then shard 1's, ..."""
+    parts = [O.find_mems_batch(ri, None, cat, offs, min_len, min_occ) for ri in indexes]
+    mems, mo, shard = [], [0], []
+    for i in range(len(offs) - 1):
+        for c, p in enumerate(parts):
+            seg = p["mems"][p["mem_offsets"][i]:p["mem_offsets"][i + 1]]
+            mems.append(seg)
+            shard += [c] * len(seg)
+        mo.append(len(shard))
+    return np.array(mo, dtype=np.uint64), np.concatenate(mems), np.array(shard), parts
+
+
+def _setup(workdir):
+    idx = []
+    for k, (rl, _) in enumerate(CHROMS):
+        ri, _t = W.build_index_from_rlbwt(os.path.join(G, rl), workdir, "chrom%d" % k, with_tags=False)
+        idx.append(ri)
+    seqs = []
+    for _, t in CHROMS:
+        seqs += W.load_sequences(os.path.join(G, t))
+    cat, offs = W.sample_reads(seqs, 1500, 100, seed=8)
+    return idx, cat, offs
+
+
+def test_lpt_assign():
+    a = S.lpt_assign([10, 9, 8, 7, 6, 5, 4, 3], 3)
+    assert sorted(c for b in a for c in b) == list(range(8))
+    loads = [sum([10, 9, 8, 7, 6, 5, 4, 3][c] for c in b) for b in a]
+    assert max(loads) <= (4 * sum(loads)) // (3 * 3) + 1  # LPT bound: 4/3 of the ideal load
+    assert S.lpt_assign([5, 5], 4) == [[0], [1], [], []]
+
+
+def test_exchange_single_process(workdir):
+    paths, cat, offs = _setup(workdir)
+    indexes = [O.RIndex(p) for p in paths]
+    mo, mems, shard, parts = _expected(indexes, cat, offs, 5, 1)
+    got = S.exchange_mems({c: parts[c] for c in range(3)}, len(offs) - 1, 3)
+    assert np.array_equal(got[0], mo) and got[1].tobytes() == mems.tobytes() and np.array_equal(got[2], shard)
+    assert len(mems) > 1000 and len(set(shard)) == 3
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, os.path.join(%(root)r, "pangenome-index_amd"))
+import numpy as np, torch, torch.distributed as dist
+import oracle_ffi as O, pgx_shard as S
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from test_chrom_shard import _setup, _expected
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+paths, cat, offs = _setup(%(wd)r + "/r%%d" %% rank)
+indexes = [O.RIndex(p) for p in paths]
+mine = S.lpt_assign([8022, 3012, 4011], world)[rank]           # chromosome lengths -> ranks
+local = {c: O.find_mems_batch(indexes[c], None, cat, offs, 5, 1) for c in mine}
+got = S.exchange_mems(local, len(offs) - 1, 3, dist=dist, device="cpu")
+mo, mems, shard, _ = _expected(indexes, cat, offs, 5, 1)
+ok = np.array_equal(got[0], mo) and got[1].tobytes() == mems.tobytes() and np.array_equal(got[2], shard)
+print("RANK%%d %%s %%d" %% (rank, "CHROM_OK" if ok else "CHROM_MISMATCH", len(mems)), flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_exchange_world_size_2_gloo(built, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "wd": str(tmp_path)})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29519", str(script)], capture_output=True, text=True, env=env, timeout=900)
+    assert out.stdout.count("CHROM_OK") == 2, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_exchange_with_hip_engine(workdir):
+    import pgx_ffi as P
+
+    paths, cat, offs = _setup(workdir)
+    indexes = [O.RIndex(p) for p in paths]
+    mo, mems, shard, _ = _expected(indexes, cat, offs, 5, 1)
+    local = {c: P.Index(paths[c]).find_mems(cat, offs, 5, 1) for c in range(3)}
+    got = S.exchange_mems(local, len(offs) - 1, 3)
+    assert np.array_equal(got[0], mo) and got[1].tobytes() == mems.tobytes() and np.array_equal(got[2], shard)
