@@ -61,6 +61,11 @@ __global__ void pgx_tag_sort_unique_kernel(const uint64_t *list, uint64_t n_list
                                            uint64_t *buf, uint64_t *ucount);
 __global__ void pgx_tag_sort_large_kernel(const uint64_t *list, uint64_t n_list, const uint64_t *run_nums, const uint64_t *seg_off,
                                           uint64_t *buf, uint64_t *scratch, const uint64_t *scratch_off, uint64_t *ucount);
+__global__ void pgx_tag_list_fetch_kernel(const uint64_t *list, uint64_t n_list, const uint64_t *first_item, const uint64_t *run_nums,
+                                          uint64_t *out);
+__global__ void pgx_tag_copy_dups_kernel(const uint64_t *pairs, uint64_t n_pairs, uint64_t n_tag_items, const uint64_t *first_item,
+                                         const uint64_t *run_nums, const uint64_t *seg_off, uint64_t *buf, uint64_t *ucount,
+                                         unsigned long long *n_overflow);
 __global__ void pgx_tag_compact_kernel(uint64_t n, const uint64_t *ucount, const uint64_t *seg_off, const uint64_t *buf,
                                        const uint64_t *pos_off, uint64_t *positions);
 

@@ -260,3 +260,32 @@ pgx_tag_compact_kernel(uint64_t n, const uint64_t *__restrict__ ucount, const ui
     const uint64_t c = ucount[q], src = seg_off[q], dst = pos_off[q];
     for (uint64_t t = l16; t < c; t += 16) positions[dst + t] = buf[src + t];
 }
+
+// (query id, first item, run count) of every listed query -> host, which groups identical queries
+__global__ void __launch_bounds__(256)
+pgx_tag_list_fetch_kernel(const uint64_t *__restrict__ list, uint64_t n_list, const uint64_t *__restrict__ first_item,
+                          const uint64_t *__restrict__ run_nums, uint64_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_list) return;
+    const uint64_t q = list[i];
+    out[3 * i] = q;
+    out[3 * i + 1] = first_item[q];
+    out[3 * i + 2] = run_nums[q];
+}
+
+// one workgroup per (duplicate, representative) pair: the duplicate query reads exactly the same items, so
+// its sorted unique result is the representative's (and it overflows iff the representative does)
+__global__ void __launch_bounds__(256)
+pgx_tag_copy_dups_kernel(const uint64_t *__restrict__ pairs, uint64_t n_pairs, uint64_t n_tag_items,
+                         const uint64_t *__restrict__ first_item, const uint64_t *__restrict__ run_nums,
+                         const uint64_t *__restrict__ seg_off, uint64_t *__restrict__ buf, uint64_t *__restrict__ ucount,
+                         unsigned long long *__restrict__ n_overflow) {
+    if (blockIdx.x >= n_pairs) return;
+    const uint64_t dup = pairs[2 * blockIdx.x], rep = pairs[2 * blockIdx.x + 1];
+    const uint64_t c = ucount[rep], src = seg_off[rep], dst = seg_off[dup];
+    for (uint64_t t = threadIdx.x; t < c; t += blockDim.x) buf[dst + t] = buf[src + t];
+    if (threadIdx.x == 0) {
+        ucount[dup] = c;
+        if (first_item[dup] + run_nums[dup] > n_tag_items) atomicAdd(n_overflow, 1ull);
+    }
+}

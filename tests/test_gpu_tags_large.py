@@ -26,6 +26,9 @@ def test_tag_query_all_size_classes(workdir, x_index):
     extra_l = np.concatenate([rng.integers(0, 40, 100), rng.integers(40, 5000, 60), rng.integers(5000, total, 40)]).astype(np.uint64)
     st = np.concatenate([st, extra_s])
     en = np.concatenate([en, np.minimum(extra_s + extra_l, np.uint64(total - 1))])
+    # identical large queries are answered once and copied (dedup path): repeat some of them
+    st = np.concatenate([st, st[:2], st[:2], st[-40:], st[-40:]])
+    en = np.concatenate([en, en[:2], en[:2], en[-40:], en[-40:]])
     rn, po, pos, nover = idx.tag_query_batch(st, en)
     classes = set()
     for i in range(len(st)):
