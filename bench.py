@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target core-seconds of the CPU sample")
     ap.add_argument("--workdir", default=None)
+    ap.add_argument("--pcie", action="store_true",
+                    help="also time the host-buffer API (upload + run + download per call); reported separately, never as value")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --one-device rehearses the N>1 path on a single-GPU box")
     ap.add_argument("--one-device", action="store_true", help="every rank uses device 0 (rehearsal only)")
@@ -204,6 +206,13 @@ def main():
                 "kernel_ms": fm_ms, "bytes_per_extension": 2.0 * (b_blk + 16.0),
             },
         }
+        if args.pcie:
+            t1 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                res = idx.find_mems(cat, offs, args.min_len, args.min_occ, tags=not args.no_tags, device=local)
+            line["pcie_inclusive_reads_per_s"] = n * reps / (time.perf_counter() - t1)
+            line["pcie_inclusive_note"] = "pgx_find_mems_batch: H2D of reads+offsets, all kernels, D2H of MEMs/positions, host CSR copies"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, ri, tags, cat, offs)
         print(json.dumps(line), flush=True)

@@ -182,6 +182,9 @@ typedef struct {
  * find_mems.cpp:96-98, empty lines already skipped by the caller) to `device`. */
 pgx_status pgx_batch_create(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets,
                             uint64_t n_reads, pgx_batch **out);
+/* Replace the reads of an existing batch (its device and pinned host buffers only ever grow: a long-lived
+ * batch costs no allocation per call).  Invalidates the results of the previous run. */
+pgx_status pgx_batch_upload(pgx_batch *b, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads);
 /* Run find_all_mems (+ tag queries) for every read of the batch; results stay on the device.
  * `stream` is a hipStream_t (NULL = default stream).  Asynchronous except for the few scalar
  * read-backs that size intermediate buffers. */

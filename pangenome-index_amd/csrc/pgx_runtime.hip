@@ -93,6 +93,28 @@ struct DevBuf { // grow-only device buffer
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+struct HostBuf { // grow-only pinned host buffer (fast D2H; returned to the caller as result arrays)
+    void *p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            (void)hipGetLastError();
+            throw Error(PGX_ERR_NOMEM, "hipHostMalloc of " + std::to_string(want) + " bytes failed: " + hipGetErrorString(e));
+        }
+        cap = want;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 struct pgx_device_image {
     int device = -1;
     PgxDevImage img{};
@@ -353,8 +375,7 @@ struct pgx_batch {
     uint64_t n_mems = 0, n_positions = 0, n_ext = 0, n_tag_overflow = 0;
     bool ran = false, ran_tags = false;
     // host copies
-    std::vector<uint64_t> h_mem_off, h_run_nums, h_pos_off, h_positions;
-    std::vector<pgx_mem> h_mems;
+    HostBuf h_mem_off, h_mems, h_run_nums, h_pos_off, h_positions;
     // timing
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
@@ -368,6 +389,8 @@ static void batch_release(pgx_batch *b) {
                          &b->counters};
         for (DevBuf *d : all) d->release();
         b->tw.release();
+        HostBuf *hb[] = {&b->h_mem_off, &b->h_mems, &b->h_run_nums, &b->h_pos_off, &b->h_positions};
+        for (HostBuf *x : hb) x->release();
         for (auto &e : b->ev)
             if (e) { (void)hipEventDestroy(e); e = nullptr; }
     }
@@ -375,6 +398,23 @@ static void batch_release(pgx_batch *b) {
 }
 
 extern "C" void pgx_batch_free(pgx_batch *b) { batch_release(b); }
+
+// (re)fill a batch: device buffers only ever grow, so a long-lived batch costs no allocation per call
+static void batch_upload(pgx_batch *b, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads) {
+    b->n_reads = n_reads;
+    b->ran = b->ran_tags = false;
+    b->plan_valid = false;
+    const uint64_t lo = offsets[0], hi = offsets[n_reads];
+    b->read_bytes = hi - lo;
+    // device offsets are rebased to 0; 16 bytes of zero padding after the last read
+    b->reads.ensure(b->read_bytes + 16);
+    HIPCHECK(hipMemset((uint8_t *)b->reads.p + b->read_bytes, 0, 16));
+    if (b->read_bytes) HIPCHECK(hipMemcpy(b->reads.p, reads + lo, b->read_bytes, hipMemcpyHostToDevice));
+    b->h_offsets.resize(n_reads + 1);
+    for (uint64_t i = 0; i <= n_reads; i++) b->h_offsets[i] = offsets[i] - lo;
+    b->offsets.ensure((n_reads + 1) * 8);
+    HIPCHECK(hipMemcpy(b->offsets.p, b->h_offsets.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice));
+}
 
 extern "C" pgx_status pgx_batch_create(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets,
                                        uint64_t n_reads, pgx_batch **out) {
@@ -392,19 +432,21 @@ extern "C" pgx_status pgx_batch_create(pgx_index *h, int device, const uint8_t *
     b->h = h;
     b->dimg = dimg;
     b->device = device;
-    b->n_reads = n_reads;
-    const uint64_t lo = offsets[0], hi = offsets[n_reads];
-    b->read_bytes = hi - lo;
-    // device offsets are rebased to 0; 16 bytes of zero padding after the last read
-    b->reads.ensure(b->read_bytes + 16);
-    HIPCHECK(hipMemset(b->reads.p, 0, b->read_bytes + 16));
-    if (b->read_bytes) HIPCHECK(hipMemcpy(b->reads.p, reads + lo, b->read_bytes, hipMemcpyHostToDevice));
-    std::vector<uint64_t> reb(n_reads + 1);
-    for (uint64_t i = 0; i <= n_reads; i++) reb[i] = offsets[i] - lo;
-    b->offsets.ensure((n_reads + 1) * 8);
-    HIPCHECK(hipMemcpy(b->offsets.p, reb.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice));
-    b->h_offsets = std::move(reb);
+    batch_upload(b.get(), reads, offsets, n_reads);
     *out = b.release();
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_batch_upload(pgx_batch *b, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads) {
+    PGX_GUARD_BEGIN
+    if (!b || !offsets || (!reads && n_reads && offsets[n_reads] != offsets[0])) throw Error(PGX_ERR_ARG, "pgx_batch_upload: null argument");
+    for (uint64_t i = 0; i < n_reads; i++) {
+        if (offsets[i + 1] < offsets[i]) throw Error(PGX_ERR_ARG, "pgx_batch_upload: offsets must be non-decreasing");
+        if (offsets[i + 1] - offsets[i] >= (1ull << 31)) throw Error(PGX_ERR_UNSUPPORTED, "read longer than 2^31 bytes");
+    }
+    use_device(b->device);
+    batch_upload(b, reads, offsets, n_reads);
     return PGX_OK;
     PGX_GUARD_END
 }
@@ -573,26 +615,26 @@ extern "C" pgx_status pgx_batch_result(pgx_batch *b, pgx_result *out) {
     if (!b || !out || !b->ran) throw Error(PGX_ERR_ARG, "pgx_batch_result: batch has not been run");
     use_device(b->device);
     const uint64_t n = b->n_reads, m = b->n_mems;
-    b->h_mem_off.assign(n + 1, 0);
-    HIPCHECK(hipMemcpy(b->h_mem_off.data(), b->mem_off.p, (n + 1) * 8, hipMemcpyDeviceToHost));
-    b->h_mems.resize(m);
-    if (m) HIPCHECK(hipMemcpy(b->h_mems.data(), b->mems.p, m * sizeof(pgx_mem), hipMemcpyDeviceToHost));
+    b->h_mem_off.ensure((n + 1) * 8);
+    HIPCHECK(hipMemcpy(b->h_mem_off.p, b->mem_off.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+    b->h_mems.ensure((m ? m : 1) * sizeof(pgx_mem));
+    if (m) HIPCHECK(hipMemcpy(b->h_mems.p, b->mems.p, m * sizeof(pgx_mem), hipMemcpyDeviceToHost));
     std::memset(out, 0, sizeof *out);
     out->n_reads = n;
     out->n_mems = m;
-    out->mem_offsets = b->h_mem_off.data();
-    out->mems = b->h_mems.data();
+    out->mem_offsets = b->h_mem_off.as<uint64_t>();
+    out->mems = b->h_mems.as<pgx_mem>();
     out->n_extensions = b->n_ext;
     if (b->ran_tags) {
-        b->h_run_nums.resize(m);
-        b->h_pos_off.assign(m + 1, 0);
-        b->h_positions.resize(b->n_positions);
-        if (m) HIPCHECK(hipMemcpy(b->h_run_nums.data(), b->tw.run_nums.p, m * 8, hipMemcpyDeviceToHost));
-        HIPCHECK(hipMemcpy(b->h_pos_off.data(), b->tw.pos_off.p, (m + 1) * 8, hipMemcpyDeviceToHost));
-        if (b->n_positions) HIPCHECK(hipMemcpy(b->h_positions.data(), b->tw.positions.p, b->n_positions * 8, hipMemcpyDeviceToHost));
-        out->tag_run_counts = b->h_run_nums.data();
-        out->pos_offsets = b->h_pos_off.data();
-        out->positions = b->h_positions.data();
+        b->h_run_nums.ensure((m ? m : 1) * 8);
+        b->h_pos_off.ensure((m + 1) * 8);
+        b->h_positions.ensure((b->n_positions ? b->n_positions : 1) * 8);
+        if (m) HIPCHECK(hipMemcpy(b->h_run_nums.p, b->tw.run_nums.p, m * 8, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(b->h_pos_off.p, b->tw.pos_off.p, (m + 1) * 8, hipMemcpyDeviceToHost));
+        if (b->n_positions) HIPCHECK(hipMemcpy(b->h_positions.p, b->tw.positions.p, b->n_positions * 8, hipMemcpyDeviceToHost));
+        out->tag_run_counts = b->h_run_nums.as<uint64_t>();
+        out->pos_offsets = b->h_pos_off.as<uint64_t>();
+        out->positions = b->h_positions.as<uint64_t>();
         out->n_positions = b->n_positions;
         out->n_tag_overflow = b->n_tag_overflow;
     }

@@ -95,6 +95,7 @@ def lib():
     L.pgx_count_batch.argtypes = [p, C.c_int, p, p, u64, p]
     L.pgx_tag_query_batch.argtypes = [p, C.c_int, p, p, u64, p, p, p, u64, C.POINTER(u64)]
     L.pgx_batch_create.argtypes = [p, C.c_int, p, p, u64, C.POINTER(p)]
+    L.pgx_batch_upload.argtypes = [p, p, p, u64]
     L.pgx_batch_run.argtypes = [p, u64, u64, u32, p]
     L.pgx_batch_result.argtypes = [p, C.POINTER(Result)]
     L.pgx_batch_counts.argtypes = [p, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
@@ -242,6 +243,12 @@ class Batch:
         self.b = p()
         _check(self.L.pgx_batch_create(index.h, device, reads_cat.ctypes.data if len(reads_cat) else None,
                                        offsets.ctypes.data, self.n, C.byref(self.b)))
+
+    def upload(self, reads_cat, offsets):
+        reads_cat = np.ascontiguousarray(reads_cat, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.n = len(offsets) - 1
+        _check(self.L.pgx_batch_upload(self.b, reads_cat.ctypes.data if len(reads_cat) else None, offsets.ctypes.data, self.n))
 
     def run(self, min_len, min_occ, flags=0, stream=None):
         _check(self.L.pgx_batch_run(self.b, min_len, min_occ, flags, stream))

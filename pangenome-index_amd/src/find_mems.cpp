@@ -71,6 +71,7 @@ int main(int argc, char **argv) {
     std::ifstream reads(reads_file);
     if (!reads) { std::cerr << "Cannot open reads file: " << reads_file << std::endl; std::exit(EXIT_FAILURE); } // :91
 
+    pgx_batch *b = nullptr;
     std::string cat, line, out;
     std::vector<uint64_t> offs;
     size_t seq_no = 0;
@@ -86,10 +87,13 @@ int main(int argc, char **argv) {
         }
         const size_t n = offs.size() - 1;
         if (n == 0) break;
-        pgx_batch *b = nullptr;
+        // one long-lived batch: its device and pinned host buffers are reused by every chunk of reads
         pgx_result r;
-        if (pgx_find_mems_batch(h, device, reinterpret_cast<const uint8_t *>(cat.data()), offs.data(), n, mem_length, min_occ,
-                                PGX_RUN_TAGS | PGX_RUN_TIMING, &b, &r) != PGX_OK) {
+        const uint8_t *rp = reinterpret_cast<const uint8_t *>(cat.data());
+        pgx_status st = b ? pgx_batch_upload(b, rp, offs.data(), n) : pgx_batch_create(h, device, rp, offs.data(), n, &b);
+        if (st == PGX_OK) st = pgx_batch_run(b, mem_length, min_occ, PGX_RUN_TAGS | PGX_RUN_TIMING, nullptr);
+        if (st == PGX_OK) st = pgx_batch_result(b, &r);
+        if (st != PGX_OK) {
             std::cerr << pgx_last_error() << std::endl;
             return EXIT_FAILURE;
         }
@@ -117,8 +121,8 @@ int main(int argc, char **argv) {
         }
         std::cout << out;
         std::cerr << err;
-        pgx_batch_free(b);
     }
+    pgx_batch_free(b);
     std::cout << "\nTotal time for finding all MEMs: " << total_mem_time << " seconds" << std::endl; // :144
     std::cout << "Total time for all tag queries: " << total_tag_time << " seconds" << std::endl;   // :145
     pgx_index_close(h);
