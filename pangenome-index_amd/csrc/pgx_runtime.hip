@@ -1,11 +1,14 @@
 // pgx_runtime.hip -- device memory, launches and the batch pipeline behind the C ABI.
 //
 // Pipeline of pgx_batch_run (one HIP stream, results stay on the device):
-//   scan(cap)      -> slot offsets (worst-case MEMs per read: len - min_len + 1)
-//   find_mems      -> MEM slots + per-read counts                      [dominant kernel]
+//   scan(cap)      -> slot offsets (worst-case MEMs per read: min(len, len - min_len + 1)); the slot buffer
+//                     is bounded, larger batches run in chunks of consecutive reads
+//   find_mems      -> MEM slots + per-read counts                      [dominant kernel, persistent grid]
 //   scan(count)    -> CSR offsets ; compact slots -> dense MEM array in read order
-//   tag_locate     -> per MEM run_nums + first item ; scan -> segment offsets
-//   tag_gather     -> values ; tag_sort_unique -> unique counts ; scan ; tag_compact -> positions
+//   tag_locate     -> per MEM run_nums + first item + size-class lists ; scans -> segment offsets
+//   tag_small      -> <= 16 runs: gather + sort + unique in registers
+//   tag_gather / tag_sort_unique / tag_sort_large -> listed bigger queries (identical large ones once)
+//   scan ; tag_compact -> positions CSR
 // The only host synchronisations are the scalar read-backs that size the next buffer.
 #include <hip/hip_runtime.h>
 
@@ -291,15 +294,12 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
     }
     if (nlarge) {
         const uint64_t *large = w.big_list.as<uint64_t>() + (m - nlarge); // the back of the shared list array
-        static bool lds_opt_in = false;
         uint64_t p2max = 64;
         while (p2max < hv[4] && p2max < PGX_SORT_WG_LDS_CAP) p2max <<= 1;
         const size_t lds = (size_t)p2max * 8; // smaller segments -> more workgroups per CU
-        if (!lds_opt_in) {
-            HIPCHECK(hipFuncSetAttribute((const void *)pgx_tag_sort_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)(PGX_SORT_WG_LDS_CAP * 8)));
-            lds_opt_in = true;
-        }
+        // opt in to > 64 KiB of dynamic LDS (per device; cheap enough to repeat)
+        HIPCHECK(hipFuncSetAttribute((const void *)pgx_tag_sort_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(PGX_SORT_WG_LDS_CAP * 8)));
         // Identical large queries are common (every read from the same repeat / N run yields the same SA interval):
         // sort one representative per distinct (first item, run count) and copy its result to the duplicates.
         std::vector<uint64_t> keys(3 * nlarge); // (query id, first item, run count) of every listed query
