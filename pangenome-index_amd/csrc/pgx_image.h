@@ -14,7 +14,7 @@
  *              stored 4-bit field is the bit offset of the code's 3-bit weight in the per-extension
  *              weight rows, so a decode step is two bit-field extracts and two multiply-adds per sum
  *    block_start = sum of the counts whose code is not in `excl_mask` (see PgxConsts)
- *  directory   u64 dir[i], one bucket of 2^dir_shift positions each, about one bucket per block:
+ *  directory   u64 dir[i], one bucket of 2^dir_shift positions each, about one bucket per two blocks:
  *                bits  0..31  lo  = number of blocks whose start is < (i << dir_shift)
  *                bits 32..39  cnt = blocks starting inside bucket i (saturates at 255)
  *                bits 40..51  low part of the 1st, bits 52..63 of the 2nd block start in the bucket

@@ -82,11 +82,68 @@ __device__ __forceinline__ void pgx_rank_ab(const PgxDevImage &img, const uint4 
     B = b + ib;
 }
 
-// The two rank probes of one extension, rank(pos0) and rank(pos1) with pos1 = pos0 + s.  Once the
-// interval is narrow (s ~ number of haplotypes) both positions fall into the same 64-byte block,
-// so the block of pos0 is decoded once for both; only when pos1 lies beyond it (or the interval
-// wrapped) is a second block decoded.  The decode exists once in the instruction stream (a rolled
-// two-trip loop) to keep code size and live registers down.  Outputs A0, A1 and B1 - B0.
+// One block decode ("trip") of the rank machinery: decodes the block holding p and returns
+//   Ap, Bp  rank sums at p (primary position; p <= n)
+//   As, Bs  rank sums at the secondary position p1 when `with_secondary` and this block also serves p1
+//           (`covered`): once an interval is narrow (s ~ number of haplotypes) both probes of an extension
+//           fall into the same 64-byte block and one decode answers both.
+// A = count of code cv, B = sum over codes of mult[code] * count(code), both modulo 2^64.
+template <bool LDS_IMAGE>
+__device__ __forceinline__ void pgx_probe(const PgxDevImage &img, const uint4 *__restrict__ lds_blocks,
+                                          const uint64_t *__restrict__ lds_dir, const uint16_t *__restrict__ lds_blow,
+                                          uint64_t p, uint64_t p1, bool with_secondary, uint32_t cv, uint32_t mrow,
+                                          uint64_t &Ap, uint64_t &Bp, uint64_t &As, uint64_t &Bs, bool &covered) {
+    const uint32_t lo = pgx_find_block<LDS_IMAGE>(img, lds_dir, lds_blow, p);
+    const uint4 *bp = (LDS_IMAGE ? lds_blocks : img.blocks) + (size_t)lo * 4;
+    const uint4 h0 = bp[0], h1 = bp[1], r0 = bp[2], r1 = bp[3];
+    uint64_t c[6];
+    c[0] = (uint64_t)h0.x | ((uint64_t)(h1.z & 0xFFu) << 32);
+    c[1] = (uint64_t)h0.y | ((uint64_t)((h1.z >> 8) & 0xFFu) << 32);
+    c[2] = (uint64_t)h0.z | ((uint64_t)((h1.z >> 16) & 0xFFu) << 32);
+    c[3] = (uint64_t)h0.w | ((uint64_t)(h1.z >> 24) << 32);
+    c[4] = (uint64_t)h1.x | ((uint64_t)(h1.w & 0xFFu) << 32);
+    c[5] = (uint64_t)h1.y | ((uint64_t)((h1.w >> 8) & 0xFFu) << 32);
+    uint64_t start = 0, a = 0, b = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        start += ((img.excl_mask >> i) & 1u) ? 0ull : c[i];
+        a = (cv == (uint32_t)i) ? c[i] : a;
+        b += c[i] * (uint64_t)((mrow >> (3 * i)) & 7u);
+    }
+    uint32_t relp = (uint32_t)(p - start);   // primary position (inside the block)
+    const uint64_t d1 = p1 - start;          // p1 relative to this block; wraps when p1 < start
+    uint32_t rels = with_secondary ? (d1 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d1) : 0u;
+    uint32_t iap = 0, ibp = 0, ias = 0, ibs = 0, total = 0;
+    const uint32_t arow = 1u << (3 * cv); // one-hot weight row selecting code cv
+    const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+    for (int e = 0; e < PGX_BLOCK_RUNS; e++) {
+        // entry = (3 * code) << 12 | len: the stored shift indexes the 3-bit weight rows directly
+        const uint32_t w = rw[e >> 1];
+        const uint32_t sh = (e & 1) ? (w >> 28) : __builtin_amdgcn_ubfe(w, 12, 4);
+        const uint32_t len = (e & 1) ? __builtin_amdgcn_ubfe(w, 16, 12) : (w & PGX_RUN_LEN_MAX);
+        const uint32_t tp = min(len, relp), ts = min(len, rels);
+        const uint32_t wa = __builtin_amdgcn_ubfe(arow, sh, 3), wm = __builtin_amdgcn_ubfe(mrow, sh, 3);
+        total += len;
+        relp -= tp;
+        rels -= ts;
+        iap += tp * wa;
+        ias += ts * wa;
+        ibp += tp * wm;
+        ibs += ts * wm;
+    }
+    Ap = a + iap;
+    Bp = b + ibp;
+    As = a + ias;
+    Bs = b + ibs;
+    // p1 is served by this block when it lies strictly inside it (a probe AT the block end belongs to the
+    // next block, whose header may carry a different quirk value), or at the end of the BWT
+    covered = with_secondary && (d1 < (uint64_t)total || (rels == 0 && lo + 1 == img.n_blocks));
+}
+
+// The two rank probes of one extension, rank(pos0) and rank(pos1) with pos1 = pos0 + s, as at most two
+// trips of pgx_probe in a rolled loop (the decode exists once in the instruction stream).
+// Outputs A0, A1 and B1 - B0.  (Used by the primitives; the find_mems kernel schedules trips itself.)
 template <bool LDS_IMAGE>
 __device__ __forceinline__ void pgx_rank_pair(const PgxDevImage &img, const uint4 *__restrict__ lds_blocks,
                                               const uint64_t *__restrict__ lds_dir, const uint16_t *__restrict__ lds_blow,
@@ -99,60 +156,14 @@ __device__ __forceinline__ void pgx_rank_pair(const PgxDevImage &img, const uint
 #pragma unroll 1
     for (int it = 0; it < 2; ++it) {
         if (!done) {
-            const uint64_t p = it ? p1 : p0;
-            const uint32_t lo = pgx_find_block<LDS_IMAGE>(img, lds_dir, lds_blow, p);
-            const uint4 *bp = (LDS_IMAGE ? lds_blocks : img.blocks) + (size_t)lo * 4;
-            const uint4 h0 = bp[0], h1 = bp[1], r0 = bp[2], r1 = bp[3];
-            uint64_t c[6];
-            c[0] = (uint64_t)h0.x | ((uint64_t)(h1.z & 0xFFu) << 32);
-            c[1] = (uint64_t)h0.y | ((uint64_t)((h1.z >> 8) & 0xFFu) << 32);
-            c[2] = (uint64_t)h0.z | ((uint64_t)((h1.z >> 16) & 0xFFu) << 32);
-            c[3] = (uint64_t)h0.w | ((uint64_t)(h1.z >> 24) << 32);
-            c[4] = (uint64_t)h1.x | ((uint64_t)(h1.w & 0xFFu) << 32);
-            c[5] = (uint64_t)h1.y | ((uint64_t)((h1.w >> 8) & 0xFFu) << 32);
-            uint64_t start = 0, a = 0, b = 0;
-#pragma unroll
-            for (int i = 0; i < 6; i++) {
-                start += ((img.excl_mask >> i) & 1u) ? 0ull : c[i];
-                a = (cv == (uint32_t)i) ? c[i] : a;
-                b += c[i] * (uint64_t)((mrow >> (3 * i)) & 7u);
-            }
-            uint32_t relp = (uint32_t)(p - start);   // primary position of this trip (inside the block)
-            const uint64_t d1 = p1 - start;          // pos1 relative to this block; wraps when p1 < start
-            uint32_t rels = it ? 0u : (d1 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d1);
-            uint32_t iap = 0, ibp = 0, ias = 0, ibs = 0, total = 0;
-            const uint32_t arow = 1u << (3 * cv); // one-hot weight row selecting code cv
-            const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-#pragma unroll
-            for (int e = 0; e < PGX_BLOCK_RUNS; e++) {
-                // entry = (3 * code) << 12 | len: the stored shift indexes the 3-bit weight rows directly
-                const uint32_t w = rw[e >> 1];
-                const uint32_t sh = (e & 1) ? (w >> 28) : __builtin_amdgcn_ubfe(w, 12, 4);
-                const uint32_t len = (e & 1) ? __builtin_amdgcn_ubfe(w, 16, 12) : (w & PGX_RUN_LEN_MAX);
-                const uint32_t tp = min(len, relp), ts = min(len, rels);
-                const uint32_t wa = __builtin_amdgcn_ubfe(arow, sh, 3), wm = __builtin_amdgcn_ubfe(mrow, sh, 3);
-                total += len;
-                relp -= tp;
-                rels -= ts;
-                iap += tp * wa;
-                ias += ts * wa;
-                ibp += tp * wm;
-                ibs += ts * wm;
-            }
+            uint64_t Ap, Bp, As, Bs;
+            bool covered;
+            pgx_probe<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, it ? p1 : p0, p1, it == 0, cv, mrow, Ap, Bp, As, Bs, covered);
             if (it == 0) {
-                A0 = a + iap;
-                B0 = b + ibp;
-                // pos1 is served by this block when it lies strictly inside it (a probe AT the block end
-                // belongs to the next block, whose header may carry a different quirk value), or at the
-                // end of the BWT
-                if (d1 < (uint64_t)total || (rels == 0 && lo + 1 == img.n_blocks)) {
-                    A1 = a + ias;
-                    B1 = b + ibs;
-                    done = true;
-                }
+                A0 = Ap; B0 = Bp;
+                if (covered) { A1 = As; B1 = Bs; done = true; }
             } else {
-                A1 = a + iap;
-                B1 = b + ibp;
+                A1 = Ap; B1 = Bp;
             }
         }
     }
@@ -234,6 +245,8 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     uint32_t nm = 0, next = 0;
     int ph = 0;                      // 0 = idle (no read, or read finished)
     uint64_t win = 0, win_at = ~0ull; // 8 read bytes cached in registers (absolute, 8-aligned offset)
+    uint64_t A0 = 0, B0 = 0;          // first-probe sums of an extension whose second probe is pending
+    bool pend = false;
     uint64_t rnext = 0, rend = 0;    // wave-uniform reservoir of read ids
     bool exhausted = false;          // wave-uniform: the global cursor has passed n_reads
 
@@ -293,7 +306,9 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
             if (exhausted && rnext == rend) break; // nothing live, nothing left
             continue;                               // only zero-work reads were handed out: refill again
         }
-        // ---- one extension for every live lane ----
+        // ---- one block decode for every live lane: an extension whose second probe falls outside the block
+        //      of the first takes two trips of this loop (pend = 1 in between), so no lane ever waits for
+        //      another lane's second trip ----
         if (ph > 0) {
             uint32_t byte = 0u; // pattern[len] reads as 0 (quirk 4)
             if (j < len) {
@@ -305,26 +320,56 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                 byte = (uint32_t)(win >> (8u * (uint32_t)(at & 7ull))) & 0xFFu;
             }
             const bool fwd = (ph == 2);
-            pgx_extend<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, s_ext, s_C, k, kp, s, byte, fwd);
-            next++;
-            const bool small = (s < min_occ) || (s == 0); // :671 (unsigned compare) || size <= 0
-            if (ph == 1) {
-                if (small) { x = j + 1; begin(); }
-                else if (j == x) {
-                    Jk = k; Js = s; j = x + (int32_t)min_len;
-                    if (j >= len) emit(); else ph = 2;
-                } else j--;
-            } else if (ph == 2) {
-                if (small) emit();
-                else {
-                    Jk = k; Js = s; j++;
-                    if (j >= len) emit();
+            // extension by `byte` (backward, or forward = backward on the swapped interval by the complement,
+            // folded into ext_tab[256 + byte]): src/r-index.cpp:713-764
+            const uint32_t ee = s_ext[(fwd ? 256u : 0u) + byte];
+            const uint32_t cv = PGX_EXT_CV(ee), mrow = PGX_EXT_M(ee);
+            const uint64_t kk = fwd ? kp : k, kq = fwd ? k : kp;
+            const uint64_t p0 = kk > n ? n : kk, p1 = (kk + s) > n ? n : (kk + s);
+            uint64_t Ap, Bp, As, Bs;
+            bool covered;
+            pgx_probe<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, pend ? p1 : p0, p1, !pend, cv, mrow, Ap, Bp, As, Bs, covered);
+            bool fin;
+            uint64_t A1, B1;
+            if (!pend) {
+                A0 = Ap; B0 = Bp;
+                A1 = As; B1 = Bs;
+                fin = covered;
+                pend = !covered;
+            } else {
+                A1 = Ap; B1 = Bp;
+                fin = true;
+                pend = false;
+            }
+            if (fin) {
+                next++;
+                if (PGX_EXT_KILL(ee) || A0 >= A1) { // rank_k >= rank_ks -> bi_interval(0,0,0), src/r-index.cpp:751
+                    k = 0; kp = 0; s = 0;
+                } else {
+                    const uint64_t nk = A0 + s_C[PGX_EXT_V(ee)], nq = kq + (B1 - B0);
+                    s = A1 - A0;
+                    k = fwd ? nq : nk;
+                    kp = fwd ? nk : nq;
                 }
-            } else { // ph == 3
-                if (small) { x = j + 1; begin(); }
-                else {
-                    j--;
-                    if (j <= x) { x = x + 1; begin(); }
+                const bool small = (s < min_occ) || (s == 0); // :671 (unsigned compare) || size <= 0
+                if (ph == 1) {
+                    if (small) { x = j + 1; begin(); }
+                    else if (j == x) {
+                        Jk = k; Js = s; j = x + (int32_t)min_len;
+                        if (j >= len) emit(); else ph = 2;
+                    } else j--;
+                } else if (ph == 2) {
+                    if (small) emit();
+                    else {
+                        Jk = k; Js = s; j++;
+                        if (j >= len) emit();
+                    }
+                } else { // ph == 3
+                    if (small) { x = j + 1; begin(); }
+                    else {
+                        j--;
+                        if (j <= x) { x = x + 1; begin(); }
+                    }
                 }
             }
         }
