@@ -325,28 +325,35 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
             const uint32_t ee = s_ext[(fwd ? 256u : 0u) + byte];
             const uint32_t cv = PGX_EXT_CV(ee), mrow = PGX_EXT_M(ee);
             const uint64_t kk = fwd ? kp : k, kq = fwd ? k : kp;
-            const uint64_t p0 = kk > n ? n : kk, p1 = (kk + s) > n ? n : (kk + s);
-            uint64_t Ap, Bp, As, Bs;
-            bool covered;
-            pgx_probe<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, pend ? p1 : p0, p1, !pend, cv, mrow, Ap, Bp, As, Bs, covered);
             bool fin;
-            uint64_t A1, B1;
-            if (!pend) {
-                A0 = Ap; B0 = Bp;
-                A1 = As; B1 = Bs;
-                fin = covered;
-                pend = !covered;
-            } else {
-                A1 = Ap; B1 = Bp;
+            uint64_t A1, dB;
+            if (LDS_IMAGE) {
+                // image in LDS: no memory latency to hide and most extensions of a tiny index need both blocks,
+                // so both trips run back to back (measured 6 % faster than the one-trip-per-iteration form)
+                pgx_rank_pair<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, kk, kk + s, cv, mrow, A0, A1, dB);
                 fin = true;
-                pend = false;
+            } else {
+                const uint64_t p0 = kk > n ? n : kk, p1 = (kk + s) > n ? n : (kk + s);
+                uint64_t Ap, Bp, As, Bs;
+                bool covered;
+                pgx_probe<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, pend ? p1 : p0, p1, !pend, cv, mrow, Ap, Bp, As, Bs, covered);
+                if (!pend) {
+                    A0 = Ap; B0 = Bp;
+                    A1 = As; dB = Bs - Bp;
+                    fin = covered;
+                    pend = !covered;
+                } else {
+                    A1 = Ap; dB = Bp - B0;
+                    fin = true;
+                    pend = false;
+                }
             }
             if (fin) {
                 next++;
                 if (PGX_EXT_KILL(ee) || A0 >= A1) { // rank_k >= rank_ks -> bi_interval(0,0,0), src/r-index.cpp:751
                     k = 0; kp = 0; s = 0;
                 } else {
-                    const uint64_t nk = A0 + s_C[PGX_EXT_V(ee)], nq = kq + (B1 - B0);
+                    const uint64_t nk = A0 + s_C[PGX_EXT_V(ee)], nq = kq + dB;
                     s = A1 - A0;
                     k = fwd ? nq : nk;
                     kp = fwd ? nk : nq;
