@@ -562,6 +562,98 @@ void orc_count(const orc_ri *r, int mode, const uint8_t *read, uint64_t len, uin
     *second = hi;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* locate: locateFirst / locateNext / locate / locate_encoded / decompressSA / decompressDA */
+
+/* FastLocate::locateFirst = getSample(0), include/pangenome_index/r-index.hpp:490-492,616-618 */
+uint64_t orc_locate_first(const orc_ri *r) { return r->samples.n ? iv_get(&r->samples, 0) : ORC_NO_POSITION; }
+
+/* FastLocate::locateNext, src/r-index.cpp:1363-1366:
+ *   iter = last.predecessor(prev); return samples[last_to_run[iter->first] + 1] + (prev - iter->second)
+ * Undefined in the reference when no tail sample precedes prev or when the tail belongs to the last run
+ * (samples[r] is read past the end); defined here as ORC_NO_POSITION. */
+uint64_t orc_locate_next(const orc_ri *r, uint64_t prev) {
+    uint64_t rank = 0, pos = 0;
+    if (prev == ORC_NO_POSITION || !ef_predecessor(&r->last, prev, &rank, &pos)) return ORC_NO_POSITION;
+    const uint64_t run = iv_get(&r->last_to_run, rank) + 1;
+    if (run >= r->samples.n) return ORC_NO_POSITION;
+    return iv_get(&r->samples, run) + (prev - pos);
+}
+
+uint64_t orc_seq_id(const orc_ri *r, uint64_t v) { return v / r->max_length; }      /* r-index.hpp:429 */
+uint64_t orc_seq_offset(const orc_ri *r, uint64_t v) { return v % r->max_length; }  /* r-index.hpp:431 */
+
+/* FastLocate::decompressSA, src/r-index.cpp:1343-1353 (decompressDA :1355-1361 divides by max_length) */
+void orc_decompress_sa(const orc_ri *r, uint64_t *out) {
+    if (!r->sequence_size) return;
+    out[0] = orc_locate_first(r);
+    for (uint64_t i = 1; i < r->sequence_size; i++) out[i] = orc_locate_next(r, out[i - 1]);
+}
+
+/* run holding BWT position pos and the BWT offset of its first symbol.
+ * legacy: Run_blocks::run_id_at (r-index.hpp:224-234) as called at src/r-index.cpp:1267-1270;
+ * encoded: the inline scan of locate_encoded (:1308-1326) == run_id_and_offset_at (:1189-1213), whose
+ * EncodedBlock::skip_header (:83-88) always skips SIX varints (quirk 3).  STRICT skips the sigma varints the
+ * writer emitted (:339).  Returns 0 when the literal scan leaves the encoded stream (undefined in the reference). */
+static int run_id_and_offset(const orc_ri *r, int mode, uint64_t pos, uint64_t *run_id, uint64_t *off) {
+    uint64_t bid = 0, bstart = 0;
+    if (!ef_predecessor(&r->blocks_start_pos, pos, &bid, &bstart)) return 0;
+    if (!r->encoded) {
+        const lblock_t *b = &r->blocks[bid];
+        uint64_t cur = 0, run_num = 0;
+        while (run_num < b->nruns) {
+            if (cur + b->len[run_num] > pos - bstart) break;
+            cur += b->len[run_num];
+            run_num++;
+        }
+        *run_id = bid * 10 + run_num; /* block_size = 10, r-index.hpp:312 */
+        *off = bstart + cur;
+        return 1;
+    }
+    uint64_t loc = iv_get(&r->enc_starts, bid);
+    const uint64_t skip = (mode == ORC_MODE_STRICT) ? r->sigma : 6;
+    for (uint64_t i = 0; i < skip; i++) {
+        int over = 0;
+        (void)bytecode_read(r->stream, r->stream_n, &loc, &over);
+        if (over) return 0;
+    }
+    uint64_t cur = 0, runnum = 0;
+    for (;;) {
+        if (loc >= r->stream_n) return 0;
+        uint8_t header = r->stream[loc++];
+        uint64_t prefix = header & 0x1F, run_length;
+        if (prefix < 31) run_length = prefix + 1;
+        else {
+            int over = 0;
+            run_length = 32 + bytecode_read(r->stream, r->stream_n, &loc, &over);
+            if (over) return 0;
+        }
+        if (cur + run_length > pos - bstart) {
+            *run_id = bid * (r->enc_block_size ? r->enc_block_size : 10) + runnum;
+            *off = bstart + cur;
+            return 1;
+        }
+        cur += run_length;
+        runnum++;
+    }
+}
+
+/* the suffix-array values of BWT positions [first, last] in BWT order, as FastLocate::locate (src/r-index.cpp:1252-1290)
+ * / locate_encoded (:1299-1341) produce them before seqId / sort / unique.  Returns the number of values
+ * (0 for an empty state), or ORC_NO_POSITION when the literal run scan is undefined (see run_id_and_offset). */
+uint64_t orc_locate_sa(const orc_ri *r, int mode, uint64_t first, uint64_t last, uint64_t *out) {
+    if (last < first) return 0; /* :1255 */
+    uint64_t run_id = 0, off = 0;
+    if (!run_id_and_offset(r, mode, first, &run_id, &off)) return ORC_NO_POSITION;
+    if (run_id >= r->samples.n) return ORC_NO_POSITION;
+    uint64_t v = iv_get(&r->samples, run_id); /* getSample(run_id) */
+    while (off < first) { v = orc_locate_next(r, v); off++; }
+    uint64_t k = 0;
+    out[k++] = v;
+    for (uint64_t i = first + 1; i <= last; i++) { v = orc_locate_next(r, v); out[k++] = v; }
+    return k;
+}
+
 typedef struct { orc_mem *v; uint64_t n, cap, total; } memsink_t;
 static inline void sink_push(memsink_t *s, orc_mem m) {
     if (s->n < s->cap) s->v[s->n++] = m;

@@ -97,6 +97,17 @@ uint64_t orc_find_all_mems(const orc_ri *r, int mode, const uint8_t *read, uint6
  * wrong-but-deterministic on an encoded index without N).  STRICT: textbook backward search. */
 void orc_count(const orc_ri *r, int mode, const uint8_t *read, uint64_t len, uint64_t *first, uint64_t *second);
 
+/* ---- locate: src/r-index.cpp:1252-1366, r-index.hpp:424-436,490-501 ---- */
+#define ORC_NO_POSITION (~(uint64_t)0)
+uint64_t orc_locate_first(const orc_ri *r);
+uint64_t orc_locate_next(const orc_ri *r, uint64_t prev);
+uint64_t orc_seq_id(const orc_ri *r, uint64_t v);
+uint64_t orc_seq_offset(const orc_ri *r, uint64_t v);
+void orc_decompress_sa(const orc_ri *r, uint64_t *out); /* out has bwt_size entries; DA = seq_id of each */
+/* SA values of BWT[first..last] in BWT order (what locate / locate_encoded compute before seqId + sort + unique);
+ * returns their number, or ORC_NO_POSITION when the reference's literal scan is undefined (COMPAT, encoded, no N) */
+uint64_t orc_locate_sa(const orc_ri *r, int mode, uint64_t first, uint64_t last, uint64_t *out);
+
 /* ---- tag array ---- */
 orc_tags *orc_tags_load(const char *path, int format);
 void orc_tags_free(orc_tags *t);

@@ -44,6 +44,9 @@ MEM_DTYPE = np.dtype([("start", "<u8"), ("end", "<u8"), ("bwt_start", "<u8"), ("
 _lib = None
 
 
+NO_POSITION = 0xFFFFFFFFFFFFFFFF
+
+
 def build():
     subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
 
@@ -82,6 +85,12 @@ def lib():
     L.orc_find_all_mems.restype = u64
     L.orc_find_all_mems.argtypes = [p, C.c_int, C.c_char_p, u64, u64, u64, C.POINTER(Mem), u64, C.POINTER(u64)]
     L.orc_count.argtypes = [p, C.c_int, C.c_char_p, u64, C.POINTER(u64), C.POINTER(u64)]
+    L.orc_locate_first.restype, L.orc_locate_first.argtypes = u64, [p]
+    L.orc_locate_next.restype, L.orc_locate_next.argtypes = u64, [p, u64]
+    L.orc_seq_id.restype, L.orc_seq_id.argtypes = u64, [p, u64]
+    L.orc_seq_offset.restype, L.orc_seq_offset.argtypes = u64, [p, u64]
+    L.orc_decompress_sa.argtypes = [p, C.c_void_p]
+    L.orc_locate_sa.restype, L.orc_locate_sa.argtypes = u64, [p, C.c_int, u64, u64, C.c_void_p]
     L.orc_tags_load.restype, L.orc_tags_load.argtypes = p, [C.c_char_p, C.c_int]
     L.orc_tags_free.argtypes = [p]
     for name in ("n_runs", "bwt_intervals_size", "n_items", "n_starts", "file_bytes_consumed"):
@@ -173,6 +182,39 @@ class RIndex:
         lo, hi = C.c_uint64(0), C.c_uint64(0)
         self.L.orc_count(self.h, mode, b, len(b), C.byref(lo), C.byref(hi))
         return lo.value, hi.value
+
+    max_length = property(lambda s: s.L.orc_ri_max_length(s.h))
+
+    def locate_first(self):
+        return self.L.orc_locate_first(self.h)
+
+    def locate_next(self, prev):
+        return self.L.orc_locate_next(self.h, prev)
+
+    def decompress_sa(self):
+        out = np.zeros(self.n, dtype=np.uint64)
+        self.L.orc_decompress_sa(self.h, out.ctypes.data)
+        return out
+
+    def decompress_da(self):
+        return self.decompress_sa() // np.uint64(self.max_length)
+
+    def locate_sa(self, first, last, mode=MODE_COMPAT):
+        """SA values of BWT[first..last] in BWT order; None when the reference's literal scan is undefined."""
+        if last < first:
+            return np.zeros(0, dtype=np.uint64)
+        out = np.zeros(last - first + 1, dtype=np.uint64)
+        k = self.L.orc_locate_sa(self.h, mode, first, last, out.ctypes.data)
+        if k == NO_POSITION:
+            return None
+        return out[:k]
+
+    def locate(self, first, last, mode=MODE_COMPAT):
+        """FastLocate::locate / locate_encoded: sorted unique sequence ids."""
+        sa = self.locate_sa(first, last, mode)
+        if sa is None:
+            return None
+        return np.unique(sa // np.uint64(self.max_length))
 
     def find_all_mems(self, read, min_len, min_occ, mode=MODE_COMPAT, with_ext=False):
         b = read.encode() if isinstance(read, str) else bytes(read)
