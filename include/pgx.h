@@ -82,6 +82,8 @@ typedef struct {
     uint64_t image_bytes;   /* device bytes of the rank image (blocks + directory + block lows) */
     uint64_t tag_image_bytes;
     double ref_block_mean_bytes; /* mean encoded block size of the reference layout (B_blk) */
+    uint64_t max_length;    /* Header::max_length: packed position = seq * max_length + offset (r-index.hpp:424) */
+    uint64_t n_samples;     /* samples.size() = runs in the reference's numbering */
 } pgx_index_info;
 
 const char *pgx_last_error(void);
@@ -150,6 +152,26 @@ typedef struct {
 } pgx_range;
 pgx_status pgx_count_batch(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
                            pgx_range *out);
+
+/* ---- locate: suffix-array samples of the r-index ---------------------------------------- */
+#define PGX_NO_POSITION (~(uint64_t)0)
+#define PGX_LOCATE_SEQ_IDS 1u /* values are seqId(v) = v / max_length (r-index.hpp:429) instead of packed positions */
+#define PGX_LOCATE_UNIQUE 2u  /* every query's values sorted and de-duplicated (src/r-index.cpp:1293-1294)            */
+/* FastLocate::locate / locate_encoded (src/r-index.cpp:1252-1341) for n BWT ranges [first[i], last[i]] (inclusive;
+ * last < first is the empty state).  flags = PGX_LOCATE_SEQ_IDS | PGX_LOCATE_UNIQUE is the reference's result
+ * (sorted unique sequence ids); flags = 0 gives the packed suffix-array values pack(seq, offset) in BWT order.
+ * val_offsets has n + 1 entries.  values == NULL returns the offsets only; otherwise values_cap must hold the
+ * result (sum of last - first + 1 always suffices).  Ranges must end before bwt_size (PGX_ERR_ARG otherwise).
+ * PGX_ERR_UNSUPPORTED in COMPAT mode on an encoded index without N: the reference's run scan skips six header
+ * varints where five were written (EncodedBlock::skip_header, src/r-index.cpp:83-88). */
+pgx_status pgx_locate_batch(pgx_index *h, int device, const uint64_t *first, const uint64_t *last, uint64_t n,
+                            uint32_t flags, uint64_t *val_offsets, uint64_t *values, uint64_t values_cap);
+/* FastLocate::locateNext (src/r-index.cpp:1363-1366) for n packed positions; PGX_NO_POSITION where the reference's
+ * result is undefined (no tail sample at or before prev, or the tail of the last run). */
+pgx_status pgx_locate_next_batch(pgx_index *h, int device, const uint64_t *prev, uint64_t n, uint64_t *out);
+/* FastLocate::decompressSA (flags = 0) / decompressDA (flags = PGX_LOCATE_SEQ_IDS), src/r-index.cpp:1343-1361:
+ * out has bwt_size entries.  Every BWT run is an independent chain from its head sample. */
+pgx_status pgx_decompress_sa(pgx_index *h, int device, uint32_t flags, uint64_t *out);
 
 /* ---- the hot path: find_mems over a batch of reads ----------------------------------------- */
 #define PGX_RUN_TAGS 1u    /* also run the tag queries of find_mems.cpp:129 */

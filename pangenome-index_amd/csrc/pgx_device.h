@@ -69,4 +69,20 @@ __global__ void pgx_tag_copy_dups_kernel(const uint64_t *pairs, uint64_t n_pairs
 __global__ void pgx_tag_compact_kernel(uint64_t n, const uint64_t *ucount, const uint64_t *seg_off, const uint64_t *buf,
                                        const uint64_t *pos_off, uint64_t *positions);
 
+// locate image (pgx_image.h), passed by value to the locate kernels
+struct PgxLocImage {
+    const uint64_t *rstart, *rsamp; // n_runs + 1, n_runs
+    const uint32_t *rdir;
+    const uint64_t *lpos, *lnext;   // n_last each
+    const uint32_t *ldir;
+    uint64_t n, n_runs, n_last, max_length, rdir_entries, ldir_entries;
+    uint32_t rdir_shift, ldir_shift;
+};
+__global__ void pgx_locate_next_kernel(PgxLocImage loc, const uint64_t *prev, uint64_t n, uint64_t *out);
+__global__ void pgx_locate_plan_kernel(PgxLocImage loc, const uint64_t *qs, const uint64_t *qe, uint64_t n, uint64_t *run0,
+                                       uint64_t *n_pieces);
+__global__ void pgx_locate_walk_kernel(PgxLocImage loc, const uint64_t *qs, const uint64_t *qe, uint64_t n_queries,
+                                       const uint64_t *run0, const uint64_t *piece_off, uint64_t n_pieces, const uint64_t *val_off,
+                                       int seq_ids, uint64_t *out);
+
 #define PGX_SCAN_BLOCK_ITEMS 2048 // 256 threads x 8 items (pgx_kernels.hip PGX_SCAN_ITEMS)

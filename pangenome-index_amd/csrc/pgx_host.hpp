@@ -117,7 +117,15 @@ struct HostImage {
     uint64_t n_runs = 0;
 };
 
+struct LocHostImage { // locate image (pgx_image.h), built on first use
+    PgxLocConsts consts;
+    std::vector<uint64_t> rstart, rsamp, lpos, lnext;
+    std::vector<uint32_t> rdir, ldir;
+    bool built = false;
+};
+
 void build_rank_image(const RiFile &ri, uint32_t mode, HostImage &img);
+void build_locate_image(const RiFile &ri, LocHostImage &loc);
 void build_tag_image(const TagFile &tf, HostImage &img);
 void build_ext_tables(const RiFile &ri, uint32_t mode, PgxConsts &c);
 
@@ -131,5 +139,6 @@ struct pgx_index {
     bool has_tags = false, has_rank = false;
     uint32_t mode = 0;
     pgx::HostImage img;
+    pgx::LocHostImage loc;
     std::vector<pgx_device_image *> dev; // one per device ordinal (lazily filled)
 };

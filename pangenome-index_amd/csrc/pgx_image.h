@@ -71,4 +71,20 @@ typedef struct {
     uint32_t cnt_tab[256];
 } PgxConsts;
 
+/* locate image (FastLocate::locate / locateNext / decompressSA, src/r-index.cpp:1252-1366): three sorted
+ * u64 arrays with the same sampled u32 directory as tdir (dir[i] = #elements <= i << shift):
+ *   rstart[r + 1]  first BWT position of every run in the reference's run numbering (rstart[r] = n); rsamp[r] =
+ *                  samples[run] = packed text position (seq * max_length + offset) of the run's first suffix
+ *   lpos[r]        ones of `last` (packed text positions of run tails); lnext[i] = samples[last_to_run[i] + 1],
+ *                  so locateNext(v) = lnext[i] + (v - lpos[i]) with i = predecessor of v in lpos               */
+#define PGX_NO_POSITION (~(uint64_t)0)
+typedef struct {
+    uint64_t n;          /* bwt size */
+    uint64_t n_runs;     /* samples.size() */
+    uint64_t n_last;     /* ones of last */
+    uint64_t max_length; /* header.max_length: seqId = v / max_length */
+    uint64_t rdir_entries, ldir_entries;
+    uint32_t rdir_shift, ldir_shift;
+} PgxLocConsts;
+
 #endif

@@ -427,6 +427,62 @@ void build_tag_image(const TagFile &tf, HostImage &img) {
     if (nr >> 32) throw Error(PGX_ERR_UNSUPPORTED, "more than 2^32 tag runs");
 }
 
+// sampled directory over an ascending array: dir[i] = #elements <= (i << shift), about one bucket per element
+static void build_sorted_dir(const std::vector<uint64_t> &arr, uint64_t span, uint32_t &shift, uint64_t &entries,
+                             std::vector<uint32_t> &dir) {
+    const uint64_t cnt = arr.size();
+    if (cnt >> 32) throw Error(PGX_ERR_UNSUPPORTED, "more than 2^32 runs");
+    if (!span) span = 1;
+    shift = 0;
+    while (shift < 48 && ((span >> (shift + 1)) + 2) >= 2 * (cnt + 1)) shift++;
+    entries = (span >> shift) + 2;
+    dir.resize(entries);
+    uint64_t k = 0;
+    for (uint64_t i = 0; i < entries; i++) {
+        const uint64_t p = i << shift;
+        while (k < cnt && arr[k] <= p) k++;
+        dir[i] = (uint32_t)k;
+    }
+}
+
+// locate image: run starts in the reference's run numbering (the file's blocks as written: endmarker runs are one
+// symbol each, src/r-index.cpp:842-900), head samples, and the tail -> next-head map of locateNext (:1363-1366)
+void build_locate_image(const RiFile &ri, LocHostImage &loc) {
+    if (loc.built) return;
+    const uint64_t r = ri.samples.size();
+    loc.rstart.clear();
+    loc.rstart.reserve(r + 1);
+    uint64_t pos = 0;
+    for (size_t b = 0; b < ri.blocks.size(); b++)
+        for (const auto &run : ri.blocks[b].runs) {
+            loc.rstart.push_back(pos);
+            pos += run.second;
+        }
+    if (loc.rstart.size() != r) throw Error(PGX_ERR_FORMAT, "FastLocate: samples and runs disagree (" + std::to_string(r) + " samples, " +
+                                                       std::to_string(loc.rstart.size()) + " runs)");
+    if (pos != ri.sequence_size) throw Error(PGX_ERR_FORMAT, "FastLocate: run lengths do not add up to the BWT size");
+    loc.rstart.push_back(pos);
+    loc.rsamp.resize(r);
+    for (uint64_t i = 0; i < r; i++) loc.rsamp[i] = ri.samples.get(i);
+    const uint64_t nl = ri.last.ones.size();
+    if (ri.last_to_run.size() != nl) throw Error(PGX_ERR_FORMAT, "FastLocate: last and last_to_run disagree");
+    loc.lpos = ri.last.ones;
+    loc.lnext.resize(nl);
+    for (uint64_t i = 0; i < nl; i++) {
+        const uint64_t run = ri.last_to_run.get(i) + 1;
+        loc.lnext[i] = run < r ? loc.rsamp[run] : PGX_NO_POSITION; // the reference reads samples[r] (past the end) here
+    }
+    PgxLocConsts &c = loc.consts;
+    std::memset(&c, 0, sizeof c);
+    c.n = ri.sequence_size;
+    c.n_runs = r;
+    c.n_last = nl;
+    c.max_length = ri.max_length ? ri.max_length : 1;
+    build_sorted_dir(loc.rstart, ri.sequence_size + 1, c.rdir_shift, c.rdir_entries, loc.rdir);
+    build_sorted_dir(loc.lpos, ri.last.size + 1, c.ldir_shift, c.ldir_entries, loc.ldir);
+    loc.built = true;
+}
+
 } // namespace pgx
 
 // ------------------------------------------------------------------------------------------
@@ -530,6 +586,8 @@ extern "C" pgx_status pgx_index_info_get(const pgx_index *h, pgx_index_info *inf
     info->tag_image_bytes = h->img.tstart.size() * 8 + h->img.tvals.size() * 8 + h->img.tdir.size() * 4;
     info->image_in_lds = info->image_bytes <= 48 * 1024;
     info->ref_block_mean_bytes = h->ri.ref_block_mean_bytes;
+    info->max_length = h->ri.max_length;
+    info->n_samples = h->ri.samples.size();
     return PGX_OK;
     PGX_GUARD_END
 }
@@ -538,6 +596,21 @@ extern "C" pgx_status pgx_index_image_view(const pgx_index *h, int which, const 
     PGX_GUARD_BEGIN
     if (!h || !ptr || !bytes) throw Error(PGX_ERR_ARG, "pgx_index_image_view: null argument");
     const HostImage &m = h->img;
+    if (which >= 8 && which <= 14) { // locate image (built on first use)
+        if (!h->has_rank) throw Error(PGX_ERR_ARG, "pgx_index_image_view: no r-index loaded");
+        build_locate_image(h->ri, const_cast<pgx_index *>(h)->loc);
+    }
+    const LocHostImage &l = h->loc;
+    switch (which) {
+    case 8: *ptr = l.rstart.data(); *bytes = l.rstart.size() * 8; return PGX_OK;
+    case 9: *ptr = l.rsamp.data(); *bytes = l.rsamp.size() * 8; return PGX_OK;
+    case 10: *ptr = l.rdir.data(); *bytes = l.rdir.size() * 4; return PGX_OK;
+    case 11: *ptr = l.lpos.data(); *bytes = l.lpos.size() * 8; return PGX_OK;
+    case 12: *ptr = l.lnext.data(); *bytes = l.lnext.size() * 8; return PGX_OK;
+    case 13: *ptr = l.ldir.data(); *bytes = l.ldir.size() * 4; return PGX_OK;
+    case 14: *ptr = &l.consts; *bytes = sizeof(PgxLocConsts); return PGX_OK;
+    default: break;
+    }
     switch (which) {
     case 0: *ptr = m.blocks.data(); *bytes = m.blocks.size(); break;
     case 1: *ptr = m.dir.data(); *bytes = m.dir.size() * 8; break;

@@ -1,0 +1,84 @@
+// pgx_locate_kernels.hip -- the r-index locate path as gfx950 kernels:
+// FastLocate::locateNext (src/r-index.cpp:1363-1366), locate / locate_encoded (:1252-1341) and
+// decompressSA / decompressDA (:1343-1361).
+//
+// The reference walks one chain per query: first = samples[run of state.first], then one locateNext per BWT
+// position.  Every BWT run starts with a stored sample, so the chain is cut at run boundaries here and each
+// (query, run) piece is walked by its own lane -- decompressSA becomes r independent chains instead of one chain of
+// n steps.  A step is a predecessor search in the sorted tail positions (directory load + a short binary search)
+// and one load of the next head sample: dependent random 8-byte reads, latency-bound.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pgx_device.h"
+
+// number of elements <= x in the ascending array `arr` (cnt entries) with sampled directory `dir`
+__device__ __forceinline__ uint64_t pgx_sorted_upper(const uint64_t *__restrict__ arr, const uint32_t *__restrict__ dir,
+                                                     uint32_t shift, uint64_t entries, uint64_t cnt, uint64_t x) {
+    const uint64_t di = x >> shift;
+    if (di + 1 >= entries) return cnt;
+    uint64_t lo = dir[di], hi = dir[di + 1];
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (arr[mid] <= x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// FastLocate::locateNext: samples[last_to_run[pred] + 1] + (prev - pred position)
+__device__ __forceinline__ uint64_t pgx_locate_next(const PgxLocImage &loc, uint64_t prev) {
+    if (prev == PGX_NO_POSITION) return PGX_NO_POSITION;
+    const uint64_t c = pgx_sorted_upper(loc.lpos, loc.ldir, loc.ldir_shift, loc.ldir_entries, loc.n_last, prev);
+    if (c == 0) return PGX_NO_POSITION; // no tail sample at or before prev: undefined in the reference
+    const uint64_t nx = loc.lnext[c - 1];
+    return nx == PGX_NO_POSITION ? PGX_NO_POSITION : nx + (prev - loc.lpos[c - 1]);
+}
+
+__global__ void __launch_bounds__(256)
+pgx_locate_next_kernel(PgxLocImage loc, const uint64_t *__restrict__ prev, uint64_t n, uint64_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = pgx_locate_next(loc, prev[i]);
+}
+
+// per query [qs, qe]: the run holding qs and the number of runs the range touches (0 for an empty range)
+__global__ void __launch_bounds__(256)
+pgx_locate_plan_kernel(PgxLocImage loc, const uint64_t *__restrict__ qs, const uint64_t *__restrict__ qe, uint64_t n,
+                       uint64_t *__restrict__ run0, uint64_t *__restrict__ n_pieces) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t a = qs[i], b = qe[i];
+    if (b < a) { run0[i] = 0; n_pieces[i] = 0; return; } // state.second < state.first -> empty result (:1255)
+    const uint64_t r0 = pgx_sorted_upper(loc.rstart, loc.rdir, loc.rdir_shift, loc.rdir_entries, loc.n_runs, a) - 1; // rstart[0] = 0 <= a
+    const uint64_t r1 = pgx_sorted_upper(loc.rstart, loc.rdir, loc.rdir_shift, loc.rdir_entries, loc.n_runs, b) - 1;
+    run0[i] = r0;
+    n_pieces[i] = r1 - r0 + 1;
+}
+
+// one lane per (query, run) piece: start from the run's head sample, skip to the first wanted position, emit.
+// seq_ids != 0 writes seqId(v) = v / max_length (r-index.hpp:429) instead of the packed position.
+__global__ void __launch_bounds__(256)
+pgx_locate_walk_kernel(PgxLocImage loc, const uint64_t *__restrict__ qs, const uint64_t *__restrict__ qe, uint64_t n_queries,
+                       const uint64_t *__restrict__ run0, const uint64_t *__restrict__ piece_off, uint64_t n_pieces,
+                       const uint64_t *__restrict__ val_off, int seq_ids, uint64_t *__restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_pieces) return;
+    // query owning piece t: last q with piece_off[q] <= t (piece_off has n_queries + 1 entries)
+    uint64_t lo = 0, hi = n_queries;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (piece_off[mid + 1] <= t) lo = mid + 1; else hi = mid;
+    }
+    const uint64_t q = lo;
+    const uint64_t run = run0[q] + (t - piece_off[q]);
+    const uint64_t rs = loc.rstart[run], re = loc.rstart[run + 1]; // run = BWT[rs, re)
+    const uint64_t a = qs[q] > rs ? qs[q] : rs;
+    const uint64_t b = qe[q] < re - 1 ? qe[q] : re - 1;
+    uint64_t v = loc.rsamp[run];
+    for (uint64_t p = rs; p < a; p++) v = pgx_locate_next(loc, v); // :1280-1283
+    uint64_t *dst = out + val_off[q] + (a - qs[q]);
+    for (uint64_t p = a;; p++) {
+        *dst++ = (seq_ids && v != PGX_NO_POSITION) ? v / loc.max_length : v;
+        if (p == b) break;
+        v = pgx_locate_next(loc, v);
+    }
+}

@@ -122,6 +122,9 @@ struct pgx_device_image {
     int device = -1;
     PgxDevImage img{};
     DevBuf blocks, dir, blow, consts, tstart, tvals, tdir;
+    DevBuf rstart, rsamp, rdir, lpos, lnext, ldir; // locate image, uploaded on first use
+    PgxLocImage loc{};
+    bool has_loc = false;
     size_t lds_bytes = 0; // dynamic LDS of the LDS-image kernels (0 = image stays in global memory)
 };
 
@@ -131,6 +134,7 @@ void pgx_release_device_images(pgx_index *h) {
         if (hipSetDevice(d->device) == hipSuccess) {
             d->blocks.release(); d->dir.release(); d->blow.release(); d->consts.release();
             d->tstart.release(); d->tvals.release(); d->tdir.release();
+            d->rstart.release(); d->rsamp.release(); d->rdir.release(); d->lpos.release(); d->lnext.release(); d->ldir.release();
         }
         delete d;
     }
@@ -354,6 +358,207 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
         HIPCHECK(hipGetLastError());
     }
     rec(2);
+}
+
+// ------------------------------------------------------------------------------------------
+// locate path (pgx_locate_kernels.hip)
+static pgx_device_image *locate_image(pgx_index *h, int device) {
+    if (!h->has_rank) throw Error(PGX_ERR_ARG, "locate: index opened without an r-index");
+    pgx_device_image *d = device_image(h, device);
+    if (d->has_loc) return d;
+    build_locate_image(h->ri, h->loc);
+    const LocHostImage &m = h->loc;
+    upload(d->rstart, m.rstart.data(), m.rstart.size() * 8);
+    upload(d->rsamp, m.rsamp.data(), m.rsamp.size() * 8);
+    upload(d->rdir, m.rdir.data(), m.rdir.size() * 4);
+    upload(d->lpos, m.lpos.data(), m.lpos.size() * 8);
+    upload(d->lnext, m.lnext.data(), m.lnext.size() * 8);
+    upload(d->ldir, m.ldir.data(), m.ldir.size() * 4);
+    PgxLocImage &g = d->loc;
+    g.rstart = d->rstart.as<uint64_t>(); g.rsamp = d->rsamp.as<uint64_t>(); g.rdir = d->rdir.as<uint32_t>();
+    g.lpos = d->lpos.as<uint64_t>(); g.lnext = d->lnext.as<uint64_t>(); g.ldir = d->ldir.as<uint32_t>();
+    g.n = m.consts.n; g.n_runs = m.consts.n_runs; g.n_last = m.consts.n_last; g.max_length = m.consts.max_length;
+    g.rdir_entries = m.consts.rdir_entries; g.ldir_entries = m.consts.ldir_entries;
+    g.rdir_shift = m.consts.rdir_shift; g.ldir_shift = m.consts.ldir_shift;
+    d->has_loc = true;
+    return d;
+}
+
+extern "C" pgx_status pgx_locate_next_batch(pgx_index *h, int device, const uint64_t *prev, uint64_t n, uint64_t *out) {
+    PGX_GUARD_BEGIN
+    if (!h || (n && (!prev || !out))) throw Error(PGX_ERR_ARG, "pgx_locate_next_batch: null argument");
+    pgx_device_image *d = locate_image(h, device);
+    if (!n) return PGX_OK;
+    DevBuf di, dout;
+    try {
+        di.ensure(n * 8); dout.ensure(n * 8);
+        HIPCHECK(hipMemcpy(di.p, prev, n * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(pgx_locate_next_kernel, dim3(grid_for(n, 256)), dim3(256), 0, nullptr, d->loc, di.as<uint64_t>(), n,
+                           dout.as<uint64_t>());
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpy(out, dout.p, n * 8, hipMemcpyDeviceToHost));
+    } catch (...) {
+        di.release(); dout.release();
+        throw;
+    }
+    di.release(); dout.release();
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+// the walk + optional segmented sort-unique; results stay in w_vals (values) / h_off (host offsets)
+static void locate_core(pgx_index *h, pgx_device_image *d, const uint64_t *first, const uint64_t *last, uint64_t n, uint32_t flags,
+                        std::vector<uint64_t> &h_off, DevBuf &vals_out, uint64_t &n_vals_out) {
+    const uint64_t bwt_n = d->loc.n;
+    std::vector<uint64_t> cnt(n), voff(n + 1);
+    voff[0] = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (last[i] < first[i]) cnt[i] = 0;
+        else {
+            if (last[i] >= bwt_n) throw Error(PGX_ERR_ARG, "pgx_locate_batch: range " + std::to_string(i) + " ends beyond the BWT");
+            cnt[i] = last[i] - first[i] + 1;
+        }
+        voff[i + 1] = voff[i] + cnt[i];
+    }
+    const uint64_t V = voff[n];
+    DevBuf dqs, dqe, drun0, dnp, dpoff, dvoff, dcnt, scan_tmp, dlist, dneed, dsoff, dscratch, ducount, duoff;
+    DevBuf *all[] = {&dqs, &dqe, &drun0, &dnp, &dpoff, &dvoff, &dcnt, &scan_tmp, &dlist, &dneed, &dsoff, &dscratch, &ducount, &duoff};
+    DevBuf gbuf;
+    try {
+        hipStream_t s = nullptr;
+        dqs.ensure(n * 8); dqe.ensure(n * 8); drun0.ensure(n * 8); dnp.ensure(n * 8); dpoff.ensure((n + 1) * 8); dvoff.ensure((n + 1) * 8);
+        HIPCHECK(hipMemcpy(dqs.p, first, n * 8, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(dqe.p, last, n * 8, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(dvoff.p, voff.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(pgx_locate_plan_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d->loc, dqs.as<uint64_t>(), dqe.as<uint64_t>(), n,
+                           drun0.as<uint64_t>(), dnp.as<uint64_t>());
+        HIPCHECK(hipGetLastError());
+        scan_excl(1, dnp.p, n, 0, dpoff.as<uint64_t>(), scan_tmp, s);
+        const uint64_t n_pieces = read_u64(dpoff.as<uint64_t>() + n, s);
+        gbuf.ensure((V ? V : 1) * 8);
+        if (n_pieces) {
+            hipLaunchKernelGGL(pgx_locate_walk_kernel, dim3(grid_for(n_pieces, 256)), dim3(256), 0, s, d->loc, dqs.as<uint64_t>(),
+                               dqe.as<uint64_t>(), n, drun0.as<uint64_t>(), dpoff.as<uint64_t>(), n_pieces, dvoff.as<uint64_t>(),
+                               (flags & PGX_LOCATE_SEQ_IDS) ? 1 : 0, gbuf.as<uint64_t>());
+            HIPCHECK(hipGetLastError());
+        }
+        if (!(flags & PGX_LOCATE_UNIQUE)) {
+            HIPCHECK(hipStreamSynchronize(s));
+            h_off = voff;
+            vals_out = gbuf; gbuf = DevBuf();
+            n_vals_out = V;
+        } else {
+            // segmented sort + unique with the tag path's kernels: one wave per segment up to 2048 values, one
+            // 1024-thread workgroup beyond (LDS up to 16384 values, global scratch above)
+            std::vector<uint64_t> wave_list, wg_list, need(n, 0), soff(n + 1, 0);
+            uint64_t max_cnt = 0;
+            for (uint64_t i = 0; i < n; i++) {
+                if (cnt[i] == 0) continue;
+                if (cnt[i] <= PGX_SORT_LDS_CAP) wave_list.push_back(i);
+                else {
+                    wg_list.push_back(i);
+                    max_cnt = std::max(max_cnt, cnt[i]);
+                    uint64_t p2 = 64;
+                    while (p2 < cnt[i]) p2 <<= 1;
+                    if (p2 > PGX_SORT_WG_LDS_CAP) need[i] = p2;
+                }
+            }
+            for (uint64_t i = 0; i < n; i++) soff[i + 1] = soff[i] + need[i];
+            dcnt.ensure(n * 8); ducount.ensure(n * 8); duoff.ensure((n + 1) * 8);
+            dlist.ensure((n ? n : 1) * 8); dsoff.ensure((n + 1) * 8); dscratch.ensure((soff[n] ? soff[n] : 1) * 8);
+            HIPCHECK(hipMemcpy(dcnt.p, cnt.data(), n * 8, hipMemcpyHostToDevice));
+            HIPCHECK(hipMemset(ducount.p, 0, n * 8)); // empty ranges are on no list
+            HIPCHECK(hipMemcpy(dsoff.p, soff.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+            uint64_t *d_wave = dlist.as<uint64_t>(), *d_wg = d_wave + wave_list.size();
+            if (!wave_list.empty()) HIPCHECK(hipMemcpy(d_wave, wave_list.data(), wave_list.size() * 8, hipMemcpyHostToDevice));
+            if (!wg_list.empty()) HIPCHECK(hipMemcpy(d_wg, wg_list.data(), wg_list.size() * 8, hipMemcpyHostToDevice));
+            if (!wave_list.empty())
+                hipLaunchKernelGGL(pgx_tag_sort_unique_kernel, dim3(grid_for(wave_list.size(), 4)), dim3(256), 0, s, (const uint64_t *)d_wave,
+                                   (uint64_t)wave_list.size(), dcnt.as<uint64_t>(), dvoff.as<uint64_t>(), gbuf.as<uint64_t>(), ducount.as<uint64_t>());
+            if (!wg_list.empty()) {
+                uint64_t p2max = 64;
+                while (p2max < max_cnt && p2max < PGX_SORT_WG_LDS_CAP) p2max <<= 1;
+                HIPCHECK(hipFuncSetAttribute((const void *)pgx_tag_sort_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)(PGX_SORT_WG_LDS_CAP * 8)));
+                hipLaunchKernelGGL(pgx_tag_sort_large_kernel, dim3(grid_for(wg_list.size(), 1)), dim3(1024), (size_t)p2max * 8, s,
+                                   (const uint64_t *)d_wg, (uint64_t)wg_list.size(), dcnt.as<uint64_t>(), dvoff.as<uint64_t>(), gbuf.as<uint64_t>(),
+                                   dscratch.as<uint64_t>(), dsoff.as<uint64_t>(), ducount.as<uint64_t>());
+            }
+            HIPCHECK(hipGetLastError());
+            scan_excl(1, ducount.p, n, 0, duoff.as<uint64_t>(), scan_tmp, s);
+            const uint64_t U = read_u64(duoff.as<uint64_t>() + n, s);
+            vals_out.ensure((U ? U : 1) * 8);
+            hipLaunchKernelGGL(pgx_tag_compact_kernel, dim3(grid_for(n, 16)), dim3(256), 0, s, n, ducount.as<uint64_t>(), dvoff.as<uint64_t>(),
+                               gbuf.as<uint64_t>(), duoff.as<uint64_t>(), vals_out.as<uint64_t>());
+            HIPCHECK(hipGetLastError());
+            h_off.resize(n + 1);
+            HIPCHECK(hipMemcpy(h_off.data(), duoff.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+            n_vals_out = U;
+        }
+    } catch (...) {
+        for (DevBuf *b : all) b->release();
+        gbuf.release();
+        throw;
+    }
+    for (DevBuf *b : all) b->release();
+    gbuf.release();
+}
+
+static void locate_check_supported(const pgx_index *h, const char *who) {
+    if (h->mode == PGX_MODE_COMPAT && h->ri.encoded && !h->ri.hasN)
+        throw Error(PGX_ERR_UNSUPPORTED, std::string(who) + ": the reference's encoded run scan skips six header varints where five were "
+                                         "written on an index without N (src/r-index.cpp:83-88); open the index in PGX_MODE_STRICT");
+}
+
+extern "C" pgx_status pgx_locate_batch(pgx_index *h, int device, const uint64_t *first, const uint64_t *last, uint64_t n, uint32_t flags,
+                                       uint64_t *val_offsets, uint64_t *values, uint64_t values_cap) {
+    PGX_GUARD_BEGIN
+    if (!h || !val_offsets || (n && (!first || !last))) throw Error(PGX_ERR_ARG, "pgx_locate_batch: null argument");
+    if (flags & ~(PGX_LOCATE_SEQ_IDS | PGX_LOCATE_UNIQUE)) throw Error(PGX_ERR_ARG, "pgx_locate_batch: unknown flag");
+    if (!h->has_rank) throw Error(PGX_ERR_ARG, "pgx_locate_batch: index opened without an r-index");
+    locate_check_supported(h, "pgx_locate_batch");
+    pgx_device_image *d = locate_image(h, device);
+    val_offsets[0] = 0;
+    if (!n) return PGX_OK;
+    std::vector<uint64_t> off;
+    DevBuf vals;
+    uint64_t nv = 0;
+    try {
+        locate_core(h, d, first, last, n, flags, off, vals, nv);
+        std::copy(off.begin(), off.end(), val_offsets);
+        if (values) {
+            if (values_cap < nv) throw Error(PGX_ERR_ARG, "pgx_locate_batch: values_cap too small");
+            if (nv) HIPCHECK(hipMemcpy(values, vals.p, nv * 8, hipMemcpyDeviceToHost));
+        }
+    } catch (...) {
+        vals.release();
+        throw;
+    }
+    vals.release();
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_decompress_sa(pgx_index *h, int device, uint32_t flags, uint64_t *out) {
+    PGX_GUARD_BEGIN
+    if (!h || !out) throw Error(PGX_ERR_ARG, "pgx_decompress_sa: null argument");
+    if (flags & ~PGX_LOCATE_SEQ_IDS) throw Error(PGX_ERR_ARG, "pgx_decompress_sa: unknown flag");
+    pgx_device_image *d = locate_image(h, device); // run boundaries come from the parsed blocks, not from the reference's scan
+    if (!d->loc.n) return PGX_OK;
+    const uint64_t first = 0, last = d->loc.n - 1;
+    std::vector<uint64_t> off;
+    DevBuf vals;
+    uint64_t nv = 0;
+    try {
+        locate_core(h, d, &first, &last, 1, flags, off, vals, nv);
+        HIPCHECK(hipMemcpy(out, vals.p, nv * 8, hipMemcpyDeviceToHost));
+    } catch (...) {
+        vals.release();
+        throw;
+    }
+    vals.release();
+    return PGX_OK;
+    PGX_GUARD_END
 }
 
 // ------------------------------------------------------------------------------------------

@@ -75,6 +75,54 @@ public:
     std::pair<size_t, size_t> count_encoded(std::string &pattern) const { return count_impl(pattern); }
     std::pair<size_t, size_t> count(std::string &pattern) { return count_impl(pattern); }
 
+    // ---- locate (r-index.hpp:385-406, 424-436, 490-501, 616-618; src/r-index.cpp:1252-1366) ----
+    typedef std::pair<size_type, size_type> range_type; // gbwt::range_type: inclusive BWT range, empty when second < first
+    constexpr static size_type NO_POSITION = ~(size_type)0;
+    size_type pack(size_type seq_id, size_type seq_offset) const { return seq_id * info_.max_length + seq_offset; }
+    size_type seqId(size_type offset) const { return offset / info_.max_length; }
+    size_type seqOffset(size_type offset) const { return offset % info_.max_length; }
+    std::pair<size_type, size_type> unpack(size_type offset) const { return std::make_pair(seqId(offset), seqOffset(offset)); }
+    size_type size() const { return info_.n_samples; } // runs
+    size_type getSample(size_type run_id) const {
+        const void *ptr = nullptr;
+        uint64_t bytes = 0;
+        if (!h_ || pgx_index_image_view(h_, 9, &ptr, &bytes) != PGX_OK) throw std::runtime_error(pgx_last_error());
+        if (run_id >= bytes / 8) throw std::out_of_range("FastLocate::getSample");
+        return static_cast<const uint64_t *>(ptr)[run_id];
+    }
+    size_type locateFirst() const { return getSample(0); }
+    size_type locateNext(size_type prev) const {
+        uint64_t out = NO_POSITION;
+        if (!h_ || pgx_locate_next_batch(h_, device_, &prev, 1, &out) != PGX_OK) throw std::runtime_error(pgx_last_error());
+        return out;
+    }
+    size_type locate_next_nth(size_type prev, size_type n) const {
+        for (size_type i = 0; i < n; i++) prev = locateNext(prev);
+        return prev;
+    }
+    // sorted unique sequence ids of the suffixes in `state` (the `first` hint of the reference is not needed here)
+    std::vector<size_type> locate(range_type state, size_type = NO_POSITION) const { return locate_impl(state); }
+    std::vector<size_type> locate_encoded(range_type state, size_type = NO_POSITION) const { return locate_impl(state); }
+    // many ranges in one launch: offsets has ranges.size() + 1 entries
+    void locate_batch(const std::vector<range_type> &states, std::vector<size_type> &offsets, std::vector<size_type> &seq_ids) const {
+        std::vector<uint64_t> f(states.size()), l(states.size());
+        uint64_t cap = 0;
+        for (size_t i = 0; i < states.size(); i++) {
+            f[i] = states[i].first; l[i] = states[i].second;
+            if (l[i] >= f[i]) cap += l[i] - f[i] + 1;
+        }
+        offsets.assign(states.size() + 1, 0);
+        seq_ids.assign(cap ? cap : 1, 0);
+        if (!h_ || pgx_locate_batch(h_, device_, f.data(), l.data(), states.size(), PGX_LOCATE_SEQ_IDS | PGX_LOCATE_UNIQUE, offsets.data(),
+                                    seq_ids.data(), cap) != PGX_OK)
+            throw std::runtime_error(pgx_last_error());
+        seq_ids.resize(offsets.back());
+    }
+    std::vector<size_type> decompressSA() const { return decompress(0); }                   // src/r-index.cpp:1343-1353
+    std::vector<size_type> decompressDA() const { return decompress(PGX_LOCATE_SEQ_IDS); }  // :1355-1361
+    std::vector<size_type> decompressSA_encoded() const { return decompressSA(); }          // r-index.hpp:397
+    std::vector<size_type> decompressDA_encoded() const { return decompressDA(); }          // r-index.hpp:398
+
     // library handle (for the batch entry points of algorithm.hpp)
     pgx_index *handle() const { return h_; }
     int device() const { return device_; }
@@ -97,6 +145,19 @@ private:
         uint64_t c[8];
         pgx_index_tables(h_, sym_map.data(), c, nullptr);
         C.assign(c, c + info_.sigma);
+    }
+
+    std::vector<size_type> locate_impl(range_type state) const {
+        std::vector<size_type> offsets, ids;
+        locate_batch(std::vector<range_type>(1, state), offsets, ids);
+        return ids;
+    }
+
+    std::vector<size_type> decompress(uint32_t flags) const {
+        if (!h_) throw std::runtime_error("FastLocate: no index loaded");
+        std::vector<size_type> out(info_.bwt_size);
+        if (pgx_decompress_sa(h_, device_, flags, out.data()) != PGX_OK) throw std::runtime_error(pgx_last_error());
+        return out;
     }
 
     std::pair<size_t, size_t> count_impl(const std::string &pattern) const {

@@ -30,7 +30,7 @@ class IndexInfo(C.Structure):
         ("n_dev_blocks", u64), ("dir_entries", u64), ("dir_shift", u32), ("is_encoded", u32), ("has_N", u32),
         ("mode", u32), ("has_tags", u32), ("tag_format", u32), ("n_tag_runs", u64), ("tag_dir_entries", u64),
         ("tag_dir_shift", u32), ("image_in_lds", u32), ("image_bytes", u64), ("tag_image_bytes", u64),
-        ("ref_block_mean_bytes", C.c_double),
+        ("ref_block_mean_bytes", C.c_double), ("max_length", u64), ("n_samples", u64),
     ]
 
 
@@ -94,6 +94,9 @@ def lib():
     L.pgx_extend_batch.argtypes = [p, C.c_int, p, p, p, u64, p]
     L.pgx_count_batch.argtypes = [p, C.c_int, p, p, u64, p]
     L.pgx_tag_query_batch.argtypes = [p, C.c_int, p, p, u64, p, p, p, u64, C.POINTER(u64)]
+    L.pgx_locate_batch.argtypes = [p, C.c_int, p, p, u64, u32, p, p, u64]
+    L.pgx_locate_next_batch.argtypes = [p, C.c_int, p, u64, p]
+    L.pgx_decompress_sa.argtypes = [p, C.c_int, u32, p]
     L.pgx_batch_create.argtypes = [p, C.c_int, p, p, u64, C.POINTER(p)]
     L.pgx_batch_upload.argtypes = [p, p, p, u64]
     L.pgx_batch_run.argtypes = [p, u64, u64, u32, p]
@@ -145,7 +148,10 @@ def convert_tags(in_path, out_path, compact=False):
     _check(lib().pgx_convert_tags(in_path.encode(), out_path.encode(), 1 if compact else 0))
 
 
-_VIEW_DTYPES = {0: np.uint8, 1: np.uint64, 2: np.uint64, 3: np.uint64, 4: np.uint64, 5: np.uint32, 6: np.uint8, 7: np.uint16}
+_VIEW_DTYPES = {0: np.uint8, 1: np.uint64, 2: np.uint64, 3: np.uint64, 4: np.uint64, 5: np.uint32, 6: np.uint8, 7: np.uint16,
+                8: np.uint64, 9: np.uint64, 10: np.uint32, 11: np.uint64, 12: np.uint64, 13: np.uint32, 14: np.uint8}
+LOCATE_SEQ_IDS, LOCATE_UNIQUE = 1, 2
+NO_POSITION = 0xFFFFFFFFFFFFFFFF
 
 
 class Index:
@@ -219,6 +225,28 @@ class Index:
         _check(self.L.pgx_tag_query_batch(self.h, device, st.ctypes.data, en.ctypes.data, n, rn.ctypes.data, po.ctypes.data,
                                           pos.ctypes.data, len(pos), C.byref(nover)))
         return rn, po, pos[:P], nover.value
+
+    def locate_batch(self, first, last, flags=0, device=0):
+        """FastLocate::locate for n BWT ranges -> (offsets[n+1], values); flags: LOCATE_SEQ_IDS | LOCATE_UNIQUE"""
+        fi = np.ascontiguousarray(first, dtype=np.uint64)
+        la = np.ascontiguousarray(last, dtype=np.uint64)
+        n = len(fi)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        cap = int(np.sum(np.where(la >= fi, la - fi + np.uint64(1), np.uint64(0)))) if n else 0
+        vals = np.zeros(max(cap, 1), dtype=np.uint64)
+        _check(self.L.pgx_locate_batch(self.h, device, fi.ctypes.data, la.ctypes.data, n, flags, off.ctypes.data, vals.ctypes.data, cap))
+        return off, vals[: int(off[-1])]
+
+    def locate_next_batch(self, prev, device=0):
+        pv = np.ascontiguousarray(prev, dtype=np.uint64)
+        out = np.zeros(len(pv), dtype=np.uint64)
+        _check(self.L.pgx_locate_next_batch(self.h, device, pv.ctypes.data, len(pv), out.ctypes.data))
+        return out
+
+    def decompress_sa(self, seq_ids=False, device=0):
+        out = np.zeros(self.info().bwt_size, dtype=np.uint64)
+        _check(self.L.pgx_decompress_sa(self.h, device, LOCATE_SEQ_IDS if seq_ids else 0, out.ctypes.data))
+        return out
 
     # ---- hot path ---------------------------------------------------------------------------
     def batch(self, reads_cat, offsets, device=0):

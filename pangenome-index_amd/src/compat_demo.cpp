@@ -29,6 +29,15 @@ int main(int argc, char **argv) {
     auto a = r_index.backward_extend(full, 'A');
     std::cerr << "sigma=" << r_index.C.size() << " sym_map[A]=" << (int)r_index.sym_map['A'] << " bwd(A)=" << a.forward << "," << a.reverse
               << "," << a.size << " comp(A)=" << (char)r_index.complement('A') << " strings=" << r_index.tot_strings() << std::endl;
+    // locate side of the same class (r-index.hpp:385-406,490-501): Locate_* of tests/test_rindex.cpp use exactly these calls
+    {
+        const auto first = r_index.locateFirst();
+        const auto da = r_index.decompressDA_encoded();
+        const auto ids = r_index.locate(FastLocate::range_type(0, r_index.tot_strings() - 1));
+        std::cerr << "locate: first=" << first << " next=" << r_index.locateNext(first) << " seq(first)=" << r_index.seqId(first) << "+"
+                  << r_index.seqOffset(first) << " DA[0..3]=" << da[0] << "," << da[1] << "," << da[2] << "," << da[3] << " |DA|=" << da.size()
+                  << " locate(endmarkers)=" << ids.size() << ":" << ids.front() << ".." << ids.back() << std::endl;
+    }
     while (std::getline(reads, read)) {
         if (read.empty()) continue;
         i++;

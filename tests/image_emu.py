@@ -239,3 +239,65 @@ class ImageEmu:
             else:
                 vals.append(0); over = True
         return cnt, sorted(set(vals)), over
+
+
+class LocateEmu:
+    """Walk of the locate image (PgxLocConsts + views 8..13) exactly as pgx_locate_kernels.hip walks it."""
+
+    NO = M64
+
+    def __init__(self, index):
+        raw = bytes(index.image_view(14))
+        (self.n, self.n_runs, self.n_last, self.max_length, self.rdir_entries, self.ldir_entries,
+         self.rdir_shift, self.ldir_shift) = struct.unpack("<6Q2I", raw)
+        self.rstart = index.image_view(8)
+        self.rsamp = index.image_view(9)
+        self.rdir = index.image_view(10)
+        self.lpos = index.image_view(11)
+        self.lnext = index.image_view(12)
+        self.ldir = index.image_view(13)
+        assert len(self.rstart) == self.n_runs + 1 and len(self.rsamp) == self.n_runs
+        assert len(self.lpos) == self.n_last == len(self.lnext)
+        assert len(self.rdir) == self.rdir_entries and len(self.ldir) == self.ldir_entries
+
+    @staticmethod
+    def _upper(arr, dirv, shift, entries, cnt, x):
+        di = x >> shift
+        if di + 1 >= entries:
+            return cnt
+        lo, hi = int(dirv[di]), int(dirv[di + 1])
+        while lo < hi:
+            mid = (lo + hi) >> 1
+            if int(arr[mid]) <= x:
+                lo = mid + 1
+            else:
+                hi = mid
+        return lo
+
+    def locate_next(self, prev):
+        if prev == self.NO:
+            return self.NO
+        c = self._upper(self.lpos, self.ldir, self.ldir_shift, self.ldir_entries, self.n_last, prev)
+        if c == 0:
+            return self.NO
+        nx = int(self.lnext[c - 1])
+        return self.NO if nx == self.NO else nx + (prev - int(self.lpos[c - 1]))
+
+    def locate(self, first, last):
+        """values of BWT[first..last]: one chain per (range, run) piece from the run's head sample"""
+        if last < first:
+            return []
+        r0 = self._upper(self.rstart, self.rdir, self.rdir_shift, self.rdir_entries, self.n_runs, first) - 1
+        r1 = self._upper(self.rstart, self.rdir, self.rdir_shift, self.rdir_entries, self.n_runs, last) - 1
+        out = []
+        for run in range(r0, r1 + 1):
+            rs, re = int(self.rstart[run]), int(self.rstart[run + 1])
+            a, b = max(first, rs), min(last, re - 1)
+            v = int(self.rsamp[run])
+            for _ in range(rs, a):
+                v = self.locate_next(v)
+            for p in range(a, b + 1):
+                out.append(v)
+                if p < b:
+                    v = self.locate_next(v)
+        return out

@@ -60,6 +60,13 @@ def test_compat_headers_same_output(built):
     assert strip_timing(a.stdout) == b.stdout
     # public members of FastLocate through the compat header: SURVEY 8c known answer A -> (8, 3420, 2309)
     assert "sigma=5 sym_map[A]=1 bwd(A)=8,3420,2309 comp(A)=T strings=8" in b.stderr
+    # locate members: against the oracle's chain on the same file
+    r = O.RIndex(os.path.join(BT, "xy.ri"))
+    sa = r.decompress_sa()
+    ml = r.max_length
+    exp = "locate: first=%d next=%d seq(first)=%d+%d DA[0..3]=%d,%d,%d,%d |DA|=%d locate(endmarkers)=8:0..7" % (
+        sa[0], sa[1], sa[0] // ml, sa[0] % ml, sa[0] // ml, sa[1] // ml, sa[2] // ml, sa[3] // ml, len(sa))
+    assert exp in b.stderr, b.stderr
 
 
 def test_cli_errors(built, workdir):

@@ -85,3 +85,36 @@ def test_locate_ranges(golden, workdir):
                 assert np.array_equal(got, sa[a:b + 1]), (encoded, mode, a, b)
                 assert np.array_equal(r.locate(a, b, mode), np.unique(da[a:b + 1]))
         assert len(r.locate_sa(5, 4)) == 0
+
+
+@pytest.mark.parametrize("which", ["xy", "two", "x_enc", "med_legacy"])
+def test_locate_image_walk(golden, workdir, which):
+    # the flat locate image the kernels walk (rstart/rsamp/lpos/lnext + directories), emulated in Python, vs the oracle
+    import image_emu as E
+    if which == "xy":
+        ri = os.path.join(golden, "bidirectional_test", "xy.ri")
+    elif which == "two":
+        ri = os.path.join(golden, "two_contig_graph", "xy.ri")
+    elif which == "x_enc":
+        ri = os.path.join(workdir, "loc_img_x.ri")
+        P.build_rindex(os.path.join(golden, "x.rl_bwt"), ri, encoded=True)
+    else:
+        ri = os.path.join(workdir, "loc_img_med.ri")
+        P.build_rindex(os.path.join(golden, "med_test.rl_bwt"), ri, encoded=False)
+    r = O.RIndex(ri)
+    idx = P.Index(ri, mode=P.MODE_STRICT)
+    inf = idx.info()
+    assert inf.max_length == r.max_length and inf.n_samples == r.L.orc_ri_samples_size(r.h)
+    emu = E.LocateEmu(idx)
+    sa = [int(v) for v in r.decompress_sa()]
+    assert emu.locate(0, r.n - 1) == sa
+    rng = np.random.default_rng(9)
+    for _ in range(100):
+        a = int(rng.integers(0, r.n))
+        b = min(r.n - 1, a + int(rng.integers(0, 40)))
+        assert emu.locate(a, b) == sa[a:b + 1]
+    for v in sa[:-1][:: max(1, len(sa) // 200)]:
+        assert emu.locate_next(v) == r.locate_next(v)
+    # undefined inputs are defined the same way on both sides
+    assert emu.locate_next(sa[-1]) == r.locate_next(sa[-1])
+    assert emu.locate_next(E.LocateEmu.NO) == O.NO_POSITION
