@@ -249,6 +249,9 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     bool pend = false;
     uint64_t rnext = 0, rend = 0;    // wave-uniform reservoir of read ids
     bool exhausted = false;          // wave-uniform: the global cursor has passed n_reads
+#ifdef PGX_FM_STATS
+    unsigned long long st_trips = 0, st_live = 0; // diagnostics build only (scripts/fm_stats.sh)
+#endif
 
     // begin(x): entry of find_mems_function; finishing a read records its MEM count
     auto begin = [&]() {
@@ -309,6 +312,10 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
         // ---- one block decode for every live lane: an extension whose second probe falls outside the block
         //      of the first takes two trips of this loop (pend = 1 in between), so no lane ever waits for
         //      another lane's second trip ----
+#ifdef PGX_FM_STATS
+        st_trips++;
+        st_live += (unsigned long long)__popcll(__ballot(ph > 0));
+#endif
         if (ph > 0) {
             uint32_t byte = 0u; // pattern[len] reads as 0 (quirk 4)
             if (j < len) {
@@ -386,6 +393,9 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
     if (lane == 0 && tot) atomicAdd(n_ext_total, tot);
+#ifdef PGX_FM_STATS // wave trips, live lane-trips, longest wave (slots 3, 6, 7 of the counters; stats runs are made without tags)
+    if (lane == 0) { atomicAdd(n_ext_total + 6, st_trips); atomicAdd(n_ext_total + 7, st_live); atomicMax(n_ext_total + 3, st_trips); }
+#endif
 }
 
 template __global__ void pgx_find_mems_kernel<false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,

@@ -718,6 +718,10 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, PGX_FM_THREADS, b->dimg->lds_bytes));
         HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
         if (occ < 1) occ = 1;
+        if (const char *e = std::getenv("PGX_FM_WG_PER_CU")) { // experiments: fewer resident workgroups per CU
+            const int v = std::atoi(e);
+            if (v >= 1 && v < occ) occ = v;
+        }
     }
     unsigned long long *d_cursor = d_next + 5; // counters: [0] extensions [1] tag overflows [2] big [3] large [4] max large [5] read cursor
     for (size_t ci = 0; ci < chunks.size(); ci++) {
@@ -775,9 +779,12 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         b->ran_tags = true;
     }
     record(b, 7, s);
-    unsigned long long cnt[2] = {0, 0};
-    HIPCHECK(hipMemcpyAsync(cnt, b->counters.p, 16, hipMemcpyDeviceToHost, s));
+    unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHECK(hipMemcpyAsync(cnt, b->counters.p, 64, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
+    if (cnt[6] && std::getenv("PGX_FM_STATS")) // only a -DPGX_FM_STATS build of the kernels fills these (scripts/fm_stats.sh)
+        std::fprintf(stderr, "[pgx] find_mems wave trips %llu, live lane-trips %llu (%.1f%% of lanes), longest wave %llu trips, extensions %llu\n", cnt[6], cnt[7],
+                     100.0 * (double)cnt[7] / (64.0 * (double)cnt[6]), cnt[3], cnt[0]);
     b->n_ext = cnt[0];
     b->n_tag_overflow = cnt[1];
     if (b->timed) {
