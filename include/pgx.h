@@ -37,6 +37,11 @@ typedef enum {
 /* mode: which extension tables are loaded into the device image (same kernels either way) */
 #define PGX_MODE_COMPAT 0u /* bit-exact with the reference, quirks included (default)          */
 #define PGX_MODE_STRICT 1u /* textbook FMD over the true ranks; equals COMPAT on sigma=6 indexes */
+/* optional bits or-ed into `mode`: force the layout of the device rank image (default: chosen from the index size;
+ * results never depend on it).  PGX_ERR_UNSUPPORTED if dense is forced on a legacy-layout index without N in COMPAT. */
+#define PGX_MODE_IMAGE_RL 0x100u    /* run-length blocks + directory (any size)                     */
+#define PGX_MODE_IMAGE_DENSE 0x200u /* uncompressed bit planes, n bytes of device memory             */
+#define PGX_MODE_MASK 0xFFu
 
 /* tag file formats (SURVEY section 5 "Tag formats") */
 #define PGX_TAGS_AUTO 0u
@@ -84,6 +89,8 @@ typedef struct {
     double ref_block_mean_bytes; /* mean encoded block size of the reference layout (B_blk) */
     uint64_t max_length;    /* Header::max_length: packed position = seq * max_length + offset (r-index.hpp:424) */
     uint64_t n_samples;     /* samples.size() = runs in the reference's numbering */
+    uint32_t image_kind;    /* 0 = run-length blocks + directory, 1 = dense bit planes (64 symbols per 64-byte block) */
+    uint32_t reserved0;
 } pgx_index_info;
 
 const char *pgx_last_error(void);

@@ -26,9 +26,10 @@ struct PgxDevImage {
     uint32_t dir_shift;
     uint32_t excl_mask;
     uint32_t tag_dir_shift;
+    uint32_t dense; // 1: blocks are dense bit-plane blocks (PGX_IMAGE_DENSE), dir / blow unused
 };
 
-template <bool LDS_IMAGE>
+template <bool LDS_IMAGE, bool DENSE>
 __global__ void pgx_find_mems_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
                                      uint64_t min_len, uint64_t min_occ, const uint64_t *slot_off, pgx_mem *slots,
                                      uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor, uint64_t slot_base);

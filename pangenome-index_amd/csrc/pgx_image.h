@@ -23,6 +23,15 @@
  *  block lows  u16 blow[b] = block_start & ((1 << dir_shift) - 1), searched only when cnt > 2
  *              (dir_shift <= 12 so that a low part fits the 12-bit fields)
  *
+ *  DENSE rank image (image_kind = PGX_IMAGE_DENSE): for indexes whose BWT is short enough to be stored uncompressed
+ *  (64 bytes per 64 symbols = n bytes), the BWA-style layout: block b covers BWT[64 b, 64 b + 64), no directory:
+ *    dw 0..7   the same six 40-bit counts as above (counts of BWT[0, 64 b))
+ *    dw 8..13  three 64-bit planes: bit i of plane p = bit p of the nuc code of BWT[64 b + i]
+ *  rank = header count + popcounts of plane combinations under a prefix mask; both probes of an extension are two
+ *  independent 64-byte loads (no dependent directory load) and ~40 ALU operations each instead of a 16-entry run scan.
+ *  Not available when a header slot carries the legacy quirk value (excl_mask != 0: blocks must then refine the
+ *  reference's 10-run blocks).  (n >> 6) + 1 blocks, so position n has a block of its own or shares the last one.
+ *
  *  tag image: u64 tstart[r] (first BWT position of tag run r, ascending), u64 tvals[r] (the
  *  graph position the reference prints: node << 11 | rev << 10 | offset), u32 tdir like dir.
  *
@@ -40,6 +49,8 @@
 #define PGX_RUN_LEN_MAX 4095u
 #define PGX_COUNT_BITS 40
 #define PGX_DIR_MAX_SHIFT 12
+#define PGX_IMAGE_RL 0u
+#define PGX_IMAGE_DENSE 1u
 
 /* ext_tab entry (one per byte value and direction): how to extend by that byte */
 #define PGX_EXT_CV(e) ((e) & 7u)            /* nuc code whose rank gives the new interval     */
@@ -69,6 +80,8 @@ typedef struct {
     /* unidirectional backward search (FastLocate::count / count_encoded): per read byte the nuc code
      * ranked (bits 0..2), the C slot (bits 3..5) and a "no match" flag (bit 24) */
     uint32_t cnt_tab[256];
+    uint32_t image_kind;  /* PGX_IMAGE_RL / PGX_IMAGE_DENSE */
+    uint32_t reserved0;
 } PgxConsts;
 
 /* locate image (FastLocate::locate / locateNext / decompressSA, src/r-index.cpp:1252-1366): three sorted

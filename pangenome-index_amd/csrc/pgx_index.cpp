@@ -6,6 +6,7 @@
 // flat image of pgx_image.h.  No query arithmetic lives here.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <memory>
 
 #include "pgx_host.hpp"
@@ -310,13 +311,85 @@ static void put_block(std::vector<uint8_t> &blocks, const uint64_t c6[6], const 
     blocks.insert(blocks.end(), p, p + PGX_BLOCK_BYTES);
 }
 
-void build_rank_image(const RiFile &ri, uint32_t mode, HostImage &img) {
+// dense image: 64 symbols per 64-byte block as three bit planes under the usual count header (pgx_image.h)
+static void build_dense_image(const RiFile &ri, HostImage &img) {
+    PgxConsts &c = img.consts;
+    const uint64_t nb = (c.n >> 6) + 1;
+    if (nb >> 32) throw Error(PGX_ERR_UNSUPPORTED, "BWT too long for the dense image");
+    img.blocks.assign(nb * PGX_BLOCK_BYTES, 0);
+    img.bstart.clear();
+    img.dir.assign(1, 0);
+    img.blow.clear();
+    uint32_t *dw = reinterpret_cast<uint32_t *>(img.blocks.data());
+    uint64_t c6[6] = {0, 0, 0, 0, 0, 0};
+    auto put_header = [&](uint64_t b) {
+        uint32_t *h = dw + b * 16;
+        for (int i = 0; i < 6; i++) h[i] = (uint32_t)c6[i];
+        for (int i = 0; i < 4; i++) h[6] |= (uint32_t)((c6[i] >> 32) & 0xFF) << (8 * i);
+        h[7] = (uint32_t)((c6[4] >> 32) & 0xFF) | ((uint32_t)((c6[5] >> 32) & 0xFF) << 8);
+    };
+    uint64_t pos = 0, n_runs = 0;
+    put_header(0);
+    for (const auto &blk : ri.blocks)
+        for (const auto &ru : blk.runs) {
+            n_runs++;
+            const uint32_t code = ru.first;
+            uint64_t left = ru.second;
+            while (left) {
+                const uint64_t b = pos >> 6;
+                const uint32_t off = (uint32_t)(pos & 63);
+                const uint64_t take = std::min<uint64_t>(left, 64 - off);
+                const uint64_t bits = (take == 64 ? ~0ull : ((1ull << take) - 1ull)) << off;
+                uint32_t *h = dw + b * 16;
+                for (int p = 0; p < 3; p++)
+                    if ((code >> p) & 1u) {
+                        h[8 + 2 * p] |= (uint32_t)bits;
+                        h[9 + 2 * p] |= (uint32_t)(bits >> 32);
+                    }
+                c6[code] += take;
+                left -= take;
+                pos += take;
+                if ((pos & 63) == 0) put_header(pos >> 6);
+            }
+        }
+    if (pos != c.n) throw Error(PGX_ERR_FORMAT, "FastLocate: run lengths do not add up to the BWT size");
+    img.n_runs = n_runs;
+    c.n_blocks = (uint32_t)nb;
+    c.dir_shift = 0;
+    c.dir_entries = 1;
+    c.image_kind = PGX_IMAGE_DENSE;
+}
+
+// layout of the device rank image: dense bit planes when that costs little memory or the run-length image would
+// not stay cache resident either; PGX_MODE_IMAGE_* / the environment variable PGX_IMAGE force one
+static bool choose_dense(const RiFile &ri, uint32_t mode_bits, const PgxConsts &c) {
+    const bool can = c.excl_mask == 0;
+    uint32_t force = mode_bits & (PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE);
+    if (!force)
+        if (const char *e = std::getenv("PGX_IMAGE")) force = std::string(e) == "dense" ? PGX_MODE_IMAGE_DENSE : std::string(e) == "rl" ? PGX_MODE_IMAGE_RL : 0u;
+    if (force == (PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE)) throw Error(PGX_ERR_ARG, "pgx_index_open: both image layouts forced");
+    if (force & PGX_MODE_IMAGE_DENSE) {
+        if (!can) throw Error(PGX_ERR_UNSUPPORTED, "dense image: not available for a legacy-layout index without N in COMPAT mode");
+        return true;
+    }
+    if ((force & PGX_MODE_IMAGE_RL) || !can) return false;
+    uint64_t runs = 0;
+    for (const auto &b : ri.blocks) runs += b.runs.size();
+    const uint64_t dense_bytes = ((c.n >> 6) + 1) * PGX_BLOCK_BYTES, rl_bytes = (runs / PGX_BLOCK_RUNS + 1) * (PGX_BLOCK_BYTES + 4);
+    const uint64_t cache = 192ull << 20; // stays resident in the 256 MB memory-side cache next to reads and tags
+    if (dense_bytes <= cache) return true;
+    return rl_bytes > cache && dense_bytes <= (64ull << 30);
+}
+
+void build_rank_image(const RiFile &ri, uint32_t mode_bits, HostImage &img) {
+    const uint32_t mode = mode_bits & PGX_MODE_MASK;
     PgxConsts &c = img.consts;
     std::memset(&c, 0, sizeof c);
     c.n = ri.sequence_size;
     c.mode = mode;
     build_ext_tables(ri, mode, c);
     build_count_table(ri, mode, c);
+    if (choose_dense(ri, mode_bits, c)) { build_dense_image(ri, img); return; }
     // Device blocks must refine the reference's blocks only when a header slot carries the
     // reference-block cumulative endmarker count (legacy layout, absent symbol, COMPAT).
     const bool refine = c.excl_mask != 0;
@@ -502,10 +575,11 @@ extern "C" int pgx_abi_version(void) { return PGX_ABI_VERSION; }
 void pgx_release_device_images(pgx_index *h); // pgx_runtime.hip
 
 static pgx_index *open_impl(const uint8_t *ri, uint64_t ri_n, const uint8_t *tags, uint64_t tags_n, uint32_t tags_format, uint32_t mode) {
-    if (mode != PGX_MODE_COMPAT && mode != PGX_MODE_STRICT) throw Error(PGX_ERR_ARG, "pgx_index_open: bad mode");
+    if ((mode & PGX_MODE_MASK) > PGX_MODE_STRICT || (mode & ~(PGX_MODE_MASK | PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE)))
+        throw Error(PGX_ERR_ARG, "pgx_index_open: bad mode");
     if (!ri && !tags) throw Error(PGX_ERR_ARG, "pgx_index_open: neither an r-index nor a tag array given");
     std::unique_ptr<pgx_index> h(new pgx_index());
-    h->mode = mode;
+    h->mode = mode & PGX_MODE_MASK;
     std::memset(&h->img.consts, 0, sizeof h->img.consts);
     if (ri) {
         h->ri.parse(ri, ri_n);
@@ -524,7 +598,8 @@ extern "C" pgx_status pgx_index_open(const char *ri_path, const char *tags_path,
                                      uint32_t mode, pgx_index **out) {
     PGX_GUARD_BEGIN
     if (!ri_path || !out) throw Error(PGX_ERR_ARG, "pgx_index_open: null argument");
-    if (mode != PGX_MODE_COMPAT && mode != PGX_MODE_STRICT) throw Error(PGX_ERR_ARG, "pgx_index_open: bad mode");
+    if ((mode & PGX_MODE_MASK) > PGX_MODE_STRICT || (mode & ~(PGX_MODE_MASK | PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE)))
+        throw Error(PGX_ERR_ARG, "pgx_index_open: bad mode");
     *out = nullptr;
     std::vector<uint8_t> f, t;
     try { f = read_whole_file(ri_path); }
@@ -588,6 +663,7 @@ extern "C" pgx_status pgx_index_info_get(const pgx_index *h, pgx_index_info *inf
     info->ref_block_mean_bytes = h->ri.ref_block_mean_bytes;
     info->max_length = h->ri.max_length;
     info->n_samples = h->ri.samples.size();
+    info->image_kind = c.image_kind;
     return PGX_OK;
     PGX_GUARD_END
 }

@@ -40,6 +40,61 @@ __device__ __forceinline__ uint32_t pgx_find_block(const PgxDevImage &img, const
 }
 
 // ------------------------------------------------------------------------------------------
+// DENSE image (pgx_image.h): block = pos >> 6, three 64-bit planes of code bits under the same count header.
+// A dense block in registers: header dwords 0..7 and plane dwords 8..13.
+struct PgxDenseBlk {
+    uint4 h0, h1, p01; // p01 = plane0.lo, plane0.hi, plane1.lo, plane1.hi
+    uint2 p2;
+};
+
+template <bool LDS_IMAGE>
+__device__ __forceinline__ PgxDenseBlk pgx_dense_load(const PgxDevImage &img, const uint4 *__restrict__ lds_blocks, uint64_t pos) {
+    const uint4 *bp = (LDS_IMAGE ? lds_blocks : img.blocks) + (size_t)(pos >> 6) * 4;
+    PgxDenseBlk b;
+    b.h0 = bp[0]; b.h1 = bp[1]; b.p01 = bp[2];
+    b.p2 = *reinterpret_cast<const uint2 *>(bp + 3);
+    return b;
+}
+
+// rank sums at pos from its (loaded) block: A = count of code cv, B = sum over codes of mult[code] * count(code)
+__device__ __forceinline__ void pgx_dense_rank(const PgxDenseBlk &blk, uint64_t pos, uint32_t cv, uint32_t mrow, uint64_t &A, uint64_t &B) {
+    const uint4 h0 = blk.h0, h1 = blk.h1;
+    uint64_t c[6];
+    c[0] = (uint64_t)h0.x | ((uint64_t)(h1.z & 0xFFu) << 32);
+    c[1] = (uint64_t)h0.y | ((uint64_t)((h1.z >> 8) & 0xFFu) << 32);
+    c[2] = (uint64_t)h0.z | ((uint64_t)((h1.z >> 16) & 0xFFu) << 32);
+    c[3] = (uint64_t)h0.w | ((uint64_t)(h1.z >> 24) << 32);
+    c[4] = (uint64_t)h1.x | ((uint64_t)(h1.w & 0xFFu) << 32);
+    c[5] = (uint64_t)h1.y | ((uint64_t)((h1.w >> 8) & 0xFFu) << 32);
+    const uint32_t rel = (uint32_t)pos & 63u;
+    // prefix mask of rel bits, as two dwords
+    const uint32_t mlo = rel >= 32u ? 0xFFFFFFFFu : ((1u << rel) - 1u);
+    const uint32_t mhi = rel > 32u ? ((1u << (rel - 32u)) - 1u) : 0u;
+    const uint32_t a0 = blk.p01.x & mlo, a1 = blk.p01.y & mhi; // code bit 0
+    const uint32_t b0 = blk.p01.z & mlo, b1 = blk.p01.w & mhi; // code bit 1
+    const uint32_t d0 = blk.p2.x & mlo, d1 = blk.p2.y & mhi;   // code bit 2
+    const uint32_t n1 = __popc(a0) + __popc(a1), n2 = __popc(b0) + __popc(b1), n4 = __popc(d0) + __popc(d1);
+    const uint32_t n3 = __popc(a0 & b0) + __popc(a1 & b1); // code 3 = 011
+    const uint32_t n5 = __popc(a0 & d0) + __popc(a1 & d1); // code 5 = 101  (codes 6, 7 never occur)
+    uint32_t t[6];
+    t[3] = n3; t[5] = n5;
+    t[1] = n1 - n3 - n5; t[2] = n2 - n3; t[4] = n4 - n5;
+    t[0] = rel - (n1 + n2 + n4 - n3 - n5);
+    uint64_t a = 0, b = 0;
+    uint32_t ia = 0, ib = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        a = (cv == (uint32_t)i) ? c[i] : a;
+        ia = (cv == (uint32_t)i) ? t[i] : ia;
+        const uint32_t w = (mrow >> (3 * i)) & 7u;
+        b += c[i] * (uint64_t)w;
+        ib += t[i] * w;
+    }
+    A = a + ia;
+    B = b + ib;
+}
+
+// ------------------------------------------------------------------------------------------
 // rank probe: A = count of code `cv` in BWT[0,pos), B = sum over codes of mult[code] * count(code)
 // (both modulo 2^64; only differences of two probes are ever used).
 template <bool LDS_IMAGE>
@@ -47,6 +102,10 @@ __device__ __forceinline__ void pgx_rank_ab(const PgxDevImage &img, const uint4 
                                             const uint64_t *__restrict__ lds_dir, const uint16_t *__restrict__ lds_blow,
                                             uint64_t pos, uint32_t cv, uint32_t mrow, uint64_t &A, uint64_t &B) {
     if (pos > img.n) pos = img.n; // predecessor(pos >= size) = last block, rel past the end = totals
+    if (img.dense) {
+        pgx_dense_rank(pgx_dense_load<LDS_IMAGE>(img, lds_blocks, pos), pos, cv, mrow, A, B);
+        return;
+    }
     const uint32_t lo = pgx_find_block<LDS_IMAGE>(img, lds_dir, lds_blow, pos);
     const uint4 *bp = (LDS_IMAGE ? lds_blocks : img.blocks) + (size_t)lo * 4;
     const uint4 h0 = bp[0], h1 = bp[1], r0 = bp[2], r1 = bp[3];
@@ -144,13 +203,20 @@ __device__ __forceinline__ void pgx_probe(const PgxDevImage &img, const uint4 *_
 // The two rank probes of one extension, rank(pos0) and rank(pos1) with pos1 = pos0 + s, as at most two
 // trips of pgx_probe in a rolled loop (the decode exists once in the instruction stream).
 // Outputs A0, A1 and B1 - B0.  (Used by the primitives; the find_mems kernel schedules trips itself.)
-template <bool LDS_IMAGE>
+template <bool LDS_IMAGE, bool MAYBE_DENSE = true>
 __device__ __forceinline__ void pgx_rank_pair(const PgxDevImage &img, const uint4 *__restrict__ lds_blocks,
                                               const uint64_t *__restrict__ lds_dir, const uint16_t *__restrict__ lds_blow,
                                               uint64_t pos0, uint64_t pos1, uint32_t cv, uint32_t mrow, uint64_t &A0,
                                               uint64_t &A1, uint64_t &dB) {
     const uint64_t p0 = pos0 > img.n ? img.n : pos0, p1 = pos1 > img.n ? img.n : pos1;
     uint64_t B0 = 0, B1 = 0;
+    if (MAYBE_DENSE && img.dense) { // two independent block loads, no directory
+        const PgxDenseBlk k0 = pgx_dense_load<LDS_IMAGE>(img, lds_blocks, p0), k1 = pgx_dense_load<LDS_IMAGE>(img, lds_blocks, p1);
+        pgx_dense_rank(k0, p0, cv, mrow, A0, B0);
+        pgx_dense_rank(k1, p1, cv, mrow, A1, B1);
+        dB = B1 - B0;
+        return;
+    }
     A0 = 0; A1 = 0;
     bool done = false;
 #pragma unroll 1
@@ -200,7 +266,8 @@ __device__ __forceinline__ void pgx_stage_tables(const PgxDevImage &img, uint32_
         const uint32_t nb4 = img.n_blocks * 4;
         for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) lds_blocks[i] = img.blocks[i];
         for (uint64_t i = threadIdx.x; i < img.dir_entries; i += blockDim.x) lds_dir[i] = img.dir[i];
-        for (uint32_t i = threadIdx.x; i < img.n_blocks; i += blockDim.x) lds_blow[i] = img.blow[i];
+        if (!img.dense)
+            for (uint32_t i = threadIdx.x; i < img.n_blocks; i += blockDim.x) lds_blow[i] = img.blow[i];
     }
     __syncthreads();
 }
@@ -226,7 +293,7 @@ __device__ __forceinline__ void pgx_stage_tables(const PgxDevImage &img, uint32_
 // (ballot + prefix popcount).  Every wave leaves the loop once the cursor has passed n_reads and
 // all its lanes are idle.  MEMs go to per-read slots, so the output does not depend on scheduling.
 #define PGX_FM_BATCH 128u
-template <bool LDS_IMAGE>
+template <bool LDS_IMAGE, bool DENSE>
 __global__ void __launch_bounds__(PGX_FM_THREADS, PGX_FM_WAVES_PER_SIMD)
 pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                      uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
@@ -334,10 +401,20 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
             const uint64_t kk = fwd ? kp : k, kq = fwd ? k : kp;
             bool fin;
             uint64_t A1, dB;
-            if (LDS_IMAGE) {
+            if (DENSE) {
+                // dense image: the two block addresses are known at once (pos >> 6), so both 64-byte loads are in flight
+                // together and every extension is a single trip
+                const uint64_t p0 = kk > n ? n : kk, p1 = (kk + s) > n ? n : (kk + s);
+                const PgxDenseBlk k0 = pgx_dense_load<LDS_IMAGE>(img, lds_blocks, p0), k1 = pgx_dense_load<LDS_IMAGE>(img, lds_blocks, p1);
+                uint64_t Bq0, Bq1;
+                pgx_dense_rank(k0, p0, cv, mrow, A0, Bq0);
+                pgx_dense_rank(k1, p1, cv, mrow, A1, Bq1);
+                dB = Bq1 - Bq0;
+                fin = true;
+            } else if (LDS_IMAGE) {
                 // image in LDS: no memory latency to hide and most extensions of a tiny index need both blocks,
                 // so both trips run back to back (measured 6 % faster than the one-trip-per-iteration form)
-                pgx_rank_pair<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, kk, kk + s, cv, mrow, A0, A1, dB);
+                pgx_rank_pair<LDS_IMAGE, false>(img, lds_blocks, lds_dir, lds_blow, kk, kk + s, cv, mrow, A0, A1, dB);
                 fin = true;
             } else {
                 const uint64_t p0 = kk > n ? n : kk, p1 = (kk + s) > n ? n : (kk + s);
@@ -398,10 +475,14 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
 #endif
 }
 
-template __global__ void pgx_find_mems_kernel<false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                     const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t);
-template __global__ void pgx_find_mems_kernel<true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                    const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t);
+template __global__ void pgx_find_mems_kernel<false, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t);
+template __global__ void pgx_find_mems_kernel<false, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t);
+template __global__ void pgx_find_mems_kernel<true, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t);
+template __global__ void pgx_find_mems_kernel<true, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t);
 
 // ------------------------------------------------------------------------------------------
 // primitives for tests (mirror rank_at_cached_encoded / backward_extend_encoded / forward_...)
@@ -558,7 +639,8 @@ pgx_count_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint6
         const uint32_t nb4 = img.n_blocks * 4;
         for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) lds_blocks[i] = img.blocks[i];
         for (uint64_t i = threadIdx.x; i < img.dir_entries; i += blockDim.x) lds_dir[i] = img.dir[i];
-        for (uint32_t i = threadIdx.x; i < img.n_blocks; i += blockDim.x) lds_blow[i] = img.blow[i];
+        if (!img.dense)
+            for (uint32_t i = threadIdx.x; i < img.n_blocks; i += blockDim.x) lds_blow[i] = img.blow[i];
     }
     __syncthreads();
     const uint64_t rid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

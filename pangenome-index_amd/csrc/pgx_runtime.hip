@@ -177,6 +177,7 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
     g.dir_shift = m.consts.dir_shift;
     g.excl_mask = m.consts.excl_mask;
     g.tag_dir_shift = m.consts.tag_dir_shift;
+    g.dense = m.consts.image_kind == PGX_IMAGE_DENSE ? 1u : 0u;
     size_t img_bytes = m.blocks.size() + m.dir.size() * 8 + m.blow.size() * 2;
     d->lds_bytes = img_bytes <= 48 * 1024 ? ((img_bytes + 15) & ~(size_t)15) : 0;
     h->dev[device] = d.release();
@@ -711,10 +712,13 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     float ms_fm = 0, ms_cp = 0;
     uint64_t mem_base = 0;
     int occ = 0, cus = 0;
+    const void *kfn = nullptr;
     if (n) {
         // persistent grid: as many workgroups as the device keeps resident (no inter-workgroup
         // dependency exists, so any grid size is correct; this one avoids a tail of late blocks)
-        const void *kfn = b->dimg->lds_bytes ? (const void *)pgx_find_mems_kernel<true> : (const void *)pgx_find_mems_kernel<false>;
+        const bool in_lds = b->dimg->lds_bytes != 0, dense = img.dense != 0;
+        kfn = in_lds ? (dense ? (const void *)pgx_find_mems_kernel<true, true> : (const void *)pgx_find_mems_kernel<true, false>)
+                     : (dense ? (const void *)pgx_find_mems_kernel<false, true> : (const void *)pgx_find_mems_kernel<false, false>);
         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, PGX_FM_THREADS, b->dimg->lds_bytes));
         HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
         if (occ < 1) occ = 1;
@@ -732,14 +736,17 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         record(b, 1, s);
         unsigned grid = grid_for(cn, 64);
         if (grid > (unsigned)(occ * cus)) grid = (unsigned)(occ * cus);
-        if (b->dimg->lds_bytes)
-            hipLaunchKernelGGL(pgx_find_mems_kernel<true>, dim3(grid), dim3(PGX_FM_THREADS), b->dimg->lds_bytes, s, img,
-                               b->reads.as<uint8_t>(), b->offsets.as<uint64_t>(), c.r1, min_len, min_occ, b->slot_off.as<uint64_t>(),
-                               b->slots.as<pgx_mem>(), b->mem_count.as<uint32_t>(), d_next, d_cursor, c.slot_base);
-        else
-            hipLaunchKernelGGL(pgx_find_mems_kernel<false>, dim3(grid), dim3(PGX_FM_THREADS), 0, s, img, b->reads.as<uint8_t>(),
-                               b->offsets.as<uint64_t>(), c.r1, min_len, min_occ, b->slot_off.as<uint64_t>(), b->slots.as<pgx_mem>(),
-                               b->mem_count.as<uint32_t>(), d_next, d_cursor, c.slot_base);
+        {
+            const uint8_t *a_reads = b->reads.as<uint8_t>();
+            const uint64_t *a_off = b->offsets.as<uint64_t>(), *a_slot_off = b->slot_off.as<uint64_t>();
+            uint64_t a_n = c.r1, a_min_len = min_len, a_min_occ = min_occ, a_base = c.slot_base;
+            pgx_mem *a_slots = b->slots.as<pgx_mem>();
+            uint32_t *a_cnt = b->mem_count.as<uint32_t>();
+            unsigned long long *a_next = d_next, *a_cur = d_cursor;
+            PgxDevImage a_img = img;
+            void *args[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_base};
+            HIPCHECK(hipLaunchKernel(kfn, dim3(grid), dim3(PGX_FM_THREADS), args, b->dimg->lds_bytes, s)); // one of the four variants
+        }
         HIPCHECK(hipGetLastError());
         b->timing.find_mems_launches++;
         record(b, 2, s);

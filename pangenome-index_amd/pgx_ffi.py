@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(PKG_DIR, "libpgx.so")
 
 OK, ERR_IO, ERR_FORMAT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_ARG, ERR_NOMEM = range(8)
 MODE_COMPAT, MODE_STRICT = 0, 1
+MODE_IMAGE_RL, MODE_IMAGE_DENSE = 0x100, 0x200  # or-ed into mode: force the layout of the device rank image
+IMAGE_RL, IMAGE_DENSE = 0, 1
 TAGS_AUTO, TAGS_BYTECODE, TAGS_COMPACT = 0, 1, 2
 RUN_TAGS, RUN_TIMING = 1, 2
 
@@ -30,7 +32,7 @@ class IndexInfo(C.Structure):
         ("n_dev_blocks", u64), ("dir_entries", u64), ("dir_shift", u32), ("is_encoded", u32), ("has_N", u32),
         ("mode", u32), ("has_tags", u32), ("tag_format", u32), ("n_tag_runs", u64), ("tag_dir_entries", u64),
         ("tag_dir_shift", u32), ("image_in_lds", u32), ("image_bytes", u64), ("tag_image_bytes", u64),
-        ("ref_block_mean_bytes", C.c_double), ("max_length", u64), ("n_samples", u64),
+        ("ref_block_mean_bytes", C.c_double), ("max_length", u64), ("n_samples", u64), ("image_kind", u32), ("reserved0", u32),
     ]
 
 

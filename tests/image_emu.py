@@ -27,6 +27,7 @@ class Consts:
         self.n_tag_runs, self.tag_dir_entries = struct.unpack_from("<2Q", raw, o); o += 16
         self.tag_dir_shift, self.has_tags, self.mode, self.count_supported = struct.unpack_from("<4I", raw, o); o += 16
         self.cnt_tab = struct.unpack_from("<256I", raw, o); o += 1024
+        self.image_kind, _ = struct.unpack_from("<2I", raw, o); o += 8
         assert o == len(raw), (o, len(raw))
 
 
@@ -74,9 +75,30 @@ class ImageEmu:
         assert int(self.bstart[b]) <= pos and (b + 1 == c.n_blocks or pos < int(self.bstart[b + 1])), (pos, b)
         return b
 
+    def dense_rank(self, pos, cv, mrow):
+        """pgx_dense_rank: header counts + popcounts of plane combinations under a prefix mask"""
+        dw = [int(x) for x in self.blocks[pos >> 6]]
+        cnt = [dw[i] for i in range(6)]
+        for i in range(4):
+            cnt[i] |= ((dw[6] >> (8 * i)) & 0xFF) << 32
+        cnt[4] |= (dw[7] & 0xFF) << 32
+        cnt[5] |= ((dw[7] >> 8) & 0xFF) << 32
+        rel = pos & 63
+        m = (1 << rel) - 1
+        p = [(dw[8 + 2 * i] | (dw[9 + 2 * i] << 32)) & m for i in range(3)]
+        pc = lambda v: bin(v).count("1")
+        n1, n2, n4, n3, n5 = pc(p[0]), pc(p[1]), pc(p[2]), pc(p[0] & p[1]), pc(p[0] & p[2])
+        assert pc(p[1] & p[2]) == 0  # codes 6, 7 never occur
+        t = [rel - (n1 + n2 + n4 - n3 - n5), n1 - n3 - n5, n2 - n3, n3, n4 - n5, n5]
+        A = cnt[cv] + t[cv]
+        B = sum((cnt[i] + t[i]) * ((mrow >> (3 * i)) & 7) for i in range(6))
+        return A & M64, B & M64
+
     def rank_ab(self, pos, cv, mrow):
         c = self.c
         pos = min(pos, c.n)
+        if c.image_kind == 1:
+            return self.dense_rank(pos, cv, mrow)
         b = self.find_block(pos)
         cnt, ents, _ = self.block_counts(b)
         start = sum(cnt[i] for i in range(6) if not (c.excl_mask >> i) & 1)
@@ -97,6 +119,9 @@ class ImageEmu:
         """pgx_rank_pair: a two-trip loop; trip 0 decodes pos0's block and serves pos1 too when it covers it"""
         c = self.c
         p0, p1 = min(pos0, c.n), min(pos1, c.n)
+        if c.image_kind == 1:
+            (A0, B0), (A1, B1) = self.dense_rank(p0, cv, mrow), self.dense_rank(p1, cv, mrow)
+            return A0, A1, (B1 - B0) & M64
         A0 = A1 = B0 = B1 = 0
         done = False
         for it in (0, 1):

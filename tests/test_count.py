@@ -56,13 +56,13 @@ def test_count_tables_cpu(workdir):
     for ri_path, text_path, modes in _cases(workdir):
         text = open(text_path).read()
         ri = O.RIndex(ri_path)
-        for mode in (0, 1):
-            idx = P.Index(ri_path, mode=mode)
+        for mode, force in ((0, 0), (1, 0), (0, P.MODE_IMAGE_RL), (1, P.MODE_IMAGE_RL)):  # automatic layout (dense where possible), and RL
+            idx = P.Index(ri_path, mode=mode | force)
             emu = ImageEmu(idx)
             assert bool(emu.c.count_supported) == (mode in modes)
             if mode not in modes:
                 continue
-            for p in _patterns(text, rng, 120):
+            for p in _patterns(text, rng, 60):
                 exp = ri.count(p, mode)
                 assert emu.count(p) == exp, (ri_path, mode, p)
                 if mode == 1 or ri.sigma == 6 or not ri.encoded:
@@ -88,8 +88,8 @@ def test_count_batch_gpu(workdir):
         ri = O.RIndex(ri_path)
         pats = _patterns(text, rng, 2000)
         cat, offs = O.pack_reads(pats)
-        for mode in (0, 1):
-            idx = P.Index(ri_path, mode=mode)
+        for mode, force in ((0, 0), (1, 0), (0, P.MODE_IMAGE_RL), (1, P.MODE_IMAGE_RL)):
+            idx = P.Index(ri_path, mode=mode | force)
             if mode not in modes:
                 with pytest.raises(P.PgxError) as ex:
                     idx.count_batch(cat, offs)

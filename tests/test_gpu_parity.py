@@ -38,10 +38,13 @@ def xy(xy_paths, built):
     return (P.Index(ri, tags), O.RIndex(ri), O.Tags(tags, O.TAGS_BYTECODE))
 
 
-@pytest.fixture(scope="module")
-def xenc(x_index):
+@pytest.fixture(scope="module", params=["dense", "rl"])
+def xenc(x_index, request):
+    """x index (encoded, no N) under both layouts of the device rank image (dense is the automatic choice at this size)"""
     ri, tags = x_index
-    return (P.Index(ri, tags), O.RIndex(ri), O.Tags(tags, O.TAGS_COMPACT))
+    idx = P.Index(ri, tags, mode=P.MODE_COMPAT | (P.MODE_IMAGE_DENSE if request.param == "dense" else P.MODE_IMAGE_RL))
+    assert idx.info().image_kind == (P.IMAGE_DENSE if request.param == "dense" else P.IMAGE_RL)
+    return (idx, O.RIndex(ri), O.Tags(tags, O.TAGS_COMPACT))
 
 
 def test_device_present(built):
@@ -50,8 +53,8 @@ def test_device_present(built):
 
 
 @pytest.mark.parametrize("which", ["xy", "xenc"])
-def test_rank_all_positions(which, request):
-    idx, ri, _ = request.getfixturevalue(which)
+def test_rank_all_positions(which, xy, xenc):
+    idx, ri, _ = xy if which == "xy" else xenc
     n = ri.n
     pos = np.concatenate([np.arange(0, n + 1, dtype=np.uint64), np.array([n + 1, n + 1000, 2**63], dtype=np.uint64)])
     got = idx.rank_batch(pos)
@@ -67,8 +70,8 @@ def test_rank_all_positions(which, request):
 
 
 @pytest.mark.parametrize("which", ["xy", "xenc"])
-def test_extend_random(which, request):
-    idx, ri, _ = request.getfixturevalue(which)
+def test_extend_random(which, xy, xenc):
+    idx, ri, _ = xy if which == "xy" else xenc
     rng = np.random.default_rng(7)
     n = ri.n
     m = 20000
@@ -157,15 +160,17 @@ def test_synthetic_reads_xy_legacy(xy, golden):
 def test_strict_mode_matches_oracle_strict(x_index, xy_paths, golden):
     for (ri_path, tags_path), fmt, text in [(x_index, O.TAGS_COMPACT, "x.newline_separated"),
                                             (xy_paths, O.TAGS_BYTECODE, "bidirectional_test/contigs_xy")]:
-        idx = P.Index(ri_path, tags_path, mode=P.MODE_STRICT)
         ri, tags = O.RIndex(ri_path), O.Tags(tags_path, fmt)
         seqs = W.load_sequences(os.path.join(golden, text))
         cat, offs = W.sample_reads(seqs, 5000, 100, seed=44)
-        for min_len, min_occ in [(5, 1), (20, 1), (12, 2)]:
-            ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, mode=O.MODE_STRICT, threads=O.lib().orc_max_threads())
-            res = idx.find_mems(cat, offs, min_len, min_occ, tags=True)
-            _assert_same(res, ref, True)
-            assert ref["mem_offsets"][-1] > 0
+        for force in (P.MODE_IMAGE_DENSE, P.MODE_IMAGE_RL):
+            idx = P.Index(ri_path, tags_path, mode=P.MODE_STRICT | force)
+            for min_len, min_occ in [(5, 1), (20, 1), (12, 2)]:
+                ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, mode=O.MODE_STRICT, threads=O.lib().orc_max_threads())
+                res = idx.find_mems(cat, offs, min_len, min_occ, tags=True)
+                _assert_same(res, ref, True)
+                assert ref["mem_offsets"][-1] > 0
+            idx.close()
 
 
 def test_tag_queries_all_sort_paths(xy):

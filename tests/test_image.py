@@ -20,7 +20,10 @@ def _check_rank_and_extend(idx, ri, mode, n_ext=600, step=1):
     c = emu.c
     assert c.n == ri.n and c.sigma == ri.sigma and list(c.C[: ri.sigma]) == ri.C_array()
     # every block: start position = sum of header counts (minus the excluded quirk slots)
-    assert len(emu.bstart) == c.n_blocks and emu.bstart[0] == 0
+    if c.image_kind == P.IMAGE_RL:
+        assert len(emu.bstart) == c.n_blocks and emu.bstart[0] == 0
+    else:
+        assert c.n_blocks == (c.n >> 6) + 1 and len(emu.blocks) == c.n_blocks
     for pos in list(range(0, ri.n + 1, step)) + [ri.n, ri.n + 5, 1 << 62]:
         p = min(pos, ri.n)
         if mode == O.MODE_COMPAT:
@@ -62,13 +65,24 @@ def test_image_xy_legacy_fixture(built, mode):
                                           ("bidirectional_test/small_test/test.rl_bwt", True),
                                           ("bidirectional_test/small_test/test.rl_bwt", False),
                                           ("two_contig_graph/contigs_XY.rl_bwt", True)])
-def test_image_built_indexes(workdir, name, encoded, mode):
+@pytest.mark.parametrize("image", [P.IMAGE_RL, P.IMAGE_DENSE])
+def test_image_built_indexes(workdir, name, encoded, mode, image):
     ri_path, _ = W.build_index_from_rlbwt(os.path.join(G, name), workdir, "img_" + os.path.basename(name), encoded=encoded,
                                           with_tags=False)
-    idx = P.Index(ri_path, mode=mode)
     ri = O.RIndex(ri_path)
-    assert bool(idx.info().is_encoded) == encoded
-    _check_rank_and_extend(idx, ri, mode, n_ext=300, step=2)
+    force = P.MODE_IMAGE_DENSE if image == P.IMAGE_DENSE else P.MODE_IMAGE_RL
+    if image == P.IMAGE_DENSE and mode == O.MODE_COMPAT and not encoded and not ri.has_N and ri.sigma == 5:
+        # legacy layout without N in COMPAT: a header slot carries the reference-block quirk value, so the device blocks
+        # must refine the reference's blocks -- no dense image there
+        with pytest.raises(P.PgxError) as e:
+            P.Index(ri_path, mode=mode | force)
+        assert e.value.code == P.ERR_UNSUPPORTED
+        return
+    idx = P.Index(ri_path, mode=mode | force)
+    assert bool(idx.info().is_encoded) == encoded and idx.info().image_kind == image and idx.info().mode == mode
+    emu = _check_rank_and_extend(idx, ri, mode, n_ext=300, step=2)
+    for rd in ["ACCCTAGAGTAT", "GATTAGATACAT", "TTTTGGAGGAGTNNA", ""]:
+        assert emu.find_all_mems(rd, 3, 1) == ri.find_all_mems(rd, 3, 1, mode, with_ext=True), rd
 
 
 def test_image_reference_two_contig_fixture(built):
@@ -92,8 +106,8 @@ def test_long_runs_split_and_merge(workdir):
     assert int(lens.max()) > 60000
     ri_path = os.path.join(workdir, "long.ri")
     P.build_rindex(rl, ri_path, True)
-    idx, ri = P.Index(ri_path), O.RIndex(ri_path)
-    assert ri.sigma == 6 and ri.has_N
+    idx, ri = P.Index(ri_path, mode=P.MODE_IMAGE_RL), O.RIndex(ri_path)
+    assert ri.sigma == 6 and ri.has_N and idx.info().image_kind == P.IMAGE_RL
     emu = ImageEmu(idx)
     n = ri.n
     rng = np.random.default_rng(9)
@@ -107,6 +121,28 @@ def test_long_runs_split_and_merge(workdir):
         if exp is not None:
             assert tri[2] == exp, p
         assert emu.count(p) == ri.count(p)
+    # the same index as dense bit planes (the automatic choice at this size)
+    idx2 = P.Index(ri_path)
+    assert idx2.info().image_kind == P.IMAGE_DENSE
+    emu2 = ImageEmu(idx2)
+    for pos in [0, 1, 63, 64, 65, 69999, 70000, n - 1, n, n + 7] + [int(v) for v in rng.integers(0, n, 300)]:
+        assert emu2.rank6_true(pos) == ri.rank6_true(min(pos, n))
+    for p in ["A" * 100, "GACGT", "TTTTTG"]:
+        assert emu2.count(p) == ri.count(p)
+
+
+def test_image_layout_choice(workdir, built):
+    """automatic layout: dense while the BWT is small, never on the legacy-quirk header, overridable"""
+    xy = os.path.join(BT, "xy.ri")
+    assert P.Index(xy).info().image_kind == P.IMAGE_RL            # legacy, no N, COMPAT: quirk slot in the header
+    assert P.Index(xy, mode=P.MODE_STRICT).info().image_kind == P.IMAGE_DENSE
+    assert P.Index(xy, mode=P.MODE_STRICT | P.MODE_IMAGE_RL).info().image_kind == P.IMAGE_RL
+    with pytest.raises(P.PgxError) as e:
+        P.Index(xy, mode=P.MODE_IMAGE_RL | P.MODE_IMAGE_DENSE)
+    assert e.value.code == P.ERR_ARG
+    with pytest.raises(P.PgxError) as e:
+        P.Index(xy, mode=7)
+    assert e.value.code == P.ERR_ARG
 
 
 def test_tag_image_both_formats(workdir):
