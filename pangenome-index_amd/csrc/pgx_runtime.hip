@@ -735,7 +735,14 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         HIPCHECK(hipMemcpyAsync(d_cursor, &start, 8, hipMemcpyHostToDevice, s));
         record(b, 1, s);
         unsigned grid = grid_for(cn, 64);
-        if (grid > (unsigned)(occ * cus)) grid = (unsigned)(occ * cus);
+        int wg = occ;
+        if (img.dense && !std::getenv("PGX_FM_WG_PER_CU")) {
+            // the dense kernels need little occupancy, and every resident lane ends the launch inside a read (the tail):
+            // aim at >= 5 reads per lane (1 M reads: 3 workgroups per CU measured best, 493 vs 477 (x) and 179 vs 160 (synth) Mreads/s)
+            const uint64_t want = cn / (5ull * (uint64_t)cus * PGX_FM_THREADS);
+            wg = (int)std::min<uint64_t>((uint64_t)occ, std::max<uint64_t>(2, want));
+        }
+        if (grid > (unsigned)(wg * cus)) grid = (unsigned)(wg * cus);
         {
             const uint8_t *a_reads = b->reads.as<uint8_t>();
             const uint64_t *a_off = b->offsets.as<uint64_t>(), *a_slot_off = b->slot_off.as<uint64_t>();
