@@ -7,7 +7,9 @@
 // Options (ours): --device N, --mode compat|strict, --batch N (reads per device batch),
 //                 --tags-format auto|bytecode|compact, --quiet (no per-read stderr line)
 // The tag file may be either query format; the reference's find_mems only loads the sdsl-compact one.
+#include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -15,9 +17,34 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pgx.h"
+
+// decimal text of v at p; returns the end.  Two digits per division.
+static inline char *put_u64(char *p, uint64_t v) {
+    static const char d2[201] =
+        "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+    char tmp[20];
+    int k = 20;
+    while (v >= 100) {
+        const unsigned r = (unsigned)(v % 100);
+        v /= 100;
+        k -= 2;
+        tmp[k] = d2[2 * r];
+        tmp[k + 1] = d2[2 * r + 1];
+    }
+    if (v >= 10) { k -= 2; tmp[k] = d2[2 * v]; tmp[k + 1] = d2[2 * v + 1]; }
+    else tmp[--k] = (char)('0' + v);
+    std::memcpy(p, tmp + k, (size_t)(20 - k));
+    return p + (20 - k);
+}
+static inline char *put_str(char *p, const char *s) {
+    const size_t n = std::strlen(s);
+    std::memcpy(p, s, n);
+    return p + n;
+}
 
 int main(int argc, char **argv) {
     if (argc < 6) {
@@ -68,21 +95,59 @@ int main(int argc, char **argv) {
     auto time3 = std::chrono::high_resolution_clock::now();
     std::cerr << "Loading tag arrays took " << std::chrono::duration<double>(time3 - time2).count() << " seconds" << std::endl;
 
-    std::ifstream reads(reads_file);
+    std::ifstream reads(reads_file, std::ios::binary);
     if (!reads) { std::cerr << "Cannot open reads file: " << reads_file << std::endl; std::exit(EXIT_FAILURE); } // :91
 
+    // The reference formats with iostreams one value at a time; a device batch finishes in milliseconds, so the text
+    // side is what a user waits for: lines are split with memchr from 16 MiB chunks, and each batch is formatted by a
+    // pool of threads (contiguous read ranges, one buffer each) and written in read order.
+    const unsigned n_fmt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     pgx_batch *b = nullptr;
-    std::string cat, line, out;
+    std::string cat, carry;
     std::vector<uint64_t> offs;
+    std::vector<char> chunk(16u << 20);
+    size_t chunk_len = 0, chunk_pos = 0;
     size_t seq_no = 0;
     bool eof = false;
-    while (!eof) {
+    // next line of the reads file (without the '\n') appended to `cat`; false at end of file
+    auto next_line = [&](bool &empty) -> bool {
+        for (;;) {
+            if (chunk_pos < chunk_len) {
+                const char *base = chunk.data() + chunk_pos;
+                const char *nl = static_cast<const char *>(std::memchr(base, '\n', chunk_len - chunk_pos));
+                if (nl) {
+                    const size_t len = (size_t)(nl - base);
+                    empty = carry.empty() && len == 0;
+                    if (!carry.empty()) { cat += carry; carry.clear(); }
+                    cat.append(base, len);
+                    chunk_pos += len + 1;
+                    return true;
+                }
+                carry.append(base, chunk_len - chunk_pos); // line continues in the next chunk
+                chunk_pos = chunk_len;
+            }
+            if (eof) {
+                if (carry.empty()) return false;
+                empty = false; // std::getline returns a last line without a terminator
+                cat += carry;
+                carry.clear();
+                return true;
+            }
+            reads.read(chunk.data(), (std::streamsize)chunk.size());
+            chunk_len = (size_t)reads.gcount();
+            chunk_pos = 0;
+            if (chunk_len == 0) eof = true;
+        }
+    };
+    bool done = false;
+    std::vector<std::string> outs(n_fmt), errs(n_fmt);
+    while (!done) {
         cat.clear();
         offs.assign(1, 0);
         while (offs.size() <= batch_reads) {
-            if (!std::getline(reads, line)) { eof = true; break; }
-            if (line.empty()) continue; // :97
-            cat += line;
+            bool empty = false;
+            if (!next_line(empty)) { done = true; break; }
+            if (empty) continue; // :97
             offs.push_back(cat.size());
         }
         const size_t n = offs.size() - 1;
@@ -102,27 +167,52 @@ int main(int argc, char **argv) {
             total_mem_time += 1e-3 * (t.ms_find_mems + t.ms_compact);
             total_tag_time += 1e-3 * (t.ms_tag_locate + t.ms_tag_gather + t.ms_tag_sort);
         }
-        out.clear();
-        std::string err;
-        for (size_t i = 0; i < n; i++) {
-            ++seq_no;
-            if (!quiet) err += "[find_all_mems] total mems=" + std::to_string(r.mem_offsets[i + 1] - r.mem_offsets[i]) + "\n"; // algorithm.hpp:754
-            out += "Seq: " + std::to_string(seq_no) + "\n"; // :115
-            for (uint64_t m = r.mem_offsets[i]; m < r.mem_offsets[i + 1]; m++) {
-                const pgx_mem &mm = r.mems[m];
-                out += "MEM START: " + std::to_string(mm.start) + ", MEM END: " + std::to_string(mm.end) + " BWT START: " +
-                       std::to_string(mm.bwt_start) + " SIZE: " + std::to_string(mm.size) + "\n"; // :118
-                out += "Number of unique positions: " + std::to_string(r.pos_offsets[m + 1] - r.pos_offsets[m]) + "\n"; // tag_arrays.cpp:885
-                for (uint64_t p = r.pos_offsets[m]; p < r.pos_offsets[m + 1]; p++) out += std::to_string(r.positions[p]) + ", ";
-                out += "\n";
+        auto format_range = [&](unsigned w) {
+            const size_t lo = n * w / n_fmt, hi = n * (w + 1) / n_fmt;
+            std::string &out = outs[w], &err = errs[w];
+            out.clear();
+            err.clear();
+            // exact upper bound of the text of this range: 20 digits per number
+            const uint64_t m_lo = r.mem_offsets[lo], m_hi = r.mem_offsets[hi];
+            const uint64_t p_cnt = r.pos_offsets[m_hi] - r.pos_offsets[m_lo];
+            out.resize((hi - lo) * 32 + (m_hi - m_lo) * 192 + p_cnt * 22 + 64);
+            char *p = &out[0];
+            for (size_t i = lo; i < hi; i++) {
+                const size_t seq = seq_no + i + 1;
+                if (!quiet) { err += "[find_all_mems] total mems="; err += std::to_string(r.mem_offsets[i + 1] - r.mem_offsets[i]); err += '\n'; } // algorithm.hpp:754
+                p = put_str(p, "Seq: "); p = put_u64(p, seq); *p++ = '\n'; // :115
+                for (uint64_t m = r.mem_offsets[i]; m < r.mem_offsets[i + 1]; m++) {
+                    const pgx_mem &mm = r.mems[m];
+                    p = put_str(p, "MEM START: "); p = put_u64(p, mm.start);
+                    p = put_str(p, ", MEM END: "); p = put_u64(p, mm.end);
+                    p = put_str(p, " BWT START: "); p = put_u64(p, mm.bwt_start);
+                    p = put_str(p, " SIZE: ");
+                    if (mm.size < 0) { *p++ = '-'; p = put_u64(p, (uint64_t)(-(mm.size + 1)) + 1u); } else p = put_u64(p, (uint64_t)mm.size);
+                    *p++ = '\n'; // :118
+                    p = put_str(p, "Number of unique positions: "); p = put_u64(p, r.pos_offsets[m + 1] - r.pos_offsets[m]); *p++ = '\n'; // tag_arrays.cpp:885
+                    for (uint64_t q = r.pos_offsets[m]; q < r.pos_offsets[m + 1]; q++) { p = put_u64(p, r.positions[q]); *p++ = ','; *p++ = ' '; }
+                    *p++ = '\n';
+                }
+                *p++ = '\n'; // :138
             }
-            out += "\n"; // :138
-            if (out.size() > (1u << 22)) { std::cout << out; out.clear(); }
+            out.resize((size_t)(p - &out[0]));
+        };
+        if (n_fmt == 1 || n < 4096) {
+            for (unsigned w = 0; w < n_fmt; w++) format_range(w);
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned w = 0; w < n_fmt; w++) pool.emplace_back(format_range, w);
+            for (auto &th : pool) th.join();
         }
-        std::cout << out;
-        std::cerr << err;
+        for (unsigned w = 0; w < n_fmt; w++) {
+            std::fwrite(outs[w].data(), 1, outs[w].size(), stdout);
+            if (!errs[w].empty()) std::fwrite(errs[w].data(), 1, errs[w].size(), stderr);
+        }
+        seq_no += n;
     }
+    std::fflush(stdout);
     pgx_batch_free(b);
+    std::cout.flush();
     std::cout << "\nTotal time for finding all MEMs: " << total_mem_time << " seconds" << std::endl; // :144
     std::cout << "Total time for all tag queries: " << total_tag_time << " seconds" << std::endl;   // :145
     pgx_index_close(h);

@@ -1,0 +1,38 @@
+"""End-to-end wall time of the find_mems CLI (text in, text out) on the GPU box: python3 scripts/cli_e2e.py [x|synth] [n_reads]"""
+import os, subprocess, sys, time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pangenome-index_amd"))
+import numpy as np
+import pgx_workload as W
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "x"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+wd = "/tmp/pgx_cli_e2e"
+os.makedirs(wd, exist_ok=True)
+if wl == "x":
+    g = os.path.join(ROOT, "tests", "golden")
+    ri, tags = W.build_index_from_rlbwt(os.path.join(g, "x.rl_bwt"), wd, "x")[:2]
+    seqs = W.load_sequences(os.path.join(g, "x.newline_separated"))
+    min_len = 10
+else:
+    text = os.path.join(wd, "synth.txt")
+    W.synth_pangenome_text(text)
+    ri, tags = W.build_index_from_text(text, wd, "synth")[:2]
+    seqs = W.load_sequences(text)
+    min_len = 20
+cat, offs = W.sample_reads(seqs, n, 150, seed=42)
+path = os.path.join(wd, "reads.txt")
+lines = np.full((n, 151), 10, dtype=np.uint8)  # one read per line
+lines[:, :150] = cat.reshape(n, 150)
+lines.tofile(path)
+print("reads file written", flush=True)
+exe = os.path.join(ROOT, "pangenome-index_amd", "find_mems")
+for dest in ("/dev/null", os.path.join(wd, "out.txt")):
+    t0 = time.time()
+    with open(dest, "wb") as out:
+        r = subprocess.run([exe, ri, tags, path, str(min_len), "1", "--quiet"], stdout=out, stderr=subprocess.PIPE)
+    dt = time.time() - t0
+    size = os.path.getsize(dest) if dest != "/dev/null" else 0
+    print("%s n=%d -> %s: %.2f s wall (%.2f M reads/s end to end), rc=%d, output %.1f MB" % (wl, n, dest, dt, n / dt / 1e6, r.returncode, size / 1e6))
+    print("   stderr tail:", r.stderr.decode().strip().split("\n")[-3:], flush=True)
