@@ -205,6 +205,7 @@ typedef struct {
     float ms_tag_sort;
     float ms_total;       /* first launch -> last launch, device time */
     uint32_t find_mems_launches;
+    uint32_t heavy_reads; /* reads whose rest went through the heavy-read kernel (filled by every run, timed or not) */
 } pgx_timing;
 
 /* Upload reads (read i = reads[offsets[i] .. offsets[i+1]); the `std::getline` lines of

@@ -29,10 +29,30 @@ struct PgxDevImage {
     uint32_t dense; // 1: blocks are dense bit-plane blocks (PGX_IMAGE_DENSE), dir / blow unused
 };
 
+// heavy reads (pgx_kernels.hip): handed from pgx_find_mems_kernel to pgx_find_mems_heavy_kernel
+struct pgx_heavy_item {
+    uint64_t rid;
+    uint32_t x, nm; // next start position, MEMs already written
+};
+struct PgxHeavyResult { // find_mems_function(x) of one start position
+    pgx_mem mem;
+    uint32_t next_x, n_ext, has_mem, pad;
+};
+#define PGX_FM_HEAVY_EXT 2048u    // extensions spent on one read before the rest is handed on (ordinary 150-bp reads: ~200)
+#define PGX_FM_HEAVY_MAXLEN 4096u // reads up to this length take part (per-start results live in scratch)
+#define PGX_FM_HEAVY_CAP 8192u    // heavy reads per launch; beyond that lanes simply continue sequentially
+#define PGX_FM_HEAVY_GRID 64u
+template <bool LDS_IMAGE>
+__global__ void pgx_find_mems_heavy_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t min_len, uint64_t min_occ,
+                                           const uint64_t *slot_off, uint64_t slot_base, pgx_mem *slots, uint32_t *mem_count,
+                                           unsigned long long *n_ext_total, const pgx_heavy_item *heavy_list,
+                                           const unsigned long long *heavy_count, uint32_t heavy_cap, PgxHeavyResult *scratch);
+
 template <bool LDS_IMAGE, bool DENSE>
 __global__ void pgx_find_mems_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
                                      uint64_t min_len, uint64_t min_occ, const uint64_t *slot_off, pgx_mem *slots,
-                                     uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor, uint64_t slot_base);
+                                     uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor, uint64_t slot_base,
+                                     uint32_t heavy_ext, uint32_t heavy_cap, pgx_heavy_item *heavy_list, unsigned long long *heavy_count);
 __global__ void pgx_rank_kernel(PgxDevImage img, const uint64_t *pos, uint64_t n, int true_codes, uint64_t *out);
 template <bool LDS_IMAGE>
 __global__ void pgx_extend_kernel(PgxDevImage img, const pgx_biint *in, const uint8_t *sym, const uint8_t *forward, uint64_t n,

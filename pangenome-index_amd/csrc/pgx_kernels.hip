@@ -292,13 +292,19 @@ __device__ __forceinline__ void pgx_stage_tables(const PgxDevImage &img, uint32_
 // one atomicAdd of PGX_FM_BATCH on the global cursor, and idle lanes take ids from it in lane order
 // (ballot + prefix popcount).  Every wave leaves the loop once the cursor has passed n_reads and
 // all its lanes are idle.  MEMs go to per-read slots, so the output does not depend on scheduling.
+//
+// Heavy reads: a read whose suffix ends a sequence makes step 3 walk the whole read for every start position
+// (pattern[len] = 0 is the endmarker): ~len^2 / 2 extensions in one dependent chain, 100 x an
+// ordinary read, tens of milliseconds for one lane.  A lane that has spent `heavy_ext` extensions on its read hands the
+// rest (rid, next start, MEMs so far) to pgx_find_mems_heavy_kernel at the next start-position boundary.
 #define PGX_FM_BATCH 128u
 template <bool LDS_IMAGE, bool DENSE>
 __global__ void __launch_bounds__(PGX_FM_THREADS, PGX_FM_WAVES_PER_SIMD)
 pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                      uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
                      pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
-                     unsigned long long *__restrict__ cursor, uint64_t slot_base) {
+                     unsigned long long *__restrict__ cursor, uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap,
+                     pgx_heavy_item *__restrict__ heavy_list, unsigned long long *__restrict__ heavy_count) {
     __shared__ uint32_t s_ext[512];
     __shared__ uint64_t s_C[8];
     PGX_LDS_CARVE(img);
@@ -309,7 +315,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     uint64_t rid = 0, base = 0, slot = 0;
     int32_t len = 0, x = 0, j = 0;
     uint64_t k = 0, kp = 0, s = 0, Jk = 0, Js = 0;
-    uint32_t nm = 0, next = 0;
+    uint32_t nm = 0, next = 0, next0 = 0; // next0: value of `next` when the current read was taken
     int ph = 0;                      // 0 = idle (no read, or read finished)
     uint64_t win = 0, win_at = ~0ull; // 8 read bytes cached in registers (absolute, 8-aligned offset)
     uint64_t A0 = 0, B0 = 0;          // first-probe sums of an extension whose second probe is pending
@@ -323,6 +329,16 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     // begin(x): entry of find_mems_function; finishing a read records its MEM count
     auto begin = [&]() {
         if (x >= len || (uint64_t)(len - x) < min_len) { ph = 0; mem_count[rid] = nm; return; } // :745 / :658
+        if (heavy_ext && next - next0 >= heavy_ext && len <= (int32_t)PGX_FM_HEAVY_MAXLEN) { // hand the rest of a heavy read on
+            const unsigned long long at = atomicAdd(heavy_count, 1ull);
+            if (at < (unsigned long long)heavy_cap) {
+                pgx_heavy_item it;
+                it.rid = rid; it.x = (uint32_t)x; it.nm = nm;
+                heavy_list[at] = it;
+                ph = 0;
+                return;
+            }
+        }
         k = 0; kp = 0; s = n;
         if (min_len == 0) { // step 1 runs zero times (:666); step 2 starts at j = x
             Jk = 0; Js = n; j = x; ph = 2;
@@ -330,6 +346,8 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
             j = x + (int32_t)min_len - 1; ph = 1;
         }
     };
+    // the state machine below funnels every "next start position" through one begin() (the lambda is inlined per call site)
+    bool restart = false;
     // emit the MEM [x, e) and set up step 3
     auto emit = [&]() {
         pgx_mem m;
@@ -338,7 +356,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
         nm++;
         k = 0; kp = 0; s = n;
         if (j > x) ph = 3;
-        else { x = x + 1; begin(); } // loop of :722 runs zero times, returns j + 1
+        else { x = x + 1; restart = true; } // loop of :722 runs zero times, returns j + 1
     };
 
     for (;;) {
@@ -364,6 +382,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                 len = (int32_t)(offsets[rid + 1] - base);
                 slot = slot_off[rid] - slot_base; // slots are reused per chunk of reads (pgx_batch_run)
                 x = 0; nm = 0;
+                next0 = next;
                 begin(); // may leave the lane idle again (read shorter than min_len)
                 if (ph == 0) ph = -1; // served in this round; becomes idle again below
             }
@@ -443,8 +462,9 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                     kp = fwd ? nk : nq;
                 }
                 const bool small = (s < min_occ) || (s == 0); // :671 (unsigned compare) || size <= 0
+                restart = false;
                 if (ph == 1) {
-                    if (small) { x = j + 1; begin(); }
+                    if (small) { x = j + 1; restart = true; }
                     else if (j == x) {
                         Jk = k; Js = s; j = x + (int32_t)min_len;
                         if (j >= len) emit(); else ph = 2;
@@ -456,12 +476,13 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                         if (j >= len) emit();
                     }
                 } else { // ph == 3
-                    if (small) { x = j + 1; begin(); }
+                    if (small) { x = j + 1; restart = true; }
                     else {
                         j--;
-                        if (j <= x) { x = x + 1; begin(); }
+                        if (j <= x) { x = x + 1; restart = true; }
                     }
                 }
+                if (restart) begin(); // next start position of this read (or the read is finished / handed on)
             }
         }
     }
@@ -476,13 +497,107 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
 }
 
 template __global__ void pgx_find_mems_kernel<false, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t);
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t,
+                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
 template __global__ void pgx_find_mems_kernel<false, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t);
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t,
+                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
 template __global__ void pgx_find_mems_kernel<true, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t);
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t,
+                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
 template __global__ void pgx_find_mems_kernel<true, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t);
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t,
+                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
+
+// ------------------------------------------------------------------------------------------
+// The rest of a heavy read (see pgx_find_mems_kernel): one workgroup per read evaluates find_mems_function(x)
+// (algorithm.hpp:653-736) for EVERY remaining start position x at once -- the calls are independent of each other,
+// only the choice of the next start is a chain -- and thread 0 then follows the chain through the stored results,
+// writing the MEMs of the visited starts in order and adding only their extensions to the extension counter.  About
+// twice the extensions of the sequential walk, ~300 of them on the critical path instead of ~len^2 / 2.
+template <bool LDS_IMAGE>
+__global__ void __launch_bounds__(256)
+pgx_find_mems_heavy_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets, uint64_t min_len,
+                           uint64_t min_occ, const uint64_t *__restrict__ slot_off, uint64_t slot_base, pgx_mem *__restrict__ slots,
+                           uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
+                           const pgx_heavy_item *__restrict__ heavy_list, const unsigned long long *__restrict__ heavy_count,
+                           uint32_t heavy_cap, PgxHeavyResult *__restrict__ scratch) {
+    unsigned long long cnt = *heavy_count;
+    if (cnt == 0) return; // the usual case: nothing was handed on (uniform exit before any staging)
+    if (cnt > heavy_cap) cnt = heavy_cap;
+    __shared__ uint32_t s_ext[512];
+    __shared__ uint64_t s_C[8];
+    PGX_LDS_CARVE(img);
+    pgx_stage_tables<LDS_IMAGE>(img, s_ext, s_C, lds_blocks, lds_dir, lds_blow);
+    const uint64_t n = img.n;
+    PgxHeavyResult *res = scratch + (size_t)blockIdx.x * PGX_FM_HEAVY_MAXLEN;
+    for (unsigned long long h = blockIdx.x; h < cnt; h += gridDim.x) {
+        const pgx_heavy_item it = heavy_list[h];
+        const uint64_t base = offsets[it.rid];
+        const int32_t len = (int32_t)(offsets[it.rid + 1] - base), x0 = (int32_t)it.x;
+        const uint8_t *pat = reads + base;
+        for (int32_t xs = x0 + (int32_t)threadIdx.x; xs < len; xs += (int32_t)blockDim.x) {
+            PgxHeavyResult r;
+            r.mem.start = (uint64_t)xs; r.mem.end = 0; r.mem.bwt_start = 0; r.mem.size = 0;
+            r.next_x = (uint32_t)len; r.n_ext = 0; r.has_mem = 0; r.pad = 0;
+            if ((uint64_t)(len - xs) >= min_len) {
+                uint64_t k = 0, kp = 0, s = n;
+                uint32_t ne = 0;
+                bool dead = false;
+                for (int32_t j = xs + (int32_t)min_len - 1; j >= xs; j--) { // step 1 (:666-676)
+                    pgx_extend<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, s_ext, s_C, k, kp, s, pat[j], false);
+                    ne++;
+                    if (s < min_occ || s == 0) { r.next_x = (uint32_t)(j + 1); dead = true; break; }
+                }
+                if (!dead) {
+                    uint64_t Jk = k, Js = s;
+                    int32_t j = xs + (int32_t)min_len;
+                    for (; j < len; j++) { // step 2 (:684-696)
+                        pgx_extend<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, s_ext, s_C, k, kp, s, pat[j], true);
+                        ne++;
+                        if (s < min_occ || s == 0) break;
+                        Jk = k; Js = s;
+                    }
+                    r.has_mem = 1;
+                    r.mem.end = (uint64_t)j; r.mem.bwt_start = Jk; r.mem.size = (int64_t)Js; // :713
+                    k = 0; kp = 0; s = n;
+                    uint32_t nxt = (uint32_t)(xs + 1);
+                    for (; j > xs; j--) { // step 3 (:718-735); pattern[len] reads 0
+                        pgx_extend<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, s_ext, s_C, k, kp, s, j < len ? pat[j] : (uint8_t)0, false);
+                        ne++;
+                        if (s < min_occ || s == 0) { nxt = (uint32_t)(j + 1); break; }
+                    }
+                    r.next_x = nxt;
+                }
+                r.n_ext = ne;
+            }
+            res[xs - x0] = r;
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint64_t slot = slot_off[it.rid] - slot_base;
+            uint32_t nm = it.nm;
+            unsigned long long ne = 0;
+            int32_t x = x0;
+            while (x < len && (uint64_t)(len - x) >= min_len) {
+                const PgxHeavyResult r = res[x - x0];
+                ne += r.n_ext;
+                if (r.has_mem) slots[slot + nm++] = r.mem;
+                x = (int32_t)r.next_x;
+            }
+            mem_count[it.rid] = nm;
+            atomicAdd(n_ext_total, ne);
+        }
+        __syncthreads(); // res is reused by the next item of this workgroup
+    }
+}
+template __global__ void pgx_find_mems_heavy_kernel<false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, const uint64_t *, uint64_t,
+                                                           pgx_mem *, uint32_t *, unsigned long long *, const pgx_heavy_item *,
+                                                           const unsigned long long *, uint32_t, PgxHeavyResult *);
+template __global__ void pgx_find_mems_heavy_kernel<true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, const uint64_t *, uint64_t,
+                                                          pgx_mem *, uint32_t *, unsigned long long *, const pgx_heavy_item *,
+                                                          const unsigned long long *, uint32_t, PgxHeavyResult *);
 
 // ------------------------------------------------------------------------------------------
 // primitives for tests (mirror rank_at_cached_encoded / backward_extend_encoded / forward_...)

@@ -576,7 +576,7 @@ struct pgx_batch {
     uint64_t plan_min_len = 0, plan_budget = 0;
     DevBuf reads, offsets;
     // run state
-    DevBuf slot_off, slots, mem_count, mem_off, mems, scan_tmp, counters;
+    DevBuf slot_off, slots, mem_count, mem_off, mems, scan_tmp, counters, heavy_list, heavy_scratch;
     TagWork tw;
     uint64_t n_mems = 0, n_positions = 0, n_ext = 0, n_tag_overflow = 0;
     bool ran = false, ran_tags = false;
@@ -592,7 +592,7 @@ static void batch_release(pgx_batch *b) {
     if (!b) return;
     if (hipSetDevice(b->device) == hipSuccess) {
         DevBuf *all[] = {&b->reads, &b->offsets, &b->slot_off, &b->slots, &b->mem_count, &b->mem_off, &b->mems, &b->scan_tmp,
-                         &b->counters};
+                         &b->counters, &b->heavy_list, &b->heavy_scratch};
         for (DevBuf *d : all) d->release();
         b->tw.release();
         HostBuf *hb[] = {&b->h_mem_off, &b->h_mems, &b->h_run_nums, &b->h_pos_off, &b->h_positions};
@@ -678,8 +678,8 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     b->n_mems = b->n_positions = b->n_ext = b->n_tag_overflow = 0;
     std::memset(&b->timing, 0, sizeof b->timing);
 
-    b->counters.ensure(64);
-    HIPCHECK(hipMemsetAsync(b->counters.p, 0, 64, s));
+    b->counters.ensure(128); // [0..7] as listed below, [8] heavy reads handed on by the current find_mems launch
+    HIPCHECK(hipMemsetAsync(b->counters.p, 0, 128, s));
     unsigned long long *d_next = b->counters.as<unsigned long long>();
     unsigned long long *d_nover = d_next + 1;
 
@@ -727,6 +727,13 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             if (v >= 1 && v < occ) occ = v;
         }
     }
+    uint32_t heavy_ext = PGX_FM_HEAVY_EXT; // extensions on one read before its rest goes to the heavy-read kernel (0 = never)
+    if (const char *e = std::getenv("PGX_FM_HEAVY_EXT")) heavy_ext = (uint32_t)std::strtoul(e, nullptr, 10);
+    unsigned long long *d_heavy_count = d_next + 8;
+    if (heavy_ext) {
+        b->heavy_list.ensure((size_t)PGX_FM_HEAVY_CAP * sizeof(pgx_heavy_item));
+        b->heavy_scratch.ensure((size_t)PGX_FM_HEAVY_GRID * PGX_FM_HEAVY_MAXLEN * sizeof(PgxHeavyResult));
+    }
     unsigned long long *d_cursor = d_next + 5; // counters: [0] extensions [1] tag overflows [2] big [3] large [4] max large [5] read cursor
     for (size_t ci = 0; ci < chunks.size(); ci++) {
         const pgx_chunk &c = chunks[ci];
@@ -751,8 +758,23 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             uint32_t *a_cnt = b->mem_count.as<uint32_t>();
             unsigned long long *a_next = d_next, *a_cur = d_cursor;
             PgxDevImage a_img = img;
-            void *args[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_base};
+            uint32_t a_hext = heavy_ext, a_hcap = PGX_FM_HEAVY_CAP;
+            pgx_heavy_item *a_hlist = b->heavy_list.as<pgx_heavy_item>();
+            unsigned long long *a_hcount = d_heavy_count;
+            void *args[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_base,
+                            &a_hext, &a_hcap, &a_hlist, &a_hcount};
+            if (heavy_ext && ci) HIPCHECK(hipMemsetAsync(d_heavy_count, 0, 8, s));
             HIPCHECK(hipLaunchKernel(kfn, dim3(grid), dim3(PGX_FM_THREADS), args, b->dimg->lds_bytes, s)); // one of the four variants
+            if (heavy_ext) { // the rest of reads that spent heavy_ext extensions (usually none: the launch then costs a few microseconds)
+                if (b->dimg->lds_bytes)
+                    hipLaunchKernelGGL(pgx_find_mems_heavy_kernel<true>, dim3(PGX_FM_HEAVY_GRID), dim3(256), b->dimg->lds_bytes, s, img, a_reads, a_off,
+                                       min_len, min_occ, a_slot_off, c.slot_base, a_slots, a_cnt, d_next, (const pgx_heavy_item *)a_hlist,
+                                       (const unsigned long long *)d_heavy_count, (uint32_t)PGX_FM_HEAVY_CAP, b->heavy_scratch.as<PgxHeavyResult>());
+                else
+                    hipLaunchKernelGGL(pgx_find_mems_heavy_kernel<false>, dim3(PGX_FM_HEAVY_GRID), dim3(256), 0, s, img, a_reads, a_off, min_len, min_occ,
+                                       a_slot_off, c.slot_base, a_slots, a_cnt, d_next, (const pgx_heavy_item *)a_hlist,
+                                       (const unsigned long long *)d_heavy_count, (uint32_t)PGX_FM_HEAVY_CAP, b->heavy_scratch.as<PgxHeavyResult>());
+            }
         }
         HIPCHECK(hipGetLastError());
         b->timing.find_mems_launches++;
@@ -793,13 +815,15 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         b->ran_tags = true;
     }
     record(b, 7, s);
-    unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HIPCHECK(hipMemcpyAsync(cnt, b->counters.p, 64, hipMemcpyDeviceToHost, s));
+    unsigned long long cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHECK(hipMemcpyAsync(cnt, b->counters.p, 72, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
     if (cnt[6] && std::getenv("PGX_FM_STATS")) // only a -DPGX_FM_STATS build of the kernels fills these (scripts/fm_stats.sh)
         std::fprintf(stderr, "[pgx] find_mems wave trips %llu, live lane-trips %llu (%.1f%% of lanes), longest wave %llu trips, extensions %llu\n", cnt[6], cnt[7],
                      100.0 * (double)cnt[7] / (64.0 * (double)cnt[6]), cnt[3], cnt[0]);
+    if (std::getenv("PGX_DEBUG_COUNTERS")) std::fprintf(stderr, "[pgx] counters %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[6], cnt[7], cnt[8]);
     b->n_ext = cnt[0];
+    b->timing.heavy_reads += (uint32_t)std::min<unsigned long long>(cnt[8], PGX_FM_HEAVY_CAP); // of the last chunk when chunked
     b->n_tag_overflow = cnt[1];
     if (b->timed) {
         auto el = [&](int a, int c) { float ms = 0; HIPCHECK(hipEventElapsedTime(&ms, b->ev[a], b->ev[c])); return ms; };

@@ -48,7 +48,7 @@ class Timing(C.Structure):
     _fields_ = [
         ("ms_find_mems", C.c_float), ("ms_compact", C.c_float), ("ms_tag_locate", C.c_float),
         ("ms_tag_gather", C.c_float), ("ms_tag_sort", C.c_float), ("ms_total", C.c_float),
-        ("find_mems_launches", u32),
+        ("find_mems_launches", u32), ("heavy_reads", u32),
     ]
 
 
