@@ -88,7 +88,10 @@ __global__ void pgx_tag_copy_dups_kernel(const uint64_t *pairs, uint64_t n_pairs
                                          const uint64_t *run_nums, const uint64_t *seg_off, uint64_t *buf, uint64_t *ucount,
                                          unsigned long long *n_overflow);
 __global__ void pgx_tag_compact_kernel(uint64_t n, const uint64_t *ucount, const uint64_t *seg_off, const uint64_t *buf,
-                                       const uint64_t *pos_off, uint64_t *positions);
+                                       const uint64_t *pos_off, uint64_t *positions, uint64_t max_count);
+__global__ void pgx_tag_compact_list_kernel(const uint64_t *list, uint64_t n_list, const uint64_t *ucount, const uint64_t *seg_off,
+                                            const uint64_t *buf, const uint64_t *pos_off, uint64_t *positions, uint64_t max_count);
+#define PGX_TAG_COMPACT_SMALL 256 // segments up to this many unique values are copied by the 16-lane kernel
 
 // locate image (pgx_image.h), passed by value to the locate kernels
 struct PgxLocImage {

@@ -354,8 +354,18 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
     w.n_positions = read_u64(w.pos_off.as<uint64_t>() + m, s);
     w.positions.ensure((w.n_positions ? w.n_positions : 1) * 8);
     if (m) {
+        const bool listed = nbig || nlarge; // only listed queries (> 16 runs) can exceed the 16-lane kernel's limit
         hipLaunchKernelGGL(pgx_tag_compact_kernel, dim3(grid_for(m, 16)), dim3(256), 0, s, m, w.ucount.as<uint64_t>(),
-                           w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.pos_off.as<uint64_t>(), w.positions.as<uint64_t>());
+                           w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.pos_off.as<uint64_t>(), w.positions.as<uint64_t>(),
+                           listed ? (uint64_t)PGX_TAG_COMPACT_SMALL : ~0ull);
+        if (nbig)
+            hipLaunchKernelGGL(pgx_tag_compact_list_kernel, dim3(grid_for(nbig, 1)), dim3(256), 0, s, (const uint64_t *)w.big_list.as<uint64_t>(), nbig,
+                               w.ucount.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.pos_off.as<uint64_t>(),
+                               w.positions.as<uint64_t>(), (uint64_t)PGX_TAG_COMPACT_SMALL);
+        if (nlarge)
+            hipLaunchKernelGGL(pgx_tag_compact_list_kernel, dim3(grid_for(nlarge, 1)), dim3(256), 0, s,
+                               (const uint64_t *)(w.big_list.as<uint64_t>() + (m - nlarge)), nlarge, w.ucount.as<uint64_t>(), w.seg_off.as<uint64_t>(),
+                               w.gbuf.as<uint64_t>(), w.pos_off.as<uint64_t>(), w.positions.as<uint64_t>(), (uint64_t)PGX_TAG_COMPACT_SMALL);
         HIPCHECK(hipGetLastError());
     }
     rec(2);
@@ -490,7 +500,7 @@ static void locate_core(pgx_index *h, pgx_device_image *d, const uint64_t *first
             const uint64_t U = read_u64(duoff.as<uint64_t>() + n, s);
             vals_out.ensure((U ? U : 1) * 8);
             hipLaunchKernelGGL(pgx_tag_compact_kernel, dim3(grid_for(n, 16)), dim3(256), 0, s, n, ducount.as<uint64_t>(), dvoff.as<uint64_t>(),
-                               gbuf.as<uint64_t>(), duoff.as<uint64_t>(), vals_out.as<uint64_t>());
+                               gbuf.as<uint64_t>(), duoff.as<uint64_t>(), vals_out.as<uint64_t>(), ~0ull);
             HIPCHECK(hipGetLastError());
             h_off.resize(n + 1);
             HIPCHECK(hipMemcpy(h_off.data(), duoff.p, (n + 1) * 8, hipMemcpyDeviceToHost));

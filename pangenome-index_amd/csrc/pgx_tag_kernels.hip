@@ -250,15 +250,31 @@ pgx_tag_sort_large_kernel(const uint64_t *__restrict__ list, uint64_t n_list, co
     if (threadIdx.x == 0) ucount[q] = outn;
 }
 
-// 16 lanes per query: copy the unique prefix of its segment to the dense positions array
+// 16 lanes per query: copy the unique prefix of its segment to the dense positions array.  Segments with more than
+// `max_count` values are left to pgx_tag_compact_list_kernel (a few huge segments would otherwise keep 16 lanes busy
+// for thousands of iterations while the rest of the grid has finished).
 __global__ void __launch_bounds__(256)
 pgx_tag_compact_kernel(uint64_t n, const uint64_t *__restrict__ ucount, const uint64_t *__restrict__ seg_off,
-                       const uint64_t *__restrict__ buf, const uint64_t *__restrict__ pos_off, uint64_t *__restrict__ positions) {
+                       const uint64_t *__restrict__ buf, const uint64_t *__restrict__ pos_off, uint64_t *__restrict__ positions,
+                       uint64_t max_count) {
     const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int l16 = threadIdx.x & 15;
     if (q >= n) return;
     const uint64_t c = ucount[q], src = seg_off[q], dst = pos_off[q];
+    if (c > max_count) return;
     for (uint64_t t = l16; t < c; t += 16) positions[dst + t] = buf[src + t];
+}
+
+// one workgroup per listed query: the segments pgx_tag_compact_kernel skipped (more than `max_count` values)
+__global__ void __launch_bounds__(256)
+pgx_tag_compact_list_kernel(const uint64_t *__restrict__ list, uint64_t n_list, const uint64_t *__restrict__ ucount,
+                            const uint64_t *__restrict__ seg_off, const uint64_t *__restrict__ buf, const uint64_t *__restrict__ pos_off,
+                            uint64_t *__restrict__ positions, uint64_t max_count) {
+    if (blockIdx.x >= n_list) return;
+    const uint64_t q = list[blockIdx.x];
+    const uint64_t c = ucount[q], src = seg_off[q], dst = pos_off[q];
+    if (c <= max_count) return;
+    for (uint64_t t = threadIdx.x; t < c; t += blockDim.x) positions[dst + t] = buf[src + t];
 }
 
 // (query id, first item, run count) of every listed query -> host, which groups identical queries
