@@ -238,3 +238,25 @@ def test_sharded_equals_unsharded(xenc, golden):
         _assert_same(merged, whole, True)
     ref = O.find_mems_batch(ri, tags, cat, offs, 10, 1, threads=O.lib().orc_max_threads())
     _assert_same(whole, ref, True)
+
+
+def test_sigma6_pangenome_both_images(workdir):
+    """sigma = 6 synthetic pangenome (N runs, both strands): COMPAT == STRICT there, and both image layouts must agree
+    with the oracle on reads that include N runs, sequence ends and reverse complements"""
+    text = os.path.join(workdir, "p6.txt")
+    W.synth_pangenome_text(text, base_len=60000, n_hap=4, seed=11, n_runs=3, n_run_len=(100, 2000))
+    ri_path, tags_path = W.build_index_from_text(text, workdir, "p6")[:2]
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    assert ri.sigma == 6 and ri.has_N
+    seqs = W.load_sequences(text)
+    cat, offs = W.sample_reads(seqs, 20000, 150, seed=61)
+    for min_len, min_occ in [(20, 1), (12, 4)]:
+        ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, threads=O.lib().orc_max_threads())
+        strict = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, mode=O.MODE_STRICT, threads=O.lib().orc_max_threads())
+        # same MEMs; the extension counts differ (STRICT rejects pattern[len] = 0 at once, COMPAT walks on from the endmarker)
+        assert ref["mems"].tobytes() == strict["mems"].tobytes() and ref["n_extensions"] != strict["n_extensions"]
+        for mode in (P.MODE_COMPAT | P.MODE_IMAGE_DENSE, P.MODE_COMPAT | P.MODE_IMAGE_RL, P.MODE_STRICT | P.MODE_IMAGE_DENSE,
+                     P.MODE_STRICT | P.MODE_IMAGE_RL):
+            idx = P.Index(ri_path, tags_path, mode=mode)
+            _assert_same(idx.find_mems(cat, offs, min_len, min_occ, tags=True), strict if mode & 1 else ref, True)
+            idx.close()
