@@ -462,26 +462,24 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                     kp = fwd ? nk : nq;
                 }
                 const bool small = (s < min_occ) || (s == 0); // :671 (unsigned compare) || size <= 0
-                restart = false;
-                if (ph == 1) {
-                    if (small) { x = j + 1; restart = true; }
-                    else if (j == x) {
-                        Jk = k; Js = s; j = x + (int32_t)min_len;
-                        if (j >= len) emit(); else ph = 2;
-                    } else j--;
-                } else if (ph == 2) {
-                    if (small) emit();
-                    else {
-                        Jk = k; Js = s; j++;
-                        if (j >= len) emit();
-                    }
-                } else { // ph == 3
-                    if (small) { x = j + 1; restart = true; }
-                    else {
-                        j--;
-                        if (j <= x) { x = x + 1; restart = true; }
-                    }
-                }
+                // The transitions of the three steps as selects (the 64 lanes of a wave are in all three steps at once, so
+                // branches would run every path on every trip anyway, each with its own copies and exec-mask juggling):
+                //   step 1  small -> restart at j + 1 | j == x -> J = interval, j = x + min_len, step 2 (or emit) | else j--
+                //   step 2  small -> emit [x, j)      | else J = interval, j++, emit when j reaches len
+                //   step 3  small -> restart at j + 1 | else j--, restart at x + 1 once j reaches x
+                const bool adv = !small, p1 = ph == 1, p2 = ph == 2, at_x = j == x;
+                const bool to2 = p1 && adv && at_x;
+                const bool keep = adv && (to2 || p2);
+                Jk = keep ? k : Jk;
+                Js = keep ? s : Js;
+                const int32_t jn = adv ? (p1 ? (at_x ? x + (int32_t)min_len : j - 1) : (p2 ? j + 1 : j - 1)) : j;
+                const bool em = (p2 && (small || jn >= len)) || (to2 && jn >= len);
+                const bool rs_small = small && !p2, rs_end = !p1 && !p2 && adv && jn <= x;
+                restart = rs_small || rs_end;
+                x = rs_small ? j + 1 : (rs_end ? x + 1 : x);
+                ph = to2 ? 2 : ph;
+                j = jn;
+                if (em) emit();       // x is unchanged in every emitting case
                 if (restart) begin(); // next start position of this read (or the read is finished / handed on)
             }
         }
