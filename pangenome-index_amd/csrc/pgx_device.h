@@ -51,8 +51,8 @@ __global__ void pgx_find_mems_heavy_kernel(PgxDevImage img, const uint8_t *reads
 template <bool LDS_IMAGE, bool DENSE>
 __global__ void pgx_find_mems_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
                                      uint64_t min_len, uint64_t min_occ, const uint64_t *slot_off, pgx_mem *slots,
-                                     uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor, uint64_t slot_base,
-                                     uint32_t heavy_ext, uint32_t heavy_cap, pgx_heavy_item *heavy_list, unsigned long long *heavy_count);
+                                     uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor, uint64_t first_read,
+                                     uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap, pgx_heavy_item *heavy_list, unsigned long long *heavy_count);
 __global__ void pgx_rank_kernel(PgxDevImage img, const uint64_t *pos, uint64_t n, int true_codes, uint64_t *out);
 template <bool LDS_IMAGE>
 __global__ void pgx_extend_kernel(PgxDevImage img, const pgx_biint *in, const uint8_t *sym, const uint8_t *forward, uint64_t n,
@@ -62,7 +62,7 @@ __global__ void pgx_count_kernel(PgxDevImage img, const uint8_t *reads, const ui
 __global__ void pgx_scan_partial_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, uint64_t *block_sums);
 __global__ void pgx_scan_sums_kernel(uint64_t *block_sums, uint64_t nb);
 __global__ void pgx_scan_apply_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, const uint64_t *block_sums,
-                                      uint64_t nb, uint64_t *out);
+                                      uint64_t nb, uint64_t *out, uint64_t *total_out);
 __global__ void pgx_compact_mems_kernel(uint64_t first_read, uint64_t n_reads, const uint64_t *slot_off, uint64_t slot_base,
                                         const pgx_mem *slots, const uint32_t *mem_count, const uint64_t *local_off,
                                         uint64_t mem_base, pgx_mem *mems);

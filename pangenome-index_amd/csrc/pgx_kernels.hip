@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(PGX_FM_THREADS, PGX_FM_WAVES_PER_SIMD)
 pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                      uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
                      pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
-                     unsigned long long *__restrict__ cursor, uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap,
+                     unsigned long long *__restrict__ cursor, uint64_t first_read, uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap,
                      pgx_heavy_item *__restrict__ heavy_list, unsigned long long *__restrict__ heavy_count) {
     __shared__ uint32_t s_ext[512];
     __shared__ uint64_t s_C[8];
@@ -366,7 +366,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
             if (rnext == rend) {
                 if (exhausted) break;
                 unsigned long long got = 0;
-                if (lane == 0) got = atomicAdd(cursor, (unsigned long long)PGX_FM_BATCH);
+                if (lane == 0) got = first_read + atomicAdd(cursor, (unsigned long long)PGX_FM_BATCH); // the cursor counts from 0
                 // wave-uniform values are moved to scalar registers explicitly
                 got = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(got >> 32)) << 32) |
                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)got);
@@ -495,16 +495,16 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
 }
 
 template __global__ void pgx_find_mems_kernel<false, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t,
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
                                                             uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
 template __global__ void pgx_find_mems_kernel<false, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t,
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
                                                             uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
 template __global__ void pgx_find_mems_kernel<true, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t,
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
                                                             uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
 template __global__ void pgx_find_mems_kernel<true, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t,
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
                                                             uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
 
 // ------------------------------------------------------------------------------------------
@@ -701,7 +701,7 @@ __global__ void __launch_bounds__(256) pgx_scan_sums_kernel(uint64_t *block_sums
 // out has n+1 entries; out[n] = total
 __global__ void __launch_bounds__(256)
 pgx_scan_apply_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, const uint64_t *__restrict__ block_sums,
-                      uint64_t nb, uint64_t *__restrict__ out) {
+                      uint64_t nb, uint64_t *__restrict__ out, uint64_t *__restrict__ total_out) {
     __shared__ uint64_t s_wave[4];
     const uint64_t b0 = (uint64_t)blockIdx.x * 256 * PGX_SCAN_ITEMS;
     uint64_t vals[PGX_SCAN_ITEMS], v = 0;
@@ -717,7 +717,10 @@ pgx_scan_apply_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, co
         if (i < n) out[i] = ex;
         ex += vals[t];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = block_sums[nb];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[n] = block_sums[nb];
+        if (total_out) *total_out = block_sums[nb]; // a second copy next to other scalars the host reads back together
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -214,9 +214,11 @@ extern "C" pgx_status pgx_device_name(int device, char *buf, size_t buflen) {
 
 // ------------------------------------------------------------------------------------------
 // exclusive scan helper: out[n+1] on device (out[n] = total); returns nothing, async on `s`
-static void scan_excl(int mode, const void *in, uint64_t n, uint64_t min_len, uint64_t *out, DevBuf &tmp, hipStream_t s) {
+static void scan_excl(int mode, const void *in, uint64_t n, uint64_t min_len, uint64_t *out, DevBuf &tmp, hipStream_t s,
+                      uint64_t *total_out = nullptr) {
     if (n == 0) {
         HIPCHECK(hipMemsetAsync(out, 0, 8, s));
+        if (total_out) HIPCHECK(hipMemsetAsync(total_out, 0, 8, s));
         return;
     }
     const uint64_t nb = (n + PGX_SCAN_BLOCK_ITEMS - 1) / PGX_SCAN_BLOCK_ITEMS;
@@ -224,14 +226,23 @@ static void scan_excl(int mode, const void *in, uint64_t n, uint64_t min_len, ui
     uint64_t *sums = tmp.as<uint64_t>();
     hipLaunchKernelGGL(pgx_scan_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, mode, in, n, min_len, sums);
     hipLaunchKernelGGL(pgx_scan_sums_kernel, dim3(1), dim3(256), 0, s, sums, nb);
-    hipLaunchKernelGGL(pgx_scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, mode, in, n, min_len, (const uint64_t *)sums, nb, out);
+    hipLaunchKernelGGL(pgx_scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, mode, in, n, min_len, (const uint64_t *)sums, nb, out, total_out);
     HIPCHECK(hipGetLastError());
 }
 
+// scalars the host needs to size the next buffer: device -> a small pinned buffer (a pageable destination makes every such
+// copy a staged, blocking transfer) -> caller.  One buffer per host thread.
+static void read_scalars(void *dst, const void *dptr, size_t bytes, hipStream_t s) {
+    static thread_local void *pin = nullptr;
+    if (!pin) HIPCHECK(hipHostMalloc(&pin, 256, hipHostMallocPortable));
+    if (bytes > 256) throw Error(PGX_ERR_ARG, "read_scalars: too many bytes");
+    HIPCHECK(hipMemcpyAsync(pin, dptr, bytes, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    std::memcpy(dst, pin, bytes);
+}
 static uint64_t read_u64(const uint64_t *dptr, hipStream_t s) {
     uint64_t v = 0;
-    HIPCHECK(hipMemcpyAsync(&v, dptr, 8, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
+    read_scalars(&v, dptr, 8, s);
     return v;
 }
 
@@ -255,7 +266,7 @@ struct TagWork {
 };
 
 // counters: d_nover overflow count, d_nbig[0] big-list length, d_nbig[1] large-list length, d_nbig[2] largest
-// run count on the large list (all zeroed by the caller)
+// run count on the large list, d_nbig[3] / d_nbig[4] totals of the two scans (all zeroed by the caller; read back together)
 template <class Rec>
 static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const uint64_t *d_qs, const uint64_t *d_qe, uint64_t m,
                          TagWork &w, unsigned long long *d_nover, unsigned long long *d_nbig, hipStream_t s, Rec &&rec) {
@@ -272,14 +283,11 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
                            w.run_nums.as<uint64_t>(), w.first_item.as<uint64_t>(), w.need.as<uint64_t>(), w.big_list.as<uint64_t>(), d_nbig, d_nbig + 1);
         HIPCHECK(hipGetLastError());
     }
-    scan_excl(1, w.run_nums.p, m, 0, w.seg_off.as<uint64_t>(), w.scan_tmp, s);
-    scan_excl(1, w.need.p, m, 0, w.scratch_off.as<uint64_t>(), w.scan_tmp, s);
-    uint64_t hv[5] = {0, 0, 0, 0, 0};
-    HIPCHECK(hipMemcpyAsync(&hv[0], w.seg_off.as<uint64_t>() + m, 8, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipMemcpyAsync(&hv[1], w.scratch_off.as<uint64_t>() + m, 8, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipMemcpyAsync(&hv[2], d_nbig, 24, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
-    const uint64_t G = hv[0], S = hv[1], nbig = hv[2], nlarge = hv[3];
+    scan_excl(1, w.run_nums.p, m, 0, w.seg_off.as<uint64_t>(), w.scan_tmp, s, reinterpret_cast<uint64_t *>(d_nbig + 3));
+    scan_excl(1, w.need.p, m, 0, w.scratch_off.as<uint64_t>(), w.scan_tmp, s, reinterpret_cast<uint64_t *>(d_nbig + 4));
+    uint64_t hv[5] = {0, 0, 0, 0, 0}; // nbig, nlarge, largest large run count, G, S
+    read_scalars(hv, d_nbig, 40, s);
+    const uint64_t G = hv[3], S = hv[4], nbig = hv[0], nlarge = hv[1];
     w.n_big = nbig;
     rec(0);
     w.gbuf.ensure((G ? G : 1) * 8);
@@ -300,7 +308,7 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
     if (nlarge) {
         const uint64_t *large = w.big_list.as<uint64_t>() + (m - nlarge); // the back of the shared list array
         uint64_t p2max = 64;
-        while (p2max < hv[4] && p2max < PGX_SORT_WG_LDS_CAP) p2max <<= 1;
+        while (p2max < hv[2] && p2max < PGX_SORT_WG_LDS_CAP) p2max <<= 1;
         const size_t lds = (size_t)p2max * 8; // smaller segments -> more workgroups per CU
         // opt in to > 64 KiB of dynamic LDS (per device; cheap enough to repeat)
         HIPCHECK(hipFuncSetAttribute((const void *)pgx_tag_sort_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -582,7 +590,8 @@ struct pgx_batch {
     uint64_t n_reads = 0, read_bytes = 0;
     std::vector<uint64_t> h_offsets; // rebased host copy (chunk planning)
     std::vector<pgx_chunk> chunks;   // plan of the last run (reused while min_len / budget are unchanged)
-    bool plan_valid = false;
+    bool plan_valid = false, slot_off_valid = false;
+    uint64_t slot_off_min_len = 0;
     uint64_t plan_min_len = 0, plan_budget = 0;
     DevBuf reads, offsets;
     // run state
@@ -620,6 +629,7 @@ static void batch_upload(pgx_batch *b, const uint8_t *reads, const uint64_t *off
     b->n_reads = n_reads;
     b->ran = b->ran_tags = false;
     b->plan_valid = false;
+    b->slot_off_valid = false;
     const uint64_t lo = offsets[0], hi = offsets[n_reads];
     b->read_bytes = hi - lo;
     // device offsets are rebased to 0; 16 bytes of zero padding after the last read
@@ -688,8 +698,8 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     b->n_mems = b->n_positions = b->n_ext = b->n_tag_overflow = 0;
     std::memset(&b->timing, 0, sizeof b->timing);
 
-    b->counters.ensure(128); // [0..7] as listed below, [8] heavy reads handed on by the current find_mems launch
-    HIPCHECK(hipMemsetAsync(b->counters.p, 0, 128, s));
+    b->counters.ensure(256); // [0] extensions [1] tag overflows [5] read cursor [3,6,7] stats builds [8] heavy reads [16..20] tag stage
+    HIPCHECK(hipMemsetAsync(b->counters.p, 0, 256, s));
     unsigned long long *d_next = b->counters.as<unsigned long long>();
     unsigned long long *d_nover = d_next + 1;
 
@@ -697,7 +707,11 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     // 1. worst-case MEM slots per read: cap = min(len, len - min_len + 1).  The slot buffer is bounded by
     //    a budget; batches whose worst case exceeds it are processed in chunks of consecutive reads.
     b->slot_off.ensure((n + 1) * 8);
-    scan_excl(2, b->offsets.p, n, min_len, b->slot_off.as<uint64_t>(), b->scan_tmp, s);
+    if (!b->slot_off_valid || b->slot_off_min_len != min_len) { // depends on the reads and min_len only: kept across runs
+        scan_excl(2, b->offsets.p, n, min_len, b->slot_off.as<uint64_t>(), b->scan_tmp, s);
+        b->slot_off_valid = true;
+        b->slot_off_min_len = min_len;
+    }
     b->mem_count.ensure((n ? n : 1) * 4);
     b->mem_off.ensure((n + 1) * 8);
     uint64_t budget_slots = (16ull << 30) / sizeof(pgx_mem);
@@ -744,12 +758,11 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         b->heavy_list.ensure((size_t)PGX_FM_HEAVY_CAP * sizeof(pgx_heavy_item));
         b->heavy_scratch.ensure((size_t)PGX_FM_HEAVY_GRID * PGX_FM_HEAVY_MAXLEN * sizeof(PgxHeavyResult));
     }
-    unsigned long long *d_cursor = d_next + 5; // counters: [0] extensions [1] tag overflows [2] big [3] large [4] max large [5] read cursor
+    unsigned long long *d_cursor = d_next + 5; // counters layout: see the allocation above
     for (size_t ci = 0; ci < chunks.size(); ci++) {
         const pgx_chunk &c = chunks[ci];
         const uint64_t cn = c.r1 - c.r0;
-        unsigned long long start = c.r0;
-        HIPCHECK(hipMemcpyAsync(d_cursor, &start, 8, hipMemcpyHostToDevice, s));
+        if (ci) HIPCHECK(hipMemsetAsync(d_cursor, 0, 8, s)); // the cursor counts reads of this chunk from 0
         record(b, 1, s);
         unsigned grid = grid_for(cn, 64);
         int wg = occ;
@@ -763,7 +776,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         {
             const uint8_t *a_reads = b->reads.as<uint8_t>();
             const uint64_t *a_off = b->offsets.as<uint64_t>(), *a_slot_off = b->slot_off.as<uint64_t>();
-            uint64_t a_n = c.r1, a_min_len = min_len, a_min_occ = min_occ, a_base = c.slot_base;
+            uint64_t a_n = c.r1, a_min_len = min_len, a_min_occ = min_occ, a_base = c.slot_base, a_first = c.r0;
             pgx_mem *a_slots = b->slots.as<pgx_mem>();
             uint32_t *a_cnt = b->mem_count.as<uint32_t>();
             unsigned long long *a_next = d_next, *a_cur = d_cursor;
@@ -771,7 +784,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             uint32_t a_hext = heavy_ext, a_hcap = PGX_FM_HEAVY_CAP;
             pgx_heavy_item *a_hlist = b->heavy_list.as<pgx_heavy_item>();
             unsigned long long *a_hcount = d_heavy_count;
-            void *args[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_base,
+            void *args[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_first, &a_base,
                             &a_hext, &a_hcap, &a_hlist, &a_hcount};
             if (heavy_ext && ci) HIPCHECK(hipMemsetAsync(d_heavy_count, 0, 8, s));
             HIPCHECK(hipLaunchKernel(kfn, dim3(grid), dim3(PGX_FM_THREADS), args, b->dimg->lds_bytes, s)); // one of the four variants
@@ -818,7 +831,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     record(b, 3, s);
     // 4. tag queries (find_mems.cpp:129)
     if (want_tags) {
-        unsigned long long *d_nbig = d_next + 2;
+        unsigned long long *d_nbig = d_next + 16;
         tag_pipeline(img, b->mems.as<pgx_mem>(), nullptr, nullptr, b->n_mems, b->tw, d_nover, d_nbig, s,
                      [&](int stage) { record(b, 4 + stage, s); });
         b->n_positions = b->tw.n_positions;
