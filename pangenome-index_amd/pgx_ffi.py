@@ -11,7 +11,7 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "libpgx.so")
+LIB_PATH = os.environ.get("PGX_LIB") or os.path.join(PKG_DIR, "libpgx.so")  # PGX_LIB: sanitizer build (scripts/asan_host.sh)
 
 OK, ERR_IO, ERR_FORMAT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_ARG, ERR_NOMEM = range(8)
 MODE_COMPAT, MODE_STRICT = 0, 1
