@@ -260,3 +260,47 @@ def test_sigma6_pangenome_both_images(workdir):
             idx = P.Index(ri_path, tags_path, mode=mode)
             _assert_same(idx.find_mems(cat, offs, min_len, min_occ, tags=True), strict if mode & 1 else ref, True)
             idx.close()
+
+
+def test_long_and_ragged_reads(workdir):
+    """reads from 1 to 12 000 bp in one batch (beyond the heavy-read length limit, many slots per read), both layouts"""
+    text = os.path.join(workdir, "long_reads.txt")
+    W.synth_pangenome_text(text, base_len=50000, n_hap=3, seed=21, n_runs=2, n_run_len=(100, 1500))
+    ri_path, tags_path = W.build_index_from_text(text, workdir, "long_reads")[:2]
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    seqs = W.load_sequences(text)
+    rng = np.random.default_rng(8)
+    reads = []
+    for ln in [1, 2, 19, 20, 21, 150, 151, 1000, 4095, 4096, 4097, 12000] + [int(v) for v in rng.integers(1, 6000, 120)]:
+        s = seqs[int(rng.integers(0, len(seqs)))]
+        a = int(rng.integers(0, len(s) - ln))
+        r = np.array(s[a:a + ln])
+        flip = rng.random(ln) < 0.01
+        r[flip] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(flip.sum()))]
+        reads.append(bytes(r))
+    reads += [bytes(seqs[1][-2048:]), bytes(seqs[0][-700:])]  # sequence ends: quadratic reads for the heavy-read kernel
+    cat, offs = O.pack_reads(reads)
+    for min_len, min_occ in [(20, 1), (300, 2)]:
+        ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, threads=O.lib().orc_max_threads())
+        for force in (P.MODE_IMAGE_DENSE, P.MODE_IMAGE_RL):
+            idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | force)
+            _assert_same(idx.find_mems(cat, offs, min_len, min_occ, tags=True), ref, True)
+            idx.close()
+
+
+def test_batch_reuse_and_parameter_changes(xenc, golden):
+    """one long-lived batch: new reads (fewer, then more), then the same reads under other (min_len, min_occ): cached
+    slot offsets and chunk plans must follow"""
+    idx, ri, tags = xenc
+    seqs = W.load_sequences(os.path.join(golden, "x.newline_separated"))
+    sets = [W.sample_reads(seqs, n, ln, seed=70 + i) for i, (n, ln) in enumerate([(5000, 150), (100, 60), (20000, 150), (3, 150)])]
+    b = idx.batch(*sets[0])
+    try:
+        for i, (cat, offs) in enumerate(sets):
+            if i:
+                b.upload(cat, offs)
+            for min_len, min_occ in [(10, 1), (5, 1), (10, 1), (12, 3)]:
+                b.run(min_len, min_occ, P.RUN_TAGS)
+                _assert_same(b.result(), O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, threads=O.lib().orc_max_threads()), True)
+    finally:
+        b.free()
