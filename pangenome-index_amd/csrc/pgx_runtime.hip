@@ -719,13 +719,17 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     if (!b->plan_valid || b->plan_min_len != min_len || b->plan_budget != budget_slots) { // cached across runs
         b->chunks.clear();
         uint64_t r0 = 0, base = 0, acc = 0;
-        for (uint64_t i = 0; i < n; i++) {
-            const uint64_t len = b->h_offsets[i + 1] - b->h_offsets[i];
-            const uint64_t cap = len < min_len ? 0 : std::min<uint64_t>(len, len - min_len + 1);
-            if (acc && acc + cap > budget_slots) { b->chunks.push_back({r0, i, base, acc}); r0 = i; base += acc; acc = 0; }
-            acc += cap;
+        // the slots of a read never exceed its length: a batch whose bytes fit the budget is one chunk, no per-read loop
+        if (n && b->read_bytes <= budget_slots) b->chunks.push_back({0, n, 0, std::max<uint64_t>(b->read_bytes, 1)});
+        else {
+            for (uint64_t i = 0; i < n; i++) {
+                const uint64_t len = b->h_offsets[i + 1] - b->h_offsets[i];
+                const uint64_t cap = len < min_len ? 0 : std::min<uint64_t>(len, len - min_len + 1);
+                if (acc && acc + cap > budget_slots) { b->chunks.push_back({r0, i, base, acc}); r0 = i; base += acc; acc = 0; }
+                acc += cap;
+            }
+            if (n) b->chunks.push_back({r0, n, base, acc});
         }
-        if (n) b->chunks.push_back({r0, n, base, acc});
         b->plan_valid = true; b->plan_min_len = min_len; b->plan_budget = budget_slots;
     }
     const std::vector<pgx_chunk> &chunks = b->chunks;
