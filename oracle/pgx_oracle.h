@@ -11,8 +11,10 @@
  *   (1) byte-exact parsing of the reference's own fixtures (xy.ri, xy_bidirectional_compressed.tags),
  *   (2) the known answers of SURVEY.md section 8c (tests/test_oracle.py),
  *   (3) brute-force substring-count truth in ORC_MODE_STRICT.
- * The reference's own tests hold no golden vector for find_all_mems or the tag queries, therefore
- * MEM parity is "restatement-derived / unpinned by a reference binary" (DESIGN.md says the same).
+ *   (4) the reference's own Locate_* tests (tests/test_rindex.cpp:103-244) for the locate functions: decompressDA must
+ *       equal the document array of a brute-force BWT (tests/test_locate.py).
+ * The reference's own tests hold no golden vector for find_all_mems or the tag queries and no reference binary can be
+ * built here: for those two functions this oracle is "parity unpinned" (restatement-derived; DESIGN.md says the same).
  *
  * Every function cites the reference file:line it follows (paths relative to /root/reference).
  */
