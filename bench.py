@@ -259,7 +259,7 @@ def run_chrom(args, rank, world, local, wd, barrier, dist, red_dev):
         parts = {}
         for c in owners[rank]:
             batches[c].run(args.min_len, args.min_occ, 0, stream)
-            parts[c] = batches[c].result()
+            parts[c] = batches[c].device_result() if dev == "cuda" else batches[c].result()  # nccl: records stay in HBM
         return S.exchange_mems(parts, args.reads, K, dist=dist if world > 1 else None, device=dev)
 
     for _ in range(args.warmup):

@@ -221,6 +221,18 @@ pgx_status pgx_batch_upload(pgx_batch *b, const uint8_t *reads, const uint64_t *
 pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min_occ, uint32_t flags, void *stream);
 /* Copy the results of the last run to host memory owned by the batch (valid until next run/free) */
 pgx_status pgx_batch_result(pgx_batch *b, pgx_result *out);
+/* The results of the last run where they are: device pointers into buffers owned by the batch (valid until the next
+ * run / upload / free; the run has completed when pgx_batch_run returns).  For consumers that stay on the GPU, e.g.
+ * the RCCL exchange of the chromosome-sharded mode, instead of pgx_batch_result's copy to host memory. */
+typedef struct {
+    uint64_t n_reads, n_mems, n_positions;
+    const uint64_t *mem_offsets;    /* n_reads + 1 */
+    const pgx_mem *mems;            /* n_mems */
+    const uint64_t *tag_run_counts; /* n_mems        (NULL when the run had no PGX_RUN_TAGS) */
+    const uint64_t *pos_offsets;    /* n_mems + 1    (NULL ...) */
+    const uint64_t *positions;      /* n_positions   (NULL ...) */
+} pgx_device_result;
+pgx_status pgx_batch_device_result(pgx_batch *b, pgx_device_result *out);
 /* Device-side totals of the last run without downloading arrays */
 pgx_status pgx_batch_counts(pgx_batch *b, uint64_t *n_mems, uint64_t *n_positions, uint64_t *n_extensions);
 pgx_status pgx_batch_timing(pgx_batch *b, pgx_timing *out);

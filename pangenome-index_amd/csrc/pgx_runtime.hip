@@ -868,6 +868,24 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     PGX_GUARD_END
 }
 
+extern "C" pgx_status pgx_batch_device_result(pgx_batch *b, pgx_device_result *out) {
+    PGX_GUARD_BEGIN
+    if (!b || !out || !b->ran) throw Error(PGX_ERR_ARG, "pgx_batch_device_result: batch has not been run");
+    std::memset(out, 0, sizeof *out);
+    out->n_reads = b->n_reads;
+    out->n_mems = b->n_mems;
+    out->mem_offsets = b->mem_off.as<uint64_t>();
+    out->mems = b->mems.as<pgx_mem>();
+    if (b->ran_tags) {
+        out->n_positions = b->n_positions;
+        out->tag_run_counts = b->tw.run_nums.as<uint64_t>();
+        out->pos_offsets = b->tw.pos_off.as<uint64_t>();
+        out->positions = b->tw.positions.as<uint64_t>();
+    }
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
 extern "C" pgx_status pgx_batch_counts(pgx_batch *b, uint64_t *n_mems, uint64_t *n_positions, uint64_t *n_extensions) {
     PGX_GUARD_BEGIN
     if (!b || !b->ran) throw Error(PGX_ERR_ARG, "pgx_batch_counts: batch has not been run");

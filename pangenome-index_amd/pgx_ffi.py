@@ -44,6 +44,20 @@ class Result(C.Structure):
     ]
 
 
+class DeviceResult(C.Structure):
+    _fields_ = [("n_reads", u64), ("n_mems", u64), ("n_positions", u64), ("mem_offsets", p), ("mems", p),
+                ("tag_run_counts", p), ("pos_offsets", p), ("positions", p)]
+
+
+class DeviceArray:
+    """a device buffer owned by a batch, exposed through __cuda_array_interface__ (zero copy: torch.as_tensor(a, device="cuda"));
+    64-bit unsigned values are presented as int64"""
+
+    def __init__(self, ptr, shape, owner):
+        self.owner = owner  # keeps the batch alive
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<i8", "data": (int(ptr or 0), False), "version": 2, "strides": None}
+
+
 class Timing(C.Structure):
     _fields_ = [
         ("ms_find_mems", C.c_float), ("ms_compact", C.c_float), ("ms_tag_locate", C.c_float),
@@ -104,6 +118,7 @@ def lib():
     L.pgx_batch_run.argtypes = [p, u64, u64, u32, p]
     L.pgx_batch_result.argtypes = [p, C.POINTER(Result)]
     L.pgx_batch_counts.argtypes = [p, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    L.pgx_batch_device_result.argtypes = [p, C.POINTER(DeviceResult)]
     L.pgx_batch_timing.argtypes = [p, C.POINTER(Timing)]
     L.pgx_batch_free.argtypes = [p]
     L.pgx_batch_free.restype = None
@@ -304,6 +319,20 @@ class Batch:
             out["tag_run_counts"] = _u64_array(r.tag_run_counts, m)
             out["pos_offsets"] = _u64_array(r.pos_offsets, m + 1)
             out["positions"] = _u64_array(r.positions, int(r.n_positions))
+        return out
+
+    def device_result(self):
+        """results of the last run as device arrays (valid until the next run / upload / free): mem_offsets int64[n + 1],
+        mems int64[n_mems, 4] (start, end, bwt_start, size), and with tags tag_run_counts / pos_offsets / positions"""
+        r = DeviceResult()
+        _check(self.L.pgx_batch_device_result(self.b, C.byref(r)))
+        n, m = int(r.n_reads), int(r.n_mems)
+        out = dict(device=True, n_reads=n, n_mems=m, mem_offsets=DeviceArray(r.mem_offsets, (n + 1,), self),
+                   mems=DeviceArray(r.mems, (m, 4), self))
+        if r.pos_offsets:
+            out["tag_run_counts"] = DeviceArray(r.tag_run_counts, (m,), self)
+            out["pos_offsets"] = DeviceArray(r.pos_offsets, (m + 1,), self)
+            out["positions"] = DeviceArray(r.positions, (int(r.n_positions),), self)
         return out
 
     def free(self):

@@ -78,10 +78,15 @@ def exchange_mems(local, n_reads, n_chroms, dist=None, device="cpu"):
     counts = torch.zeros((max_local, n_reads), dtype=torch.int64, device=device)
     recs = []
     for k, c in enumerate(mine):
-        mo = local[c]["mem_offsets"].astype(np.int64)
-        counts[k] = torch.from_numpy(mo[1:] - mo[:-1]).to(device)
-        recs.append(np.ascontiguousarray(local[c]["mems"]).view(np.int64).reshape(-1, 4))
-    rec = torch.from_numpy(np.concatenate(recs) if recs else np.zeros((0, 4), np.int64)).to(device)
+        if local[c].get("device"):  # Batch.device_result(): the arrays are already in HBM, no host staging
+            mo = torch.as_tensor(local[c]["mem_offsets"], device=device)
+            counts[k] = mo[1:] - mo[:-1]
+            recs.append(torch.as_tensor(local[c]["mems"], device=device) if local[c]["n_mems"] else torch.zeros((0, 4), dtype=torch.int64, device=device))
+        else:
+            mo = local[c]["mem_offsets"].astype(np.int64)
+            counts[k] = torch.from_numpy(mo[1:] - mo[:-1]).to(device)
+            recs.append(torch.from_numpy(np.ascontiguousarray(local[c]["mems"]).view(np.int64).reshape(-1, 4).copy()).to(device))
+    rec = torch.cat(recs) if recs else torch.zeros((0, 4), dtype=torch.int64, device=device)
     m_local = torch.tensor([rec.shape[0]], dtype=torch.int64, device=device)
     if dist is not None:
         all_counts = [torch.zeros_like(counts) for _ in range(world)]

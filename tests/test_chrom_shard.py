@@ -100,3 +100,27 @@ def test_exchange_with_hip_engine(workdir):
     local = {c: P.Index(paths[c]).find_mems(cat, offs, 5, 1) for c in range(3)}
     got = S.exchange_mems(local, len(offs) - 1, 3)
     assert np.array_equal(got[0], mo) and got[1].tobytes() == mems.tobytes() and np.array_equal(got[2], shard)
+    # device-resident variant: the batches' device buffers go into the exchange without host staging (what the nccl path
+    # does).  In its own process with torch imported first, as bench.py does: torch's bundled HIP runtime does not
+    # initialise once the system runtime behind libpgx.so owns the device.
+    exp = os.path.join(workdir, "chrom_expected.npz")
+    np.savez(exp, mo=mo, mems=mems.view(np.int64), shard=shard, cat=cat, offs=offs, paths=np.array(paths))
+    code = """
+import sys, numpy as np, torch
+torch.cuda.init()
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import pgx_ffi as P, pgx_shard as S
+z = np.load(%r)
+paths, cat, offs = [str(p) for p in z["paths"]], z["cat"], z["offs"]
+idx = [P.Index(p) for p in paths]
+batches = [i.batch(cat, offs) for i in idx]
+for b in batches:
+    b.run(5, 1, 0)
+dev_local = {c: batches[c].device_result() for c in range(3)}
+assert all(d["device"] for d in dev_local.values())
+got = S.exchange_mems(dev_local, len(offs) - 1, 3, device="cuda")
+assert np.array_equal(got[0], z["mo"]) and np.array_equal(got[1].view(np.int64), z["mems"]) and np.array_equal(got[2], z["shard"])
+print("device exchange ok", sum(d["n_mems"] for d in dev_local.values()))
+""" % (os.path.dirname(os.path.abspath(P.__file__)), os.path.dirname(os.path.abspath(__file__)), exp)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "device exchange ok" in r.stdout, r.stdout + r.stderr
