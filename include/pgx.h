@@ -135,6 +135,19 @@ pgx_status pgx_write_compact_tags(const char *out_path, const uint64_t *values,
  * compact = 0: ByteCode format (load_compressed_tags, tag_arrays.cpp:739); 1: sdsl-compact (find_mems.cpp:79). */
 pgx_status pgx_convert_tags(const char *in_path, const char *out_path, int compact);
 
+/* merge_tags equivalent (src/merge_tags.cpp): per-chromosome tag streams (build_tags' "algorithm format": ByteCode runs
+ * offset:10 | rev:1 | len:9 | node<<20, with or without the 8-byte int_vector<8> header of sdsl::int_vector_buffer) ->
+ * the whole-genome tag array in the sdsl-compact query format find_mems loads.  `ri_path` is the whole-genome r-index;
+ * seq_to_file[s] (n_seq = tot_strings entries) names the tag file of sequence s -- the reference derives this from the
+ * GBZ (first node of path s -> weakly connected component -> the file whose first tag lies in that component,
+ * merge_tags.cpp:478-512); a GBZ reader is out of scope here, so the caller states it.  Runs on `device`: document
+ * array by the locate kernels, one scan + gather per file, run-length encoding.  Merged runs are maximal (the reference
+ * counts them in a uint16_t, which wraps beyond 65 535) and split at 511 like append_compact_run_streamed
+ * (src/tag_arrays.cpp:940-974).  PGX_ERR_FORMAT when a file holds a different number of tags than the BWT has
+ * positions of its sequences. */
+pgx_status pgx_merge_tags(const char *ri_path, const char *const *tag_paths, uint32_t n_files, const uint32_t *seq_to_file,
+                          uint64_t n_seq, int device, const char *out_path);
+
 /* ---- primitives (tests; mirror the public FastLocate / TagArray query API) ----------------- */
 /* FastLocate::rank_at_cached_encoded (src/r-index.cpp:619-641): out[i*6 .. i*6+sigma) per position;
  * entries >= sigma are zero.  true_codes!=0 returns the six true code ranks instead. */

@@ -109,4 +109,14 @@ __global__ void pgx_locate_walk_kernel(PgxLocImage loc, const uint64_t *qs, cons
                                        const uint64_t *run0, const uint64_t *piece_off, uint64_t n_pieces, const uint64_t *val_off,
                                        int seq_ids, uint64_t *out);
 
+// merge_tags passes (pgx_merge_kernels.hip)
+__global__ void pgx_mt_file_of_kernel(const uint64_t *da, uint64_t n, uint64_t n_seq, const uint32_t *seq_to_file, uint32_t n_files,
+                                      uint8_t *file_of, unsigned long long *n_bad);
+__global__ void pgx_mt_expand_kernel(const uint64_t *start, const uint64_t *val, uint64_t n_runs, uint64_t *out);
+__global__ void pgx_mt_gather_kernel(const uint8_t *file_of, uint32_t f, const uint64_t *rank, const uint64_t *expanded, uint64_t total,
+                                     uint64_t n, uint64_t *tags);
+__global__ void pgx_mt_flags_kernel(const uint64_t *tags, uint64_t n, uint64_t n_seq, uint8_t *flags);
+__global__ void pgx_mt_compact_kernel(const uint64_t *tags, const uint8_t *flags, const uint64_t *idx, uint64_t n, uint64_t n_seq,
+                                      uint64_t *out_val, uint64_t *out_start);
+
 #define PGX_SCAN_BLOCK_ITEMS 2048 // 256 threads x 8 items (pgx_kernels.hip PGX_SCAN_ITEMS)

@@ -581,6 +581,105 @@ extern "C" pgx_status pgx_decompress_sa(pgx_index *h, int device, uint32_t flags
 }
 
 // ------------------------------------------------------------------------------------------
+// merge_tags (pgx_merge_kernels.hip)
+extern "C" pgx_status pgx_merge_tags(const char *ri_path, const char *const *tag_paths, uint32_t n_files, const uint32_t *seq_to_file,
+                                     uint64_t n_seq, int device, const char *out_path) {
+    PGX_GUARD_BEGIN
+    if (!ri_path || !tag_paths || !seq_to_file || !out_path) throw Error(PGX_ERR_ARG, "pgx_merge_tags: null argument");
+    if (n_files == 0 || n_files > 250) throw Error(PGX_ERR_ARG, "pgx_merge_tags: between 1 and 250 tag files");
+    pgx_index *h = nullptr;
+    if (pgx_index_open(ri_path, nullptr, PGX_TAGS_AUTO, PGX_MODE_STRICT | PGX_MODE_IMAGE_RL, &h) != PGX_OK) return PGX_ERR_FORMAT; // message already set
+    std::unique_ptr<pgx_index, void (*)(pgx_index *)> guard(h, pgx_index_close);
+    const uint64_t n = h->ri.sequence_size, tot = h->ri.C.size() > 1 ? h->ri.C[1] - h->ri.C[0] : 0;
+    if (n_seq != tot) throw Error(PGX_ERR_ARG, "pgx_merge_tags: seq_to_file has " + std::to_string(n_seq) + " entries, the index holds " +
+                                                   std::to_string(tot) + " sequences");
+    pgx_device_image *d = locate_image(h, device);
+    DevBuf da, file_of, tags, rank, scan_tmp, s2f, ctr, rstart, rval, expanded, flags, out_val, out_start;
+    DevBuf *all[] = {&da, &file_of, &tags, &rank, &scan_tmp, &s2f, &ctr, &rstart, &rval, &expanded, &flags, &out_val, &out_start};
+    std::vector<uint64_t> h_val, h_start;
+    try {
+        hipStream_t s = nullptr;
+        // 1. document array of the whole BWT
+        {
+            const uint64_t first = 0, last = n ? n - 1 : 0;
+            std::vector<uint64_t> off;
+            uint64_t nv = 0;
+            if (n) locate_core(h, d, &first, &last, 1, PGX_LOCATE_SEQ_IDS, off, da, nv);
+        }
+        // 2. file of every position
+        file_of.ensure(n ? n : 1); tags.ensure((n ? n : 1) * 8); rank.ensure((n + 1) * 8); s2f.ensure((n_seq ? n_seq : 1) * 4); ctr.ensure(64);
+        HIPCHECK(hipMemsetAsync(ctr.p, 0, 64, s));
+        HIPCHECK(hipMemsetAsync(tags.p, 0, (n ? n : 1) * 8, s));
+        if (n_seq) HIPCHECK(hipMemcpyAsync(s2f.p, seq_to_file, n_seq * 4, hipMemcpyHostToDevice, s));
+        if (n) {
+            hipLaunchKernelGGL(pgx_mt_file_of_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, da.as<uint64_t>(), n, n_seq, s2f.as<uint32_t>(), n_files,
+                               file_of.as<uint8_t>(), ctr.as<unsigned long long>());
+            HIPCHECK(hipGetLastError());
+        }
+        if (read_u64(ctr.as<uint64_t>(), s)) throw Error(PGX_ERR_ARG, "pgx_merge_tags: seq_to_file names a file index >= n_files");
+        da.release();
+        // 3. per file: expanded stream, rank of its positions, gather
+        for (uint32_t f = 0; f < n_files; f++) {
+            if (!tag_paths[f]) throw Error(PGX_ERR_ARG, "pgx_merge_tags: null tag path");
+            std::vector<uint8_t> raw = read_whole_file(tag_paths[f]);
+            uint64_t loc = 0;
+            if (raw.size() >= 8) { // int_vector<8> header (bit count) of sdsl::int_vector_buffer<8>, merge_tags.cpp:207
+                uint64_t bits = 0;
+                std::memcpy(&bits, raw.data(), 8);
+                if (bits == (raw.size() - 8) * 8) loc = 8;
+            }
+            std::vector<uint64_t> st(1, 0), vl;
+            while (loc < raw.size()) {
+                const uint64_t v = bytecode_read(raw.data(), raw.size(), loc, "tag run");
+                const uint64_t len = (v >> 11) & 0x1FF; // decode_run, length_bits = 9 (src/tag_arrays.cpp:59-70)
+                if (!len) continue;
+                vl.push_back((v & 0x7FF) | ((v >> 20) << 11)); // offset | rev << 10 | node << 11
+                st.push_back(st.back() + len);
+            }
+            const uint64_t nr = vl.size(), total = st.back();
+            scan_excl(3, file_of.p, n, f, rank.as<uint64_t>(), scan_tmp, s);
+            const uint64_t have = read_u64(rank.as<uint64_t>() + n, s);
+            if (have != total)
+                throw Error(PGX_ERR_FORMAT, std::string("pgx_merge_tags: ") + tag_paths[f] + " holds " + std::to_string(total) + " tags, the BWT has " +
+                                                std::to_string(have) + " positions of its sequences");
+            if (!total) continue;
+            rstart.ensure((nr + 1) * 8); rval.ensure(nr * 8); expanded.ensure(total * 8);
+            HIPCHECK(hipMemcpyAsync(rstart.p, st.data(), (nr + 1) * 8, hipMemcpyHostToDevice, s));
+            HIPCHECK(hipMemcpyAsync(rval.p, vl.data(), nr * 8, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(pgx_mt_expand_kernel, dim3(grid_for(nr, 256)), dim3(256), 0, s, rstart.as<uint64_t>(), rval.as<uint64_t>(), nr,
+                               expanded.as<uint64_t>());
+            hipLaunchKernelGGL(pgx_mt_gather_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, file_of.as<uint8_t>(), f, rank.as<uint64_t>(),
+                               expanded.as<uint64_t>(), total, n, tags.as<uint64_t>());
+            HIPCHECK(hipGetLastError());
+            HIPCHECK(hipStreamSynchronize(s)); // st / vl are host vectors read by the async copies
+        }
+        // 4. run-length encode
+        uint64_t n_out = 0;
+        if (n) {
+            flags.ensure(n);
+            hipLaunchKernelGGL(pgx_mt_flags_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, tags.as<uint64_t>(), n, n_seq, flags.as<uint8_t>());
+            scan_excl(4, flags.p, n, 0, rank.as<uint64_t>(), scan_tmp, s);
+            n_out = read_u64(rank.as<uint64_t>() + n, s);
+            out_val.ensure(n_out * 8); out_start.ensure(n_out * 8);
+            hipLaunchKernelGGL(pgx_mt_compact_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, tags.as<uint64_t>(), flags.as<uint8_t>(), rank.as<uint64_t>(),
+                               n, n_seq, out_val.as<uint64_t>(), out_start.as<uint64_t>());
+            HIPCHECK(hipGetLastError());
+            h_val.resize(n_out); h_start.resize(n_out + 1);
+            HIPCHECK(hipMemcpy(h_val.data(), out_val.p, n_out * 8, hipMemcpyDeviceToHost));
+            HIPCHECK(hipMemcpy(h_start.data(), out_start.p, n_out * 8, hipMemcpyDeviceToHost));
+            h_start[n_out] = n;
+        }
+        for (uint64_t i = 0; i < n_out; i++) h_start[i] = h_start[i + 1] - h_start[i]; // lengths
+    } catch (...) {
+        for (DevBuf *b : all) b->release();
+        throw;
+    }
+    for (DevBuf *b : all) b->release();
+    return pgx_write_compact_tags(out_path, h_val.data(), h_start.data(), h_val.size());
+    PGX_GUARD_END
+}
+
+// ------------------------------------------------------------------------------------------
 struct pgx_chunk { uint64_t r0, r1, slot_base, slots; }; // consecutive reads sharing one pass over the slot buffer
 
 struct pgx_batch {

@@ -106,6 +106,7 @@ def lib():
     L.pgx_build_rlbwt.argtypes = [C.c_char_p, C.c_char_p]
     L.pgx_write_compact_tags.argtypes = [C.c_char_p, p, p, u64]
     L.pgx_convert_tags.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    L.pgx_merge_tags.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), u32, p, u64, C.c_int, C.c_char_p]
     L.pgx_rank_batch.argtypes = [p, C.c_int, p, u64, C.c_int, p]
     L.pgx_extend_batch.argtypes = [p, C.c_int, p, p, p, u64, p]
     L.pgx_count_batch.argtypes = [p, C.c_int, p, p, u64, p]
@@ -169,6 +170,14 @@ _VIEW_DTYPES = {0: np.uint8, 1: np.uint64, 2: np.uint64, 3: np.uint64, 4: np.uin
                 8: np.uint64, 9: np.uint64, 10: np.uint32, 11: np.uint64, 12: np.uint64, 13: np.uint32, 14: np.uint8}
 LOCATE_SEQ_IDS, LOCATE_UNIQUE = 1, 2
 NO_POSITION = 0xFFFFFFFFFFFFFFFF
+
+
+def merge_tags(ri_path, tag_paths, seq_to_file, out_path, device=0):
+    """merge_tags: per-chromosome tag streams (algorithm format) -> whole-genome sdsl-compact tag array; seq_to_file[s] =
+    index into tag_paths of the file that holds the tags of sequence s of the whole-genome r-index"""
+    s2f = np.ascontiguousarray(seq_to_file, dtype=np.uint32)
+    arr = (C.c_char_p * len(tag_paths))(*[t.encode() for t in tag_paths])
+    _check(lib().pgx_merge_tags(ri_path.encode(), arr, len(tag_paths), s2f.ctypes.data, len(s2f), device, out_path.encode()))
 
 
 class Index:
