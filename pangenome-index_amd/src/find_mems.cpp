@@ -59,7 +59,10 @@ int main(int argc, char **argv) {
     uint32_t mode = PGX_MODE_COMPAT, tfmt = PGX_TAGS_AUTO;
     size_t batch_reads = 1u << 20;
     bool quiet = false;
-    for (int i = 6; i < argc; i++) {
+    int first_opt = 6;
+    // find_mems_chunked.cpp:15-28 takes an optional sixth positional (chunk_size_mb of its memory-mapped loader): accepted, unused
+    if (argc > 6 && argv[6][0] >= '0' && argv[6][0] <= '9') first_opt = 7;
+    for (int i = first_opt; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> std::string { if (i + 1 >= argc) { std::cerr << "missing value for " << a << std::endl; std::exit(EXIT_FAILURE); } return argv[++i]; };
         if (a == "--device") device = std::stoi(next());
