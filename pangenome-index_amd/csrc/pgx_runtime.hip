@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 #include <array>
 #include <string>
 #include <unordered_map>
@@ -146,8 +147,12 @@ static void upload(DevBuf &b, const void *src, size_t bytes) {
     if (bytes) HIPCHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
 }
 
+// one device image per (index, device), created on first use; concurrent first calls from several host threads are serialised
+static std::mutex g_image_mutex;
+
 static pgx_device_image *device_image(pgx_index *h, int device) {
     use_device(device);
+    std::lock_guard<std::mutex> lock(g_image_mutex);
     if ((int)h->dev.size() <= device) h->dev.resize(device + 1, nullptr);
     if (h->dev[device]) return h->dev[device];
     std::unique_ptr<pgx_device_image> d(new pgx_device_image());
@@ -384,6 +389,7 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
 static pgx_device_image *locate_image(pgx_index *h, int device) {
     if (!h->has_rank) throw Error(PGX_ERR_ARG, "locate: index opened without an r-index");
     pgx_device_image *d = device_image(h, device);
+    std::lock_guard<std::mutex> lock(g_image_mutex);
     if (d->has_loc) return d;
     build_locate_image(h->ri, h->loc);
     const LocHostImage &m = h->loc;

@@ -304,3 +304,33 @@ def test_batch_reuse_and_parameter_changes(xenc, golden):
                 _assert_same(b.result(), O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, threads=O.lib().orc_max_threads()), True)
     finally:
         b.free()
+
+
+def test_concurrent_batches_from_host_threads(x_index, golden):
+    """the index handle is shared by host threads, each with its own batch (SURVEY 8b threading row)"""
+    import threading
+    ri_path, tags_path = x_index
+    idx = P.Index(ri_path, tags_path)  # device image created by whichever thread comes first
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    seqs = W.load_sequences(os.path.join(golden, "x.newline_separated"))
+    work = [W.sample_reads(seqs, 4000 + 500 * t, 150, seed=90 + t) for t in range(4)]
+    refs = [O.find_mems_batch(ri, tags, c, o, 10, 1, threads=4) for c, o in work]
+    errors = []
+
+    def run(t):
+        try:
+            cat, offs = work[t]
+            b = idx.batch(cat, offs)
+            for _ in range(5):
+                b.run(10, 1, P.RUN_TAGS)
+                _assert_same(b.result(), refs[t], True)
+            b.free()
+        except Exception as e:  # noqa: BLE001 -- reported below with the thread id
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
