@@ -72,7 +72,8 @@ __global__ void pgx_compact_mems_kernel(uint64_t first_read, uint64_t n_reads, c
 
 __global__ void pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *mems, const uint64_t *qstart, const uint64_t *qend,
                                       uint64_t n, uint64_t *run_nums, uint64_t *first_item, uint64_t *need, uint64_t *big_list,
-                                      unsigned long long *n_big, unsigned long long *n_large);
+                                      unsigned long long *n_big, unsigned long long *n_large, uint64_t *single, uint64_t *ucount,
+                                      unsigned long long *n_overflow);
 __global__ void pgx_tag_small_kernel(PgxDevImage img, uint64_t n, const uint64_t *run_nums, const uint64_t *first_item,
                                      const uint64_t *seg_off, uint64_t *buf, uint64_t *ucount, unsigned long long *n_overflow);
 __global__ void pgx_tag_gather_kernel(PgxDevImage img, const uint64_t *list, uint64_t n_list, const uint64_t *run_nums,
@@ -88,7 +89,10 @@ __global__ void pgx_tag_copy_dups_kernel(const uint64_t *pairs, uint64_t n_pairs
                                          const uint64_t *run_nums, const uint64_t *seg_off, uint64_t *buf, uint64_t *ucount,
                                          unsigned long long *n_overflow);
 __global__ void pgx_tag_compact_kernel(uint64_t n, const uint64_t *ucount, const uint64_t *seg_off, const uint64_t *buf,
-                                       const uint64_t *pos_off, uint64_t *positions, uint64_t max_count);
+                                       const uint64_t *pos_off, uint64_t *positions, uint64_t max_count, const uint64_t *run_nums,
+                                       int single_done);
+__global__ void pgx_tag_compact_single_kernel(uint64_t n, const uint64_t *run_nums, const uint64_t *single, const uint64_t *pos_off,
+                                              uint64_t *positions);
 __global__ void pgx_tag_compact_list_kernel(const uint64_t *list, uint64_t n_list, const uint64_t *ucount, const uint64_t *seg_off,
                                             const uint64_t *buf, const uint64_t *pos_off, uint64_t *positions, uint64_t max_count);
 #define PGX_TAG_COMPACT_SMALL 256 // segments up to this many unique values are copied by the 16-lane kernel

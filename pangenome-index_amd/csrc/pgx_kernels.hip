@@ -636,12 +636,13 @@ template __global__ void pgx_extend_kernel<true>(PgxDevImage, const pgx_biint *,
 //   mode 0: in32[i]                       (u32 array)
 //   mode 1: in64[i]                       (u64 array)
 //   mode 2: MEM capacity of read i from offsets (min(len, len - min_len + 1), 0 if len < min_len)
-//   mode 3: in8[i] == (uint8_t)min_len  (indicator; merge_tags)        mode 4: in8[i]
+//   mode 3: in8[i] == (uint8_t)min_len  (indicator; merge_tags)        mode 4: in8[i]        mode 5: in64[i], 1 -> 0
 __device__ __forceinline__ uint64_t pgx_scan_load(int mode, const void *in, uint64_t i, uint64_t min_len) {
     if (mode == 0) return ((const uint32_t *)in)[i];
     if (mode == 1) return ((const uint64_t *)in)[i];
     if (mode == 3) return ((const uint8_t *)in)[i] == (uint8_t)min_len ? 1u : 0u;
     if (mode == 4) return ((const uint8_t *)in)[i];
+    if (mode == 5) { const uint64_t v = ((const uint64_t *)in)[i]; return v == 1 ? 0 : v; } // tag segments: single runs need none
     const uint64_t *off = (const uint64_t *)in;
     const uint64_t len = off[i + 1] - off[i];
     if (len < min_len) return 0;

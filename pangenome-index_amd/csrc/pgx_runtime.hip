@@ -261,11 +261,11 @@ static inline unsigned grid_for(uint64_t n, unsigned per_block) {
 // ------------------------------------------------------------------------------------------
 // tag pipeline shared by pgx_batch_run and pgx_tag_query_batch
 struct TagWork {
-    DevBuf run_nums, first_item, seg_off, gbuf, need, scratch_off, scratch, ucount, pos_off, positions, big_list, scan_tmp, dedup;
+    DevBuf run_nums, first_item, seg_off, gbuf, need, scratch_off, scratch, ucount, pos_off, positions, big_list, scan_tmp, dedup, single;
     uint64_t n_positions = 0, n_big = 0;
     void release() {
         DevBuf *all[] = {&run_nums, &first_item, &seg_off, &gbuf, &need, &scratch_off, &scratch, &ucount, &pos_off, &positions,
-                         &big_list, &scan_tmp, &dedup};
+                         &big_list, &scan_tmp, &dedup, &single};
         for (DevBuf *d : all) d->release();
     }
 };
@@ -283,12 +283,14 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
     w.ucount.ensure((m ? m : 1) * 8);
     w.pos_off.ensure((m + 1) * 8);
     w.big_list.ensure((m ? m : 1) * 8);
+    w.single.ensure((m ? m : 1) * 8);
     if (m) {
         hipLaunchKernelGGL(pgx_tag_locate_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, img, d_mems, d_qs, d_qe, m,
-                           w.run_nums.as<uint64_t>(), w.first_item.as<uint64_t>(), w.need.as<uint64_t>(), w.big_list.as<uint64_t>(), d_nbig, d_nbig + 1);
+                           w.run_nums.as<uint64_t>(), w.first_item.as<uint64_t>(), w.need.as<uint64_t>(), w.big_list.as<uint64_t>(), d_nbig, d_nbig + 1,
+                           w.single.as<uint64_t>(), w.ucount.as<uint64_t>(), d_nover);
         HIPCHECK(hipGetLastError());
     }
-    scan_excl(1, w.run_nums.p, m, 0, w.seg_off.as<uint64_t>(), w.scan_tmp, s, reinterpret_cast<uint64_t *>(d_nbig + 3));
+    scan_excl(5, w.run_nums.p, m, 0, w.seg_off.as<uint64_t>(), w.scan_tmp, s, reinterpret_cast<uint64_t *>(d_nbig + 3)); // single runs: no segment
     scan_excl(1, w.need.p, m, 0, w.scratch_off.as<uint64_t>(), w.scan_tmp, s, reinterpret_cast<uint64_t *>(d_nbig + 4));
     uint64_t hv[5] = {0, 0, 0, 0, 0}; // nbig, nlarge, largest large run count, G, S
     read_scalars(hv, d_nbig, 40, s);
@@ -370,7 +372,9 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
         const bool listed = nbig || nlarge; // only listed queries (> 16 runs) can exceed the 16-lane kernel's limit
         hipLaunchKernelGGL(pgx_tag_compact_kernel, dim3(grid_for(m, 16)), dim3(256), 0, s, m, w.ucount.as<uint64_t>(),
                            w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.pos_off.as<uint64_t>(), w.positions.as<uint64_t>(),
-                           listed ? (uint64_t)PGX_TAG_COMPACT_SMALL : ~0ull);
+                           listed ? (uint64_t)PGX_TAG_COMPACT_SMALL : ~0ull, (const uint64_t *)w.run_nums.as<uint64_t>(), 1);
+        hipLaunchKernelGGL(pgx_tag_compact_single_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, m, (const uint64_t *)w.run_nums.as<uint64_t>(),
+                           (const uint64_t *)w.single.as<uint64_t>(), (const uint64_t *)w.pos_off.as<uint64_t>(), w.positions.as<uint64_t>());
         if (nbig)
             hipLaunchKernelGGL(pgx_tag_compact_list_kernel, dim3(grid_for(nbig, 1)), dim3(256), 0, s, (const uint64_t *)w.big_list.as<uint64_t>(), nbig,
                                w.ucount.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.pos_off.as<uint64_t>(),
@@ -514,7 +518,7 @@ static void locate_core(pgx_index *h, pgx_device_image *d, const uint64_t *first
             const uint64_t U = read_u64(duoff.as<uint64_t>() + n, s);
             vals_out.ensure((U ? U : 1) * 8);
             hipLaunchKernelGGL(pgx_tag_compact_kernel, dim3(grid_for(n, 16)), dim3(256), 0, s, n, ducount.as<uint64_t>(), dvoff.as<uint64_t>(),
-                               gbuf.as<uint64_t>(), duoff.as<uint64_t>(), vals_out.as<uint64_t>(), ~0ull);
+                               gbuf.as<uint64_t>(), duoff.as<uint64_t>(), vals_out.as<uint64_t>(), ~0ull, (const uint64_t *)nullptr, 0);
             HIPCHECK(hipGetLastError());
             h_off.resize(n + 1);
             HIPCHECK(hipMemcpy(h_off.data(), duoff.p, (n + 1) * 8, hipMemcpyDeviceToHost));

@@ -36,16 +36,37 @@ __global__ void __launch_bounds__(256)
 pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *__restrict__ mems, const uint64_t *__restrict__ qstart,
                       const uint64_t *__restrict__ qend, uint64_t n, uint64_t *__restrict__ run_nums,
                       uint64_t *__restrict__ first_item, uint64_t *__restrict__ need, uint64_t *__restrict__ big_list,
-                      unsigned long long *__restrict__ n_big, unsigned long long *__restrict__ n_large) {
+                      unsigned long long *__restrict__ n_big, unsigned long long *__restrict__ n_large, uint64_t *__restrict__ single,
+                      uint64_t *__restrict__ ucount, unsigned long long *__restrict__ n_overflow) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint64_t st, en;
     if (mems) { st = mems[i].bwt_start; en = st + (uint64_t)mems[i].size - 1; } // find_mems.cpp:129
     else { st = qstart[i]; en = qend[i]; }
-    const uint64_t f = pgx_tag_rank(img, st), g = pgx_tag_rank(img, en);
+    const uint64_t f = pgx_tag_rank(img, st);
+    // rank of `en`: an interval usually ends inside the run it starts in, so gallop upwards from f (one load when it does)
+    uint64_t g = f;
+    if (en >= st) {
+        const uint64_t nr = img.n_tag_runs;
+        uint64_t step = 1, lo = f, hi = f;
+        while (hi < nr && img.tstart[hi] <= en) { lo = hi + 1; hi = (hi + step < nr) ? hi + step : nr; step <<= 1; }
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (img.tstart[mid] <= en) lo = mid + 1; else hi = mid;
+        }
+        g = lo;
+    } else g = pgx_tag_rank(img, en);
     const uint64_t cnt = g - f + 1;
     run_nums[i] = cnt;
-    first_item[i] = (f % 10) ? f - 1 : f;
+    const uint64_t fi = (f % 10) ? f - 1 : f;
+    first_item[i] = fi;
+    if (cnt == 1) { // one run = one position: the common case (a MEM inside one node); no segment, no sort
+        uint64_t v = 0;
+        if (fi < img.n_tag_items) v = img.tvals[fi];
+        else atomicAdd(n_overflow, 1ull); // the reference reads past the stored runs (UB there): value 0
+        single[i] = v;
+        ucount[i] = 1;
+    }
     uint64_t p2 = 64;
     while (p2 < cnt && p2 < (1ull << 62)) p2 <<= 1;
     need[i] = p2 > PGX_SORT_WG_LDS_CAP ? p2 : 0; // global scratch of the large path
@@ -66,7 +87,8 @@ pgx_tag_small_kernel(PgxDevImage img, uint64_t n, const uint64_t *__restrict__ r
     const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
     const bool valid = q < n;
     const uint64_t cnt = valid ? run_nums[q] : 0;
-    const bool mine = valid && cnt <= PGX_TAG_SMALL;
+    const bool mine = valid && cnt <= PGX_TAG_SMALL && cnt != 1; // single-run queries were answered by the locate kernel
+    if (!__any(mine)) return;
     uint64_t v = ~0ull;
     bool over = false;
     if (mine && (uint64_t)l16 < cnt) {
@@ -256,13 +278,23 @@ pgx_tag_sort_large_kernel(const uint64_t *__restrict__ list, uint64_t n_list, co
 __global__ void __launch_bounds__(256)
 pgx_tag_compact_kernel(uint64_t n, const uint64_t *__restrict__ ucount, const uint64_t *__restrict__ seg_off,
                        const uint64_t *__restrict__ buf, const uint64_t *__restrict__ pos_off, uint64_t *__restrict__ positions,
-                       uint64_t max_count) {
+                       uint64_t max_count, const uint64_t *__restrict__ run_nums, int single_done) {
     const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int l16 = threadIdx.x & 15;
     if (q >= n) return;
+    if (single_done && run_nums[q] == 1) return; // copied by pgx_tag_compact_single_kernel
     const uint64_t c = ucount[q], src = seg_off[q], dst = pos_off[q];
     if (c > max_count) return;
     for (uint64_t t = l16; t < c; t += 16) positions[dst + t] = buf[src + t];
+}
+
+// one thread per query: single-run queries (answered by the locate kernel) go straight to their place
+__global__ void __launch_bounds__(256)
+pgx_tag_compact_single_kernel(uint64_t n, const uint64_t *__restrict__ run_nums, const uint64_t *__restrict__ single,
+                              const uint64_t *__restrict__ pos_off, uint64_t *__restrict__ positions) {
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n || run_nums[q] != 1) return;
+    positions[pos_off[q]] = single[q];
 }
 
 // one workgroup per listed query: the segments pgx_tag_compact_kernel skipped (more than `max_count` values)
