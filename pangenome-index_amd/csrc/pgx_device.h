@@ -62,7 +62,7 @@ __global__ void pgx_count_kernel(PgxDevImage img, const uint8_t *reads, const ui
 __global__ void pgx_scan_partial_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, uint64_t *block_sums);
 __global__ void pgx_scan_sums_kernel(uint64_t *block_sums, uint64_t nb);
 __global__ void pgx_scan_apply_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, const uint64_t *block_sums,
-                                      uint64_t nb, uint64_t *out, uint64_t *total_out);
+                                      uint64_t nb, uint64_t *out, uint64_t *total_out, int raw_sums);
 __global__ void pgx_compact_mems_kernel(uint64_t first_read, uint64_t n_reads, const uint64_t *slot_off, uint64_t slot_base,
                                         const pgx_mem *slots, const uint32_t *mem_count, const uint64_t *local_off,
                                         uint64_t mem_base, pgx_mem *mems);

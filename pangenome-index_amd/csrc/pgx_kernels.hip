@@ -705,9 +705,27 @@ __global__ void __launch_bounds__(256) pgx_scan_sums_kernel(uint64_t *block_sums
 // out has n+1 entries; out[n] = total
 __global__ void __launch_bounds__(256)
 pgx_scan_apply_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, const uint64_t *__restrict__ block_sums,
-                      uint64_t nb, uint64_t *__restrict__ out, uint64_t *__restrict__ total_out) {
+                      uint64_t nb, uint64_t *__restrict__ out, uint64_t *__restrict__ total_out, int raw_sums) {
     __shared__ uint64_t s_wave[4];
     const uint64_t b0 = (uint64_t)blockIdx.x * 256 * PGX_SCAN_ITEMS;
+    // raw_sums: block_sums holds the per-block totals as pgx_scan_partial_kernel wrote them (few blocks: every block adds up
+    // the totals before it, which saves the single-block launch in between); otherwise their exclusive scan + grand total
+    uint64_t base, grand = 0;
+    if (raw_sums) {
+        uint64_t part = 0, all = 0;
+        for (uint64_t i = threadIdx.x; i < nb; i += 256) {
+            const uint64_t t = block_sums[i];
+            part += i < blockIdx.x ? t : 0;
+            all += t;
+        }
+        uint64_t tot;
+        (void)pgx_block_excl_scan(part, s_wave, tot);
+        base = tot;
+        if (blockIdx.x == 0) { (void)pgx_block_excl_scan(all, s_wave, tot); grand = tot; }
+    } else {
+        base = block_sums[blockIdx.x];
+        grand = block_sums[nb];
+    }
     uint64_t vals[PGX_SCAN_ITEMS], v = 0;
     for (int t = 0; t < PGX_SCAN_ITEMS; t++) {
         const uint64_t i = b0 + (uint64_t)threadIdx.x * PGX_SCAN_ITEMS + t;
@@ -715,15 +733,15 @@ pgx_scan_apply_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, co
         v += vals[t];
     }
     uint64_t tot;
-    uint64_t ex = block_sums[blockIdx.x] + pgx_block_excl_scan(v, s_wave, tot);
+    uint64_t ex = base + pgx_block_excl_scan(v, s_wave, tot);
     for (int t = 0; t < PGX_SCAN_ITEMS; t++) {
         const uint64_t i = b0 + (uint64_t)threadIdx.x * PGX_SCAN_ITEMS + t;
         if (i < n) out[i] = ex;
         ex += vals[t];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        out[n] = block_sums[nb];
-        if (total_out) *total_out = block_sums[nb]; // a second copy next to other scalars the host reads back together
+        out[n] = grand;
+        if (total_out) *total_out = grand; // a second copy next to other scalars the host reads back together
     }
 }
 

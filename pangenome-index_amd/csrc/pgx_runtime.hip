@@ -230,8 +230,9 @@ static void scan_excl(int mode, const void *in, uint64_t n, uint64_t min_len, ui
     tmp.ensure((nb + 1) * 8);
     uint64_t *sums = tmp.as<uint64_t>();
     hipLaunchKernelGGL(pgx_scan_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, mode, in, n, min_len, sums);
-    hipLaunchKernelGGL(pgx_scan_sums_kernel, dim3(1), dim3(256), 0, s, sums, nb);
-    hipLaunchKernelGGL(pgx_scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, mode, in, n, min_len, (const uint64_t *)sums, nb, out, total_out);
+    const int raw = nb <= 2048; // up to 4 M items: no separate scan of the block totals
+    if (!raw) hipLaunchKernelGGL(pgx_scan_sums_kernel, dim3(1), dim3(256), 0, s, sums, nb);
+    hipLaunchKernelGGL(pgx_scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, mode, in, n, min_len, (const uint64_t *)sums, nb, out, total_out, raw);
     HIPCHECK(hipGetLastError());
 }
 
