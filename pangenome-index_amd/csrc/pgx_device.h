@@ -48,7 +48,7 @@ __global__ void pgx_find_mems_heavy_kernel(PgxDevImage img, const uint8_t *reads
                                            unsigned long long *n_ext_total, const pgx_heavy_item *heavy_list,
                                            const unsigned long long *heavy_count, uint32_t heavy_cap, PgxHeavyResult *scratch);
 
-template <bool LDS_IMAGE, bool DENSE>
+template <bool LDS_IMAGE, bool DENSE, bool NARROW>
 __global__ void pgx_find_mems_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
                                      uint64_t min_len, uint64_t min_occ, const uint64_t *slot_off, pgx_mem *slots,
                                      uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor, uint64_t first_read,

@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "pgx_device.h"
 
 // block holding position pos (pos <= n).  One 8-byte directory entry resolves buckets with at most
@@ -92,6 +94,40 @@ __device__ __forceinline__ void pgx_dense_rank(const PgxDenseBlk &blk, uint64_t 
     }
     A = a + ia;
     B = b + ib;
+}
+
+// in-block counts of the six codes in the first (pos & 63) symbols of a dense block
+__device__ __forceinline__ void pgx_dense_inblock(const PgxDenseBlk &blk, uint32_t pos_lo, uint32_t t[6]) {
+    const uint32_t rel = pos_lo & 63u;
+    const uint32_t mlo = rel >= 32u ? 0xFFFFFFFFu : ((1u << rel) - 1u);
+    const uint32_t mhi = rel > 32u ? ((1u << (rel - 32u)) - 1u) : 0u;
+    const uint32_t a0 = blk.p01.x & mlo, a1 = blk.p01.y & mhi, b0 = blk.p01.z & mlo, b1 = blk.p01.w & mhi;
+    const uint32_t d0 = blk.p2.x & mlo, d1 = blk.p2.y & mhi;
+    const uint32_t n1 = __popc(a0) + __popc(a1), n2 = __popc(b0) + __popc(b1), n4 = __popc(d0) + __popc(d1);
+    const uint32_t n3 = __popc(a0 & b0) + __popc(a1 & b1), n5 = __popc(a0 & d0) + __popc(a1 & d1);
+    t[3] = n3; t[5] = n5;
+    t[1] = n1 - n3 - n5; t[2] = n2 - n3; t[4] = n4 - n5;
+    t[0] = rel - (n1 + n2 + n4 - n3 - n5);
+}
+
+// Both probes of an extension in 32-bit arithmetic (BWTs shorter than 2^30: the header counts fit their low dwords):
+// A0, A1 = count of code cv before p0 / p1, dB = sum over codes of mult[code] * (count before p1 - count before p0).
+// One multiply per code for the pair instead of one 64-bit multiply-add per code and probe.
+__device__ __forceinline__ void pgx_dense_pair32(const PgxDenseBlk &k0, uint32_t p0, const PgxDenseBlk &k1, uint32_t p1, uint32_t cv,
+                                                 uint32_t mrow, uint32_t &A0, uint32_t &A1, uint32_t &dB) {
+    uint32_t t0[6], t1[6];
+    pgx_dense_inblock(k0, p0, t0);
+    pgx_dense_inblock(k1, p1, t1);
+    const uint32_t c0[6] = {k0.h0.x + t0[0], k0.h0.y + t0[1], k0.h0.z + t0[2], k0.h0.w + t0[3], k0.h1.x + t0[4], k0.h1.y + t0[5]};
+    const uint32_t c1[6] = {k1.h0.x + t1[0], k1.h0.y + t1[1], k1.h0.z + t1[2], k1.h0.w + t1[3], k1.h1.x + t1[4], k1.h1.y + t1[5]};
+    uint32_t a0 = 0, a1 = 0, d = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        a0 = (cv == (uint32_t)i) ? c0[i] : a0;
+        a1 = (cv == (uint32_t)i) ? c1[i] : a1;
+        d += (c1[i] - c0[i]) * ((mrow >> (3 * i)) & 7u);
+    }
+    A0 = a0; A1 = a1; dB = d;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -298,7 +334,10 @@ __device__ __forceinline__ void pgx_stage_tables(const PgxDevImage &img, uint32_
 // ordinary read, tens of milliseconds for one lane.  A lane that has spent `heavy_ext` extensions on its read hands the
 // rest (rid, next start, MEMs so far) to pgx_find_mems_heavy_kernel at the next start-position boundary.
 #define PGX_FM_BATCH 128u
-template <bool LDS_IMAGE, bool DENSE>
+// NARROW (dense images of BWTs shorter than 2^30 only): interval coordinates and rank sums in 32 bits -- half the moves,
+// selects and adds of the loop.  Sound because every true value is < 2^32 there; the junk coordinates the COMPAT quirks can
+// produce are caught at the two additions that could wrap (counter slot 9 is raised and the host repeats the chunk in 64 bits).
+template <bool LDS_IMAGE, bool DENSE, bool NARROW>
 __global__ void __launch_bounds__(PGX_FM_THREADS, PGX_FM_WAVES_PER_SIMD)
 pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                      uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
@@ -310,16 +349,19 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     PGX_LDS_CARVE(img);
     pgx_stage_tables<LDS_IMAGE>(img, s_ext, s_C, lds_blocks, lds_dir, lds_blow);
 
+    static_assert(!NARROW || DENSE, "the 32-bit state exists for the dense image only");
+    typedef typename std::conditional<NARROW, uint32_t, uint64_t>::type pos_t;
     const int lane = threadIdx.x & 63;
-    const uint64_t n = img.n;
+    const pos_t n = (pos_t)img.n;
     uint64_t rid = 0, base = 0, slot = 0;
     int32_t len = 0, x = 0, j = 0;
-    uint64_t k = 0, kp = 0, s = 0, Jk = 0, Js = 0;
+    pos_t k = 0, kp = 0, s = 0, Jk = 0, Js = 0;
     uint32_t nm = 0, next = 0, next0 = 0; // next0: value of `next` when the current read was taken
     int ph = 0;                      // 0 = idle (no read, or read finished)
     uint64_t win = 0, win_at = ~0ull; // 8 read bytes cached in registers (absolute, 8-aligned offset)
-    uint64_t A0 = 0, B0 = 0;          // first-probe sums of an extension whose second probe is pending
+    pos_t A0 = 0, B0 = 0;             // first-probe sums of an extension whose second probe is pending
     bool pend = false;
+    bool ovf = false;                // NARROW: some addition left 32 bits (reported once, when the wave leaves)
     uint64_t rnext = 0, rend = 0;    // wave-uniform reservoir of read ids
     bool exhausted = false;          // wave-uniform: the global cursor has passed n_reads
 #ifdef PGX_FM_STATS
@@ -351,7 +393,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     // emit the MEM [x, e) and set up step 3
     auto emit = [&]() {
         pgx_mem m;
-        m.start = (uint64_t)x; m.end = (uint64_t)j; m.bwt_start = Jk; m.size = (int64_t)Js; // e == j at every emit
+        m.start = (uint64_t)x; m.end = (uint64_t)j; m.bwt_start = (uint64_t)Jk; m.size = (int64_t)(uint64_t)Js; // e == j at every emit
         slots[slot + nm] = m;
         nm++;
         k = 0; kp = 0; s = n;
@@ -417,23 +459,34 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
             // folded into ext_tab[256 + byte]): src/r-index.cpp:713-764
             const uint32_t ee = s_ext[(fwd ? 256u : 0u) + byte];
             const uint32_t cv = PGX_EXT_CV(ee), mrow = PGX_EXT_M(ee);
-            const uint64_t kk = fwd ? kp : k, kq = fwd ? k : kp;
+            const pos_t kk = fwd ? kp : k, kq = fwd ? k : kp;
             bool fin;
-            uint64_t A1, dB;
-            if (DENSE) {
+            pos_t A1, dB;
+            if (NARROW) {
+                const uint32_t ks = (uint32_t)kk + (uint32_t)s;
+                ovf |= ks < (uint32_t)kk; // kk + s left 32 bits (junk coordinates of a COMPAT quirk): the host repeats the chunk in 64 bits
+                const uint32_t p0 = (uint32_t)kk > (uint32_t)n ? (uint32_t)n : (uint32_t)kk, p1 = ks > (uint32_t)n ? (uint32_t)n : ks;
+                const PgxDenseBlk k0 = pgx_dense_load<LDS_IMAGE>(img, lds_blocks, p0), k1 = pgx_dense_load<LDS_IMAGE>(img, lds_blocks, p1);
+                uint32_t a0, a1, d;
+                pgx_dense_pair32(k0, p0, k1, p1, cv, mrow, a0, a1, d);
+                A0 = (pos_t)a0; A1 = (pos_t)a1; dB = (pos_t)d;
+                fin = true;
+            } else if (DENSE) {
                 // dense image: the two block addresses are known at once (pos >> 6), so both 64-byte loads are in flight
                 // together and every extension is a single trip
                 const uint64_t p0 = kk > n ? n : kk, p1 = (kk + s) > n ? n : (kk + s);
                 const PgxDenseBlk k0 = pgx_dense_load<LDS_IMAGE>(img, lds_blocks, p0), k1 = pgx_dense_load<LDS_IMAGE>(img, lds_blocks, p1);
-                uint64_t Bq0, Bq1;
-                pgx_dense_rank(k0, p0, cv, mrow, A0, Bq0);
-                pgx_dense_rank(k1, p1, cv, mrow, A1, Bq1);
-                dB = Bq1 - Bq0;
+                uint64_t Aq0, Aq1, Bq0, Bq1;
+                pgx_dense_rank(k0, p0, cv, mrow, Aq0, Bq0);
+                pgx_dense_rank(k1, p1, cv, mrow, Aq1, Bq1);
+                A0 = (pos_t)Aq0; A1 = (pos_t)Aq1; dB = (pos_t)(Bq1 - Bq0);
                 fin = true;
             } else if (LDS_IMAGE) {
                 // image in LDS: no memory latency to hide and most extensions of a tiny index need both blocks,
                 // so both trips run back to back (measured 6 % faster than the one-trip-per-iteration form)
-                pgx_rank_pair<LDS_IMAGE, false>(img, lds_blocks, lds_dir, lds_blow, kk, kk + s, cv, mrow, A0, A1, dB);
+                uint64_t Aq0, Aq1, dq;
+                pgx_rank_pair<LDS_IMAGE, false>(img, lds_blocks, lds_dir, lds_blow, kk, kk + s, cv, mrow, Aq0, Aq1, dq);
+                A0 = (pos_t)Aq0; A1 = (pos_t)Aq1; dB = (pos_t)dq;
                 fin = true;
             } else {
                 const uint64_t p0 = kk > n ? n : kk, p1 = (kk + s) > n ? n : (kk + s);
@@ -441,12 +494,12 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                 bool covered;
                 pgx_probe<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, pend ? p1 : p0, p1, !pend, cv, mrow, Ap, Bp, As, Bs, covered);
                 if (!pend) {
-                    A0 = Ap; B0 = Bp;
-                    A1 = As; dB = Bs - Bp;
+                    A0 = (pos_t)Ap; B0 = (pos_t)Bp;
+                    A1 = (pos_t)As; dB = (pos_t)(Bs - Bp);
                     fin = covered;
                     pend = !covered;
                 } else {
-                    A1 = Ap; dB = Bp - B0;
+                    A1 = (pos_t)Ap; dB = (pos_t)(Bp - B0);
                     fin = true;
                     pend = false;
                 }
@@ -456,12 +509,13 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                 if (PGX_EXT_KILL(ee) || A0 >= A1) { // rank_k >= rank_ks -> bi_interval(0,0,0), src/r-index.cpp:751
                     k = 0; kp = 0; s = 0;
                 } else {
-                    const uint64_t nk = A0 + s_C[PGX_EXT_V(ee)], nq = kq + dB;
+                    const pos_t nk = A0 + (pos_t)s_C[PGX_EXT_V(ee)], nq = kq + dB;
+                    if (NARROW) ovf |= nq < kq; // the other coordinate left 32 bits (see above)
                     s = A1 - A0;
                     k = fwd ? nq : nk;
                     kp = fwd ? nk : nq;
                 }
-                const bool small = (s < min_occ) || (s == 0); // :671 (unsigned compare) || size <= 0
+                const bool small = ((uint64_t)s < min_occ) || (s == 0); // :671 (unsigned compare) || size <= 0
                 // The transitions of the three steps as selects (the 64 lanes of a wave are in all three steps at once, so
                 // branches would run every path on every trip anyway, each with its own copies and exec-mask juggling):
                 //   step 1  small -> restart at j + 1 | j == x -> J = interval, j = x + min_len, step 2 (or emit) | else j--
@@ -484,6 +538,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
             }
         }
     }
+    if (NARROW && __any(ovf) && lane == 0) n_ext_total[9] = 1;
     // one atomic per wave for the extension counter
     unsigned long long tot = next;
 #pragma unroll
@@ -494,16 +549,22 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
 #endif
 }
 
-template __global__ void pgx_find_mems_kernel<false, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+template __global__ void pgx_find_mems_kernel<false, false, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
                                                             const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
                                                             uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<false, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+template __global__ void pgx_find_mems_kernel<false, true, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
                                                             const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
                                                             uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<true, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+template __global__ void pgx_find_mems_kernel<true, false, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
                                                             const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
                                                             uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<true, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+template __global__ void pgx_find_mems_kernel<true, true, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
+                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
+template __global__ void pgx_find_mems_kernel<true, true, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
+                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
+template __global__ void pgx_find_mems_kernel<false, true, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
                                                             const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
                                                             uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
 

@@ -850,13 +850,19 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     float ms_fm = 0, ms_cp = 0;
     uint64_t mem_base = 0;
     int occ = 0, cus = 0;
-    const void *kfn = nullptr;
+    const void *kfn = nullptr, *kfn_wide = nullptr;
+    uint64_t n_ext_host = 0;
     if (n) {
         // persistent grid: as many workgroups as the device keeps resident (no inter-workgroup
         // dependency exists, so any grid size is correct; this one avoids a tail of late blocks)
         const bool in_lds = b->dimg->lds_bytes != 0, dense = img.dense != 0;
-        kfn = in_lds ? (dense ? (const void *)pgx_find_mems_kernel<true, true> : (const void *)pgx_find_mems_kernel<true, false>)
-                     : (dense ? (const void *)pgx_find_mems_kernel<false, true> : (const void *)pgx_find_mems_kernel<false, false>);
+        kfn_wide = in_lds ? (dense ? (const void *)pgx_find_mems_kernel<true, true, false> : (const void *)pgx_find_mems_kernel<true, false, false>)
+                          : (dense ? (const void *)pgx_find_mems_kernel<false, true, false> : (const void *)pgx_find_mems_kernel<false, false, false>);
+        kfn = kfn_wide;
+        // 32-bit interval state for dense images of BWTs shorter than 2^30 (PGX_FM_NARROW=0 switches it off)
+        const char *nv = std::getenv("PGX_FM_NARROW");
+        if (dense && img.n < (1ull << 30) && !(nv && nv[0] == '0'))
+            kfn = in_lds ? (const void *)pgx_find_mems_kernel<true, true, true> : (const void *)pgx_find_mems_kernel<false, true, true>;
         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, PGX_FM_THREADS, b->dimg->lds_bytes));
         HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
         if (occ < 1) occ = 1;
@@ -876,7 +882,6 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     for (size_t ci = 0; ci < chunks.size(); ci++) {
         const pgx_chunk &c = chunks[ci];
         const uint64_t cn = c.r1 - c.r0;
-        if (ci) HIPCHECK(hipMemsetAsync(d_cursor, 0, 8, s)); // the cursor counts reads of this chunk from 0
         record(b, 1, s);
         unsigned grid = grid_for(cn, 64);
         int wg = occ;
@@ -887,7 +892,12 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             wg = (int)std::min<uint64_t>((uint64_t)occ, std::max<uint64_t>(2, want));
         }
         if (grid > (unsigned)(wg * cus)) grid = (unsigned)(wg * cus);
-        {
+        uint64_t *local = b->mem_off.as<uint64_t>() + c.r0; // local CSR offsets of this chunk (scratch until the global scan below)
+        uint64_t cm = 0;
+        const void *kf = kfn;
+        for (int attempt = 0;; attempt++) {
+            // per-chunk counters: [0] extensions [5] cursor [8] heavy reads [9] 32-bit overflow flag [10] MEMs of the chunk
+            if (ci || attempt) HIPCHECK(hipMemsetAsync(d_next, 0, 128, s));
             const uint8_t *a_reads = b->reads.as<uint8_t>();
             const uint64_t *a_off = b->offsets.as<uint64_t>(), *a_slot_off = b->slot_off.as<uint64_t>();
             uint64_t a_n = c.r1, a_min_len = min_len, a_min_occ = min_occ, a_base = c.slot_base, a_first = c.r0;
@@ -900,8 +910,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             unsigned long long *a_hcount = d_heavy_count;
             void *args[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_first, &a_base,
                             &a_hext, &a_hcap, &a_hlist, &a_hcount};
-            if (heavy_ext && ci) HIPCHECK(hipMemsetAsync(d_heavy_count, 0, 8, s));
-            HIPCHECK(hipLaunchKernel(kfn, dim3(grid), dim3(PGX_FM_THREADS), args, b->dimg->lds_bytes, s)); // one of the four variants
+            HIPCHECK(hipLaunchKernel(kf, dim3(grid), dim3(PGX_FM_THREADS), args, b->dimg->lds_bytes, s)); // one of the six variants
             if (heavy_ext) { // the rest of reads that spent heavy_ext extensions (usually none: the launch then costs a few microseconds)
                 if (b->dimg->lds_bytes)
                     hipLaunchKernelGGL(pgx_find_mems_heavy_kernel<true>, dim3(PGX_FM_HEAVY_GRID), dim3(256), b->dimg->lds_bytes, s, img, a_reads, a_off,
@@ -912,14 +921,19 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                                        a_slot_off, c.slot_base, a_slots, a_cnt, d_next, (const pgx_heavy_item *)a_hlist,
                                        (const unsigned long long *)d_heavy_count, (uint32_t)PGX_FM_HEAVY_CAP, b->heavy_scratch.as<PgxHeavyResult>());
             }
+            HIPCHECK(hipGetLastError());
+            b->timing.find_mems_launches++;
+            record(b, 2, s);
+            scan_excl(0, b->mem_count.as<uint32_t>() + c.r0, cn, 0, local, b->scan_tmp, s, reinterpret_cast<uint64_t *>(d_next + 10));
+            unsigned long long cc[11];
+            read_scalars(cc, d_next, sizeof cc, s);
+            const bool forced = attempt == 0 && kf != kfn_wide && std::getenv("PGX_FM_NARROW_FORCE_REDO") != nullptr; // tests
+            if ((cc[9] || forced) && kf != kfn_wide) { kf = kfn_wide; continue; } // a coordinate left 32 bits: repeat the chunk in 64 bits
+            n_ext_host += cc[0];
+            b->timing.heavy_reads += (uint32_t)std::min<unsigned long long>(cc[8], PGX_FM_HEAVY_CAP);
+            cm = cc[10];
+            break;
         }
-        HIPCHECK(hipGetLastError());
-        b->timing.find_mems_launches++;
-        record(b, 2, s);
-        // local CSR offsets of this chunk (mem_off[r0 .. r1] is scratch until the global scan below)
-        uint64_t *local = b->mem_off.as<uint64_t>() + c.r0;
-        scan_excl(0, b->mem_count.as<uint32_t>() + c.r0, cn, 0, local, b->scan_tmp, s);
-        const uint64_t cm = read_u64(local + cn, s);
         b->mems.ensure_keep((mem_base + cm ? mem_base + cm : 1) * sizeof(pgx_mem), mem_base * sizeof(pgx_mem));
         hipLaunchKernelGGL(pgx_compact_mems_kernel, dim3(grid_for(cn, 256)), dim3(256), 0, s, c.r0, cn, b->slot_off.as<uint64_t>(),
                            c.slot_base, b->slots.as<pgx_mem>(), b->mem_count.as<uint32_t>(), (const uint64_t *)local, mem_base,
@@ -959,8 +973,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         std::fprintf(stderr, "[pgx] find_mems wave trips %llu, live lane-trips %llu (%.1f%% of lanes), longest wave %llu trips, extensions %llu\n", cnt[6], cnt[7],
                      100.0 * (double)cnt[7] / (64.0 * (double)cnt[6]), cnt[3], cnt[0]);
     if (std::getenv("PGX_DEBUG_COUNTERS")) std::fprintf(stderr, "[pgx] counters %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[6], cnt[7], cnt[8]);
-    b->n_ext = cnt[0];
-    b->timing.heavy_reads += (uint32_t)std::min<unsigned long long>(cnt[8], PGX_FM_HEAVY_CAP); // of the last chunk when chunked
+    b->n_ext = n_ext_host;
     b->n_tag_overflow = cnt[1];
     if (b->timed) {
         auto el = [&](int a, int c) { float ms = 0; HIPCHECK(hipEventElapsedTime(&ms, b->ev[a], b->ev[c])); return ms; };

@@ -334,3 +334,25 @@ def test_concurrent_batches_from_host_threads(x_index, golden):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("env", [{"PGX_FM_NARROW": "0"}, {"PGX_FM_NARROW_FORCE_REDO": "1"}])
+def test_wide_state_and_forced_redo(x_index, golden, monkeypatch, env):
+    """dense images of short BWTs run with 32-bit interval state; the 64-bit kernels (PGX_FM_NARROW=0) and the repeat of a
+    chunk after a (here: simulated) 32-bit overflow must give the same answers"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ri_path, tags_path = x_index
+    idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | P.MODE_IMAGE_DENSE)
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    seqs = W.load_sequences(os.path.join(golden, "x.newline_separated"))
+    cat, offs = W.sample_reads(seqs, 20000, 150, seed=97)
+    monkeypatch.setenv("PGX_SLOT_BUDGET_MB", "20")  # several chunks: the repeat happens per chunk
+    for min_len, min_occ in [(10, 1), (5, 2)]:
+        ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, threads=O.lib().orc_max_threads())
+        b = idx.batch(cat, offs)
+        b.run(min_len, min_occ, P.RUN_TAGS | P.RUN_TIMING)
+        _assert_same(b.result(), ref, True)
+        launches = b.timing().find_mems_launches
+        b.free()
+        assert launches >= 3
