@@ -109,6 +109,7 @@ pgx_status pgx_index_open_memory(const void *ri_bytes, uint64_t ri_n, const void
 /* FastLocate's public tables: sym_map (r-index.hpp:307), C (:310), complement_table (:347) */
 pgx_status pgx_index_tables(const pgx_index *h, uint8_t sym_map[256], uint64_t C[8], uint8_t complement[256]);
 pgx_status pgx_index_info_get(const pgx_index *h, pgx_index_info *info);
+/* Frees the host image and every device image.  Batches created from the index use its device images: free them first. */
 void pgx_index_close(pgx_index *h);
 
 /* Copy the image to a HIP device (idempotent per device). */
