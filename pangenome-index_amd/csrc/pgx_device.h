@@ -7,6 +7,7 @@
 #include "../../include/pgx.h"
 #include "pgx_image.h"
 
+#define PGX_DENSE_LDS_U4 5 // uint4 slots per dense block in LDS (64 data bytes + 16 of padding)
 #define PGX_FM_THREADS 256
 #define PGX_FM_WAVES_PER_SIMD 4 // __launch_bounds__ 2nd argument: caps the kernel at 128 VGPRs
 

@@ -51,7 +51,8 @@ struct PgxDenseBlk {
 
 template <bool LDS_IMAGE>
 __device__ __forceinline__ PgxDenseBlk pgx_dense_load(const PgxDevImage &img, const uint4 *__restrict__ lds_blocks, uint64_t pos) {
-    const uint4 *bp = (LDS_IMAGE ? lds_blocks : img.blocks) + (size_t)(pos >> 6) * 4;
+    // in LDS the blocks are 80 bytes apart (PGX_DENSE_LDS_U4): with 64 they would start in only two bank groups
+    const uint4 *bp = LDS_IMAGE ? lds_blocks + (size_t)(pos >> 6) * PGX_DENSE_LDS_U4 : img.blocks + (size_t)(pos >> 6) * 4;
     PgxDenseBlk b;
     b.h0 = bp[0]; b.h1 = bp[1]; b.p01 = bp[2];
     b.p2 = *reinterpret_cast<const uint2 *>(bp + 3);
@@ -300,8 +301,9 @@ __device__ __forceinline__ void pgx_stage_tables(const PgxDevImage &img, uint32_
     if (threadIdx.x < 8) s_C[threadIdx.x] = img.consts->C[threadIdx.x];
     if (LDS_IMAGE) {
         const uint32_t nb4 = img.n_blocks * 4;
-        for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) lds_blocks[i] = img.blocks[i];
-        for (uint64_t i = threadIdx.x; i < img.dir_entries; i += blockDim.x) lds_dir[i] = img.dir[i];
+        for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) lds_blocks[img.dense ? (i >> 2) * PGX_DENSE_LDS_U4 + (i & 3u) : i] = img.blocks[i];
+        if (!img.dense)
+            for (uint64_t i = threadIdx.x; i < img.dir_entries; i += blockDim.x) lds_dir[i] = img.dir[i];
         if (!img.dense)
             for (uint32_t i = threadIdx.x; i < img.n_blocks; i += blockDim.x) lds_blow[i] = img.blow[i];
     }
@@ -836,8 +838,9 @@ pgx_count_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint6
     if (threadIdx.x < 8) s_C[threadIdx.x] = img.consts->C[threadIdx.x];
     if (LDS_IMAGE) {
         const uint32_t nb4 = img.n_blocks * 4;
-        for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) lds_blocks[i] = img.blocks[i];
-        for (uint64_t i = threadIdx.x; i < img.dir_entries; i += blockDim.x) lds_dir[i] = img.dir[i];
+        for (uint32_t i = threadIdx.x; i < nb4; i += blockDim.x) lds_blocks[img.dense ? (i >> 2) * PGX_DENSE_LDS_U4 + (i & 3u) : i] = img.blocks[i];
+        if (!img.dense)
+            for (uint64_t i = threadIdx.x; i < img.dir_entries; i += blockDim.x) lds_dir[i] = img.dir[i];
         if (!img.dense)
             for (uint32_t i = threadIdx.x; i < img.n_blocks; i += blockDim.x) lds_blow[i] = img.blow[i];
     }

@@ -184,6 +184,7 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
     g.tag_dir_shift = m.consts.tag_dir_shift;
     g.dense = m.consts.image_kind == PGX_IMAGE_DENSE ? 1u : 0u;
     size_t img_bytes = m.blocks.size() + m.dir.size() * 8 + m.blow.size() * 2;
+    if (g.dense) img_bytes = (size_t)m.consts.n_blocks * 16 * PGX_DENSE_LDS_U4 + 16; // padded blocks, no directory (pgx_dense_load)
     d->lds_bytes = img_bytes <= 48 * 1024 ? ((img_bytes + 15) & ~(size_t)15) : 0;
     h->dev[device] = d.release();
     return h->dev[device];
