@@ -360,9 +360,10 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     pos_t k = 0, kp = 0, s = 0, Jk = 0, Js = 0;
     uint32_t nm = 0, next = 0, next0 = 0; // next0: value of `next` when the current read was taken
     int ph = 0;                      // 0 = idle (no read, or read finished)
-    // read bytes cached in registers: 16 (absolute, 16-aligned offset) when the image is in global memory and the loop waits
-    // on memory anyway (3.94 -> 3.78 ms on the synthetic pangenome), 8 when it is in LDS and the loop is bound by issue slots
-    uint64_t win = 0, win_hi = 0, win_at = ~0ull;
+    // read bytes cached in registers: 32 (absolute, 32-aligned offset) when the image is in global memory and the loop waits
+    // on memory anyway (8 -> 16 -> 32 bytes: 3.94 -> 3.77 -> 3.72 ms on the synthetic pangenome), 8 when it is in LDS and the
+    // loop is bound by issue slots.  The reads buffer is padded with 32 zero bytes, so the window never overruns.
+    uint64_t win = 0, win_hi = 0, win2 = 0, win3 = 0, win_at = ~0ull;
     pos_t A0 = 0, B0 = 0;             // first-probe sums of an extension whose second probe is pending
     bool pend = false;
     bool ovf = false;                // NARROW: some addition left 32 bits (reported once, when the wave leaves)
@@ -459,12 +460,14 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                     }
                     byte = (uint32_t)(win >> (8u * (uint32_t)(at & 7ull))) & 0xFFu;
                 } else {
-                    if ((at & ~15ull) != win_at) {
-                        win_at = at & ~15ull;
+                    if ((at & ~31ull) != win_at) {
+                        win_at = at & ~31ull;
                         const ulonglong2 w2 = *reinterpret_cast<const ulonglong2 *>(reads + win_at);
-                        win = w2.x; win_hi = w2.y;
+                        const ulonglong2 w3 = *reinterpret_cast<const ulonglong2 *>(reads + win_at + 16);
+                        win = w2.x; win_hi = w2.y; win2 = w3.x; win3 = w3.y;
                     }
-                    byte = (uint32_t)(((at & 8ull) ? win_hi : win) >> (8u * (uint32_t)(at & 7ull))) & 0xFFu;
+                    const uint64_t wlo = (at & 8ull) ? win_hi : win, whi = (at & 8ull) ? win3 : win2;
+                    byte = (uint32_t)(((at & 16ull) ? whi : wlo) >> (8u * (uint32_t)(at & 7ull))) & 0xFFu;
                 }
             }
             const bool fwd = (ph == 2);

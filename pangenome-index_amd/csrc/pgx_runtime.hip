@@ -744,8 +744,8 @@ static void batch_upload(pgx_batch *b, const uint8_t *reads, const uint64_t *off
     const uint64_t lo = offsets[0], hi = offsets[n_reads];
     b->read_bytes = hi - lo;
     // device offsets are rebased to 0; 16 bytes of zero padding after the last read
-    b->reads.ensure(b->read_bytes + 16);
-    HIPCHECK(hipMemset((uint8_t *)b->reads.p + b->read_bytes, 0, 16));
+    b->reads.ensure(b->read_bytes + 32);
+    HIPCHECK(hipMemset((uint8_t *)b->reads.p + b->read_bytes, 0, 32));
     if (b->read_bytes) HIPCHECK(hipMemcpy(b->reads.p, reads + lo, b->read_bytes, hipMemcpyHostToDevice));
     b->h_offsets.resize(n_reads + 1);
     for (uint64_t i = 0; i <= n_reads; i++) b->h_offsets[i] = offsets[i] - lo;
