@@ -264,8 +264,10 @@ static inline unsigned grid_for(uint64_t n, unsigned per_block) {
 // tag pipeline shared by pgx_batch_run and pgx_tag_query_batch
 struct TagWork {
     DevBuf run_nums, first_item, seg_off, gbuf, need, scratch_off, scratch, ucount, pos_off, positions, big_list, scan_tmp, dedup, single;
+    HostBuf h_dedup; // pinned staging of the large-query keys and lists
     uint64_t n_positions = 0, n_big = 0;
     void release() {
+        h_dedup.release();
         DevBuf *all[] = {&run_nums, &first_item, &seg_off, &gbuf, &need, &scratch_off, &scratch, &ucount, &pos_off, &positions,
                          &big_list, &scan_tmp, &dedup, &single};
         for (DevBuf *d : all) d->release();
@@ -324,37 +326,45 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
                                      (int)(PGX_SORT_WG_LDS_CAP * 8)));
         // Identical large queries are common (every read from the same repeat / N run yields the same SA interval):
         // sort one representative per distinct (first item, run count) and copy its result to the duplicates.
-        std::vector<uint64_t> keys(3 * nlarge); // (query id, first item, run count) of every listed query
+        // keys and lists travel through one pinned buffer: [3 * nlarge keys | nlarge representatives | 2 * nlarge pairs]
+        w.h_dedup.ensure(6 * nlarge * 8);
+        uint64_t *keys = w.h_dedup.as<uint64_t>(), *reps = keys + 3 * nlarge, *dup_pairs = reps + nlarge;
         w.dedup.ensure(3 * nlarge * 8);
         hipLaunchKernelGGL(pgx_tag_list_fetch_kernel, dim3(grid_for(nlarge, 256)), dim3(256), 0, s, large, nlarge,
                            w.first_item.as<uint64_t>(), w.run_nums.as<uint64_t>(), w.dedup.as<uint64_t>());
         HIPCHECK(hipGetLastError());
-        HIPCHECK(hipMemcpyAsync(keys.data(), w.dedup.p, 3 * nlarge * 8, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipMemcpyAsync(keys, w.dedup.p, 3 * nlarge * 8, hipMemcpyDeviceToHost, s));
         HIPCHECK(hipStreamSynchronize(s));
-        std::vector<uint64_t> reps, dup_pairs; // representatives (query ids); (duplicate id, representative id) pairs
+        uint64_t nrep = 0, ndup = 0;
         {
-            std::unordered_map<uint64_t, std::vector<std::pair<uint64_t, uint64_t>>> seen; // hash -> [(first, cnt) key idx]
-            std::vector<std::array<uint64_t, 3>> rep_keys;
+            // open addressing over (first item, run count): slot -> index of the representative in `reps`
+            uint64_t cap = 16;
+            while (cap < 2 * nlarge) cap <<= 1;
+            std::vector<uint32_t> table(cap, 0xFFFFFFFFu);
+            std::vector<uint32_t> rep_key(nlarge); // representative r was listed at position rep_key[r]
             for (uint64_t i = 0; i < nlarge; i++) {
                 const uint64_t q = keys[3 * i], f = keys[3 * i + 1], c = keys[3 * i + 2];
-                auto &bucket = seen[f * 0x9E3779B97F4A7C15ull ^ c];
-                uint64_t rep = ~0ull;
-                for (auto &e : bucket)
-                    if (rep_keys[e.first][1] == f && rep_keys[e.first][2] == c) { rep = rep_keys[e.first][0]; break; }
-                if (rep == ~0ull) {
-                    bucket.emplace_back(rep_keys.size(), 0);
-                    rep_keys.push_back({q, f, c});
-                    reps.push_back(q);
-                } else {
-                    dup_pairs.push_back(q);
-                    dup_pairs.push_back(rep);
+                uint64_t hsh = (f * 0x9E3779B97F4A7C15ull ^ c * 0xC2B2AE3D27D4EB4Full) & (cap - 1);
+                for (;; hsh = (hsh + 1) & (cap - 1)) {
+                    const uint32_t r = table[hsh];
+                    if (r == 0xFFFFFFFFu) {
+                        table[hsh] = (uint32_t)nrep;
+                        rep_key[nrep] = (uint32_t)i;
+                        reps[nrep++] = q;
+                        break;
+                    }
+                    if (keys[3 * (uint64_t)rep_key[r] + 1] == f && keys[3 * (uint64_t)rep_key[r] + 2] == c) {
+                        dup_pairs[2 * ndup] = q;
+                        dup_pairs[2 * ndup + 1] = reps[r];
+                        ndup++;
+                        break;
+                    }
                 }
             }
         }
-        const uint64_t nrep = reps.size(), ndup = dup_pairs.size() / 2;
         uint64_t *d_reps = w.dedup.as<uint64_t>(), *d_dups = d_reps + nrep;
-        HIPCHECK(hipMemcpyAsync(d_reps, reps.data(), nrep * 8, hipMemcpyHostToDevice, s));
-        if (ndup) HIPCHECK(hipMemcpyAsync(d_dups, dup_pairs.data(), ndup * 16, hipMemcpyHostToDevice, s));
+        HIPCHECK(hipMemcpyAsync(d_reps, reps, nrep * 8, hipMemcpyHostToDevice, s));
+        if (ndup) HIPCHECK(hipMemcpyAsync(d_dups, dup_pairs, ndup * 16, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(pgx_tag_gather_kernel, dim3(grid_for(nrep, 4)), dim3(256), 0, s, img, (const uint64_t *)d_reps, nrep,
                            w.run_nums.as<uint64_t>(), w.first_item.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), d_nover);
         hipLaunchKernelGGL(pgx_tag_sort_large_kernel, dim3(grid_for(nrep, 1)), dim3(1024), lds, s, (const uint64_t *)d_reps, nrep,
@@ -365,7 +375,7 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
                                img.n_tag_items, w.first_item.as<uint64_t>(), w.run_nums.as<uint64_t>(), w.seg_off.as<uint64_t>(),
                                w.gbuf.as<uint64_t>(), w.ucount.as<uint64_t>(), d_nover);
         HIPCHECK(hipGetLastError());
-        HIPCHECK(hipStreamSynchronize(s)); // reps / dup_pairs are host vectors read by the async copies above
+        // (the lists live in w.h_dedup, which outlives the asynchronous copies above)
     }
     scan_excl(1, w.ucount.p, m, 0, w.pos_off.as<uint64_t>(), w.scan_tmp, s);
     w.n_positions = read_u64(w.pos_off.as<uint64_t>() + m, s);
