@@ -67,6 +67,7 @@ __global__ void pgx_scan_apply_kernel(int mode, const void *in, uint64_t n, uint
 __global__ void pgx_compact_mems_kernel(uint64_t first_read, uint64_t n_reads, const uint64_t *slot_off, uint64_t slot_base,
                                         const pgx_mem *slots, const uint32_t *mem_count, const uint64_t *local_off,
                                         uint64_t mem_base, pgx_mem *mems);
+#define PGX_TAG_LOCATE_THREADS 1024 // workgroup of pgx_tag_locate_kernel (one list atomic per workgroup)
 #define PGX_SORT_LDS_CAP 2048 // values per wave sorted in an LDS slice (pgx_tag_sort_unique_kernel)
 #define PGX_TAG_SMALL 16      // queries with at most this many runs take the 16-lane path
 #define PGX_SORT_WG_LDS_CAP 16384 // values one workgroup sorts in (dynamic) LDS (pgx_tag_sort_large_kernel)
@@ -74,8 +75,8 @@ __global__ void pgx_compact_mems_kernel(uint64_t first_read, uint64_t n_reads, c
 __global__ void pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *mems, const uint64_t *qstart, const uint64_t *qend,
                                       uint64_t n, uint64_t *run_nums, uint64_t *first_item, uint64_t *need, uint64_t *big_list,
                                       unsigned long long *n_big, unsigned long long *n_large, uint64_t *single, uint64_t *ucount,
-                                      unsigned long long *n_overflow);
-__global__ void pgx_tag_small_kernel(PgxDevImage img, uint64_t n, const uint64_t *run_nums, const uint64_t *first_item,
+                                      unsigned long long *n_overflow, uint64_t *small_list, unsigned long long *n_small);
+__global__ void pgx_tag_small_kernel(PgxDevImage img, const uint64_t *list, uint64_t n, const uint64_t *run_nums, const uint64_t *first_item,
                                      const uint64_t *seg_off, uint64_t *buf, uint64_t *ucount, unsigned long long *n_overflow);
 __global__ void pgx_tag_gather_kernel(PgxDevImage img, const uint64_t *list, uint64_t n_list, const uint64_t *run_nums,
                                       const uint64_t *first_item, const uint64_t *seg_off, uint64_t *buf,
@@ -89,9 +90,8 @@ __global__ void pgx_tag_list_fetch_kernel(const uint64_t *list, uint64_t n_list,
 __global__ void pgx_tag_copy_dups_kernel(const uint64_t *pairs, uint64_t n_pairs, uint64_t n_tag_items, const uint64_t *first_item,
                                          const uint64_t *run_nums, const uint64_t *seg_off, uint64_t *buf, uint64_t *ucount,
                                          unsigned long long *n_overflow);
-__global__ void pgx_tag_compact_kernel(uint64_t n, const uint64_t *ucount, const uint64_t *seg_off, const uint64_t *buf,
-                                       const uint64_t *pos_off, uint64_t *positions, uint64_t max_count, const uint64_t *run_nums,
-                                       int single_done);
+__global__ void pgx_tag_compact_kernel(const uint64_t *list, uint64_t n, const uint64_t *ucount, const uint64_t *seg_off, const uint64_t *buf,
+                                       const uint64_t *pos_off, uint64_t *positions, uint64_t max_count);
 __global__ void pgx_tag_compact_single_kernel(uint64_t n, const uint64_t *run_nums, const uint64_t *single, const uint64_t *pos_off,
                                               uint64_t *positions);
 __global__ void pgx_tag_compact_list_kernel(const uint64_t *list, uint64_t n_list, const uint64_t *ucount, const uint64_t *seg_off,

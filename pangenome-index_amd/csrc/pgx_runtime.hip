@@ -263,13 +263,13 @@ static inline unsigned grid_for(uint64_t n, unsigned per_block) {
 // ------------------------------------------------------------------------------------------
 // tag pipeline shared by pgx_batch_run and pgx_tag_query_batch
 struct TagWork {
-    DevBuf run_nums, first_item, seg_off, gbuf, need, scratch_off, scratch, ucount, pos_off, positions, big_list, scan_tmp, dedup, single;
+    DevBuf run_nums, first_item, seg_off, gbuf, need, scratch_off, scratch, ucount, pos_off, positions, big_list, scan_tmp, dedup, single, small_list;
     HostBuf h_dedup; // pinned staging of the large-query keys and lists
     uint64_t n_positions = 0, n_big = 0;
     void release() {
         h_dedup.release();
         DevBuf *all[] = {&run_nums, &first_item, &seg_off, &gbuf, &need, &scratch_off, &scratch, &ucount, &pos_off, &positions,
-                         &big_list, &scan_tmp, &dedup, &single};
+                         &big_list, &scan_tmp, &dedup, &single, &small_list};
         for (DevBuf *d : all) d->release();
     }
 };
@@ -288,24 +288,26 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
     w.pos_off.ensure((m + 1) * 8);
     w.big_list.ensure((m ? m : 1) * 8);
     w.single.ensure((m ? m : 1) * 8);
+    w.small_list.ensure((m ? m : 1) * 8);
     if (m) {
-        hipLaunchKernelGGL(pgx_tag_locate_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, img, d_mems, d_qs, d_qe, m,
+        hipLaunchKernelGGL(pgx_tag_locate_kernel, dim3(grid_for(m, PGX_TAG_LOCATE_THREADS)), dim3(PGX_TAG_LOCATE_THREADS), 0, s, img, d_mems, d_qs, d_qe, m,
                            w.run_nums.as<uint64_t>(), w.first_item.as<uint64_t>(), w.need.as<uint64_t>(), w.big_list.as<uint64_t>(), d_nbig, d_nbig + 1,
-                           w.single.as<uint64_t>(), w.ucount.as<uint64_t>(), d_nover);
+                           w.single.as<uint64_t>(), w.ucount.as<uint64_t>(), d_nover, w.small_list.as<uint64_t>(), d_nbig + 5);
         HIPCHECK(hipGetLastError());
     }
     scan_excl(5, w.run_nums.p, m, 0, w.seg_off.as<uint64_t>(), w.scan_tmp, s, reinterpret_cast<uint64_t *>(d_nbig + 3)); // single runs: no segment
     scan_excl(1, w.need.p, m, 0, w.scratch_off.as<uint64_t>(), w.scan_tmp, s, reinterpret_cast<uint64_t *>(d_nbig + 4));
-    uint64_t hv[5] = {0, 0, 0, 0, 0}; // nbig, nlarge, largest large run count, G, S
-    read_scalars(hv, d_nbig, 40, s);
-    const uint64_t G = hv[3], S = hv[4], nbig = hv[0], nlarge = hv[1];
+    uint64_t hv[6] = {0, 0, 0, 0, 0, 0}; // nbig, nlarge, largest large run count, G, S, nsmall
+    read_scalars(hv, d_nbig, 48, s);
+    const uint64_t G = hv[3], S = hv[4], nbig = hv[0], nlarge = hv[1], nsmall = hv[5];
     w.n_big = nbig;
     rec(0);
     w.gbuf.ensure((G ? G : 1) * 8);
     w.scratch.ensure((S ? S : 1) * 8);
-    if (m) {
-        hipLaunchKernelGGL(pgx_tag_small_kernel, dim3(grid_for(m, 16)), dim3(256), 0, s, img, m, w.run_nums.as<uint64_t>(),
-                           w.first_item.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.ucount.as<uint64_t>(), d_nover);
+    if (nsmall) { // queries with 2 .. 16 runs (single runs were answered by the locate kernel)
+        hipLaunchKernelGGL(pgx_tag_small_kernel, dim3(grid_for(nsmall, 16)), dim3(256), 0, s, img, (const uint64_t *)w.small_list.as<uint64_t>(), nsmall,
+                           w.run_nums.as<uint64_t>(), w.first_item.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(),
+                           w.ucount.as<uint64_t>(), d_nover);
         HIPCHECK(hipGetLastError());
     }
     rec(1);
@@ -381,10 +383,15 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
     w.n_positions = read_u64(w.pos_off.as<uint64_t>() + m, s);
     w.positions.ensure((w.n_positions ? w.n_positions : 1) * 8);
     if (m) {
-        const bool listed = nbig || nlarge; // only listed queries (> 16 runs) can exceed the 16-lane kernel's limit
-        hipLaunchKernelGGL(pgx_tag_compact_kernel, dim3(grid_for(m, 16)), dim3(256), 0, s, m, w.ucount.as<uint64_t>(),
-                           w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.pos_off.as<uint64_t>(), w.positions.as<uint64_t>(),
-                           listed ? (uint64_t)PGX_TAG_COMPACT_SMALL : ~0ull, (const uint64_t *)w.run_nums.as<uint64_t>(), 1);
+        // every query is on exactly one list: single (thread per query), small, big, large (16 lanes per query up to
+        // PGX_TAG_COMPACT_SMALL unique values, one workgroup per query beyond)
+        const uint64_t *lists[3] = {w.small_list.as<uint64_t>(), w.big_list.as<uint64_t>(), w.big_list.as<uint64_t>() + (m - nlarge)};
+        const uint64_t counts[3] = {nsmall, nbig, nlarge};
+        for (int li = 0; li < 3; li++)
+            if (counts[li])
+                hipLaunchKernelGGL(pgx_tag_compact_kernel, dim3(grid_for(counts[li], 16)), dim3(256), 0, s, lists[li], counts[li], w.ucount.as<uint64_t>(),
+                                   w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.pos_off.as<uint64_t>(), w.positions.as<uint64_t>(),
+                                   (uint64_t)PGX_TAG_COMPACT_SMALL);
         hipLaunchKernelGGL(pgx_tag_compact_single_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, m, (const uint64_t *)w.run_nums.as<uint64_t>(),
                            (const uint64_t *)w.single.as<uint64_t>(), (const uint64_t *)w.pos_off.as<uint64_t>(), w.positions.as<uint64_t>());
         if (nbig)
@@ -529,8 +536,8 @@ static void locate_core(pgx_index *h, pgx_device_image *d, const uint64_t *first
             scan_excl(1, ducount.p, n, 0, duoff.as<uint64_t>(), scan_tmp, s);
             const uint64_t U = read_u64(duoff.as<uint64_t>() + n, s);
             vals_out.ensure((U ? U : 1) * 8);
-            hipLaunchKernelGGL(pgx_tag_compact_kernel, dim3(grid_for(n, 16)), dim3(256), 0, s, n, ducount.as<uint64_t>(), dvoff.as<uint64_t>(),
-                               gbuf.as<uint64_t>(), duoff.as<uint64_t>(), vals_out.as<uint64_t>(), ~0ull, (const uint64_t *)nullptr, 0);
+            hipLaunchKernelGGL(pgx_tag_compact_kernel, dim3(grid_for(n, 16)), dim3(256), 0, s, (const uint64_t *)nullptr, n, ducount.as<uint64_t>(), dvoff.as<uint64_t>(),
+                               gbuf.as<uint64_t>(), duoff.as<uint64_t>(), vals_out.as<uint64_t>(), ~0ull);
             HIPCHECK(hipGetLastError());
             h_off.resize(n + 1);
             HIPCHECK(hipMemcpy(h_off.data(), duoff.p, (n + 1) * 8, hipMemcpyDeviceToHost));

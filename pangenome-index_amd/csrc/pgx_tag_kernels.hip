@@ -32,63 +32,83 @@ __device__ __forceinline__ uint64_t pgx_tag_rank(const PgxDevImage &img, uint64_
 
 // per query: run_nums (number_of_runs, :860) and the index of the first item read (:862-874,
 // including the off-by-one when first_bit_index % 10 == 0)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(PGX_TAG_LOCATE_THREADS)
 pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *__restrict__ mems, const uint64_t *__restrict__ qstart,
                       const uint64_t *__restrict__ qend, uint64_t n, uint64_t *__restrict__ run_nums,
                       uint64_t *__restrict__ first_item, uint64_t *__restrict__ need, uint64_t *__restrict__ big_list,
                       unsigned long long *__restrict__ n_big, unsigned long long *__restrict__ n_large, uint64_t *__restrict__ single,
-                      uint64_t *__restrict__ ucount, unsigned long long *__restrict__ n_overflow) {
+                      uint64_t *__restrict__ ucount, unsigned long long *__restrict__ n_overflow, uint64_t *__restrict__ small_list,
+                      unsigned long long *__restrict__ n_small) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t st, en;
-    if (mems) { st = mems[i].bwt_start; en = st + (uint64_t)mems[i].size - 1; } // find_mems.cpp:129
-    else { st = qstart[i]; en = qend[i]; }
-    const uint64_t f = pgx_tag_rank(img, st);
-    // rank of `en`: an interval usually ends inside the run it starts in, so gallop upwards from f (one load when it does)
-    uint64_t g = f;
-    if (en >= st) {
-        const uint64_t nr = img.n_tag_runs;
-        uint64_t step = 1, lo = f, hi = f;
-        while (hi < nr && img.tstart[hi] <= en) { lo = hi + 1; hi = (hi + step < nr) ? hi + step : nr; step <<= 1; }
-        while (lo < hi) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if (img.tstart[mid] <= en) lo = mid + 1; else hi = mid;
+    const bool valid = i < n; // no early return: the small list is appended to by whole waves
+    uint64_t cnt = 0;
+    if (valid) {
+        uint64_t st, en;
+        if (mems) { st = mems[i].bwt_start; en = st + (uint64_t)mems[i].size - 1; } // find_mems.cpp:129
+        else { st = qstart[i]; en = qend[i]; }
+        const uint64_t f = pgx_tag_rank(img, st);
+        // rank of `en`: an interval usually ends inside the run it starts in, so gallop upwards from f (one load when it does)
+        uint64_t g = f;
+        if (en >= st) {
+            const uint64_t nr = img.n_tag_runs;
+            uint64_t step = 1, lo = f, hi = f;
+            while (hi < nr && img.tstart[hi] <= en) { lo = hi + 1; hi = (hi + step < nr) ? hi + step : nr; step <<= 1; }
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (img.tstart[mid] <= en) lo = mid + 1; else hi = mid;
+            }
+            g = lo;
+        } else g = pgx_tag_rank(img, en);
+        cnt = g - f + 1;
+        run_nums[i] = cnt;
+        const uint64_t fi = (f % 10) ? f - 1 : f;
+        first_item[i] = fi;
+        if (cnt == 1) { // one run = one position: the common case (a MEM inside one node); no segment, no sort
+            uint64_t v = 0;
+            if (fi < img.n_tag_items) v = img.tvals[fi];
+            else atomicAdd(n_overflow, 1ull); // the reference reads past the stored runs (UB there): value 0
+            single[i] = v;
+            ucount[i] = 1;
+        } else if (cnt == 0) ucount[i] = 0; // an inverted query is on no list
+        uint64_t p2 = 64;
+        while (p2 < cnt && p2 < (1ull << 62)) p2 <<= 1;
+        need[i] = p2 > PGX_SORT_WG_LDS_CAP ? p2 : 0; // global scratch of the large path
+        // one array, two lists: "big" grows from the front, "large" from the back (they cannot meet)
+        if (cnt > PGX_SORT_LDS_CAP) {
+            big_list[n - 1 - atomicAdd(n_large, 1ull)] = i;
+            atomicMax(n_large + 1, (unsigned long long)cnt); // sizes the LDS of the large-path launch
         }
-        g = lo;
-    } else g = pgx_tag_rank(img, en);
-    const uint64_t cnt = g - f + 1;
-    run_nums[i] = cnt;
-    const uint64_t fi = (f % 10) ? f - 1 : f;
-    first_item[i] = fi;
-    if (cnt == 1) { // one run = one position: the common case (a MEM inside one node); no segment, no sort
-        uint64_t v = 0;
-        if (fi < img.n_tag_items) v = img.tvals[fi];
-        else atomicAdd(n_overflow, 1ull); // the reference reads past the stored runs (UB there): value 0
-        single[i] = v;
-        ucount[i] = 1;
+        else if (cnt > PGX_TAG_SMALL) big_list[atomicAdd(n_big, 1ull)] = i;
     }
-    uint64_t p2 = 64;
-    while (p2 < cnt && p2 < (1ull << 62)) p2 <<= 1;
-    need[i] = p2 > PGX_SORT_WG_LDS_CAP ? p2 : 0; // global scratch of the large path
-    // one array, two lists: "big" grows from the front, "large" from the back (they cannot meet)
-    if (cnt > PGX_SORT_LDS_CAP) {
-        big_list[n - 1 - atomicAdd(n_large, 1ull)] = i;
-        atomicMax(n_large + 1, (unsigned long long)cnt); // sizes the LDS of the large-path launch
+    // queries with 2 .. 16 runs: a list of their own, so that the 16-lane kernels only see those.  One atomic per
+    // 1024-thread workgroup: all of them hit one address, and one per wave (23 k for 1.5 M MEMs) cost 0.27 ms.
+    __shared__ uint32_t s_cnt[PGX_TAG_LOCATE_THREADS / 64];
+    __shared__ unsigned long long s_base;
+    const bool is_small = valid && cnt >= 2 && cnt <= PGX_TAG_SMALL;
+    const unsigned long long m = __ballot(is_small);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int k = 0; k < PGX_TAG_LOCATE_THREADS / 64; k++) { const uint32_t c = s_cnt[k]; s_cnt[k] = tot; tot += c; }
+        s_base = tot ? atomicAdd(n_small, (unsigned long long)tot) : 0ull;
     }
-    else if (cnt > PGX_TAG_SMALL) big_list[atomicAdd(n_big, 1ull)] = i;
+    __syncthreads();
+    if (is_small) small_list[s_base + s_cnt[wv] + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = i;
 }
 
 // 16 lanes per query, <= 16 runs: gather, sort, unique -> seg, ucount
 __global__ void __launch_bounds__(256)
-pgx_tag_small_kernel(PgxDevImage img, uint64_t n, const uint64_t *__restrict__ run_nums, const uint64_t *__restrict__ first_item,
-                     const uint64_t *__restrict__ seg_off, uint64_t *__restrict__ buf, uint64_t *__restrict__ ucount,
-                     unsigned long long *__restrict__ n_overflow) {
-    const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+pgx_tag_small_kernel(PgxDevImage img, const uint64_t *__restrict__ list, uint64_t n, const uint64_t *__restrict__ run_nums,
+                     const uint64_t *__restrict__ first_item, const uint64_t *__restrict__ seg_off, uint64_t *__restrict__ buf,
+                     uint64_t *__restrict__ ucount, unsigned long long *__restrict__ n_overflow) {
+    const uint64_t w16 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; // entry of the small list (2 .. 16 runs)
     const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
-    const bool valid = q < n;
+    const bool valid = w16 < n;
+    const uint64_t q = valid ? list[w16] : 0;
     const uint64_t cnt = valid ? run_nums[q] : 0;
-    const bool mine = valid && cnt <= PGX_TAG_SMALL && cnt != 1; // single-run queries were answered by the locate kernel
-    if (!__any(mine)) return;
+    const bool mine = valid;
     uint64_t v = ~0ull;
     bool over = false;
     if (mine && (uint64_t)l16 < cnt) {
@@ -276,13 +296,13 @@ pgx_tag_sort_large_kernel(const uint64_t *__restrict__ list, uint64_t n_list, co
 // `max_count` values are left to pgx_tag_compact_list_kernel (a few huge segments would otherwise keep 16 lanes busy
 // for thousands of iterations while the rest of the grid has finished).
 __global__ void __launch_bounds__(256)
-pgx_tag_compact_kernel(uint64_t n, const uint64_t *__restrict__ ucount, const uint64_t *__restrict__ seg_off,
+pgx_tag_compact_kernel(const uint64_t *__restrict__ list, uint64_t n, const uint64_t *__restrict__ ucount, const uint64_t *__restrict__ seg_off,
                        const uint64_t *__restrict__ buf, const uint64_t *__restrict__ pos_off, uint64_t *__restrict__ positions,
-                       uint64_t max_count, const uint64_t *__restrict__ run_nums, int single_done) {
-    const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+                       uint64_t max_count) {
+    const uint64_t w16 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int l16 = threadIdx.x & 15;
-    if (q >= n) return;
-    if (single_done && run_nums[q] == 1) return; // copied by pgx_tag_compact_single_kernel
+    if (w16 >= n) return;
+    const uint64_t q = list ? list[w16] : w16; // a list of queries (small / big / large), or all of them
     const uint64_t c = ucount[q], src = seg_off[q], dst = pos_off[q];
     if (c > max_count) return;
     for (uint64_t t = l16; t < c; t += 16) positions[dst + t] = buf[src + t];
