@@ -296,10 +296,14 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
         HIPCHECK(hipGetLastError());
     }
     scan_excl(5, w.run_nums.p, m, 0, w.seg_off.as<uint64_t>(), w.scan_tmp, s, reinterpret_cast<uint64_t *>(d_nbig + 3)); // single runs: no segment
-    scan_excl(1, w.need.p, m, 0, w.scratch_off.as<uint64_t>(), w.scan_tmp, s, reinterpret_cast<uint64_t *>(d_nbig + 4));
-    uint64_t hv[6] = {0, 0, 0, 0, 0, 0}; // nbig, nlarge, largest large run count, G, S, nsmall
+    uint64_t hv[6] = {0, 0, 0, 0, 0, 0}; // nbig, nlarge, largest large run count, G, (unused), nsmall
     read_scalars(hv, d_nbig, 48, s);
-    const uint64_t G = hv[3], S = hv[4], nbig = hv[0], nlarge = hv[1], nsmall = hv[5];
+    const uint64_t G = hv[3], nbig = hv[0], nlarge = hv[1], nsmall = hv[5];
+    uint64_t S = 0; // global sort scratch: only queries with more than PGX_SORT_WG_LDS_CAP runs need any (rare: one more scan then)
+    if (hv[2] > PGX_SORT_WG_LDS_CAP) {
+        scan_excl(1, w.need.p, m, 0, w.scratch_off.as<uint64_t>(), w.scan_tmp, s);
+        S = read_u64(w.scratch_off.as<uint64_t>() + m, s);
+    }
     w.n_big = nbig;
     rec(0);
     w.gbuf.ensure((G ? G : 1) * 8);
