@@ -335,7 +335,7 @@ __device__ __forceinline__ void pgx_stage_tables(const PgxDevImage &img, uint32_
 // (pattern[len] = 0 is the endmarker): ~len^2 / 2 extensions in one dependent chain, 100 x an
 // ordinary read, tens of milliseconds for one lane.  A lane that has spent `heavy_ext` extensions on its read hands the
 // rest (rid, next start, MEMs so far) to pgx_find_mems_heavy_kernel at the next start-position boundary.
-#define PGX_FM_BATCH (LDS_IMAGE ? 128u : 64u) // reads per grab: fewer leave less in the wave's reserve when the queue runs dry (synth: 64 < 128 < 256),
+#define PGX_FM_BATCH (LDS_IMAGE ? 128u : 32u) // reads per grab: fewer leave less in the wave's reserve when the queue runs dry (synth: 32 < 64 < 128 < 256),
                                                // but the LDS kernels are fast enough to feel the contention on the cursor (x: 128 < 64)
 // NARROW (dense images of BWTs shorter than 2^30 only): interval coordinates and rank sums in 32 bits -- half the moves,
 // selects and adds of the loop.  Sound because every true value is < 2^32 there; the junk coordinates the COMPAT quirks can
