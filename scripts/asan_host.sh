@@ -12,7 +12,7 @@ void pgx_release_device_images(pgx_index *) {}
 STUB(pgx_index_to_device) STUB(pgx_device_count) STUB(pgx_device_name) STUB(pgx_rank_batch) STUB(pgx_extend_batch) STUB(pgx_count_batch)
 STUB(pgx_tag_query_batch) STUB(pgx_locate_batch) STUB(pgx_locate_next_batch) STUB(pgx_decompress_sa) STUB(pgx_batch_create)
 STUB(pgx_batch_upload) STUB(pgx_batch_run) STUB(pgx_batch_result) STUB(pgx_batch_counts) STUB(pgx_batch_timing) STUB(pgx_batch_free)
-STUB(pgx_find_mems_batch)
+STUB(pgx_find_mems_batch) STUB(pgx_merge_tags) STUB(pgx_batch_device_result)
 CPP
 g++ -O1 -g -std=c++17 -fPIC -shared -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined \
     -o /tmp/libpgx_asan.so pangenome-index_amd/csrc/pgx_index.cpp pangenome-index_amd/csrc/pgx_sdsl.cpp pangenome-index_amd/csrc/pgx_build.cpp /tmp/pgx_asan_stub.cpp
