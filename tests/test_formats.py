@@ -153,3 +153,24 @@ def test_convert_tags_reproduces_reference_fixture_byte_for_byte(workdir):
         s = int(rng.integers(0, 8022))
         e = int(min(8021, s + rng.integers(0, 100)))
         assert a.query(s, e) == b.query(s, e)
+
+
+def test_builder_clis(golden, workdir, built):
+    """build_rindex / convert_tags binaries (reference CLIs src/build_rindex.cpp, src/convert_tags.cpp): host only"""
+    import subprocess
+    pkg = os.path.dirname(os.path.abspath(P.__file__))
+    bt = os.path.join(golden, "bidirectional_test")
+    r = subprocess.run([os.path.join(pkg, "build_rindex"), os.path.join(bt, "contigs_xy.rl_bwt"), "--legacy"], capture_output=True, timeout=120)
+    assert r.returncode == 0 and r.stdout == open(os.path.join(bt, "xy.ri"), "rb").read()  # the reference's own file
+    r = subprocess.run([os.path.join(pkg, "build_rindex"), os.path.join(golden, "x.rl_bwt")], capture_output=True, timeout=120)
+    ref = os.path.join(workdir, "cli_x.ri")
+    P.build_rindex(os.path.join(golden, "x.rl_bwt"), ref, encoded=True)
+    assert r.returncode == 0 and r.stdout == open(ref, "rb").read()
+    out = os.path.join(workdir, "cli_conv.tags")
+    r = subprocess.run([os.path.join(pkg, "convert_tags"), os.path.join(bt, "xy_bidirectional.tags"), out, "tmp1", "tmp2", "--format", "bytecode"],
+                       capture_output=True, timeout=120)
+    assert r.returncode == 0 and open(out, "rb").read() == open(os.path.join(bt, "xy_bidirectional_compressed.tags"), "rb").read()
+    r = subprocess.run([os.path.join(pkg, "convert_tags"), os.path.join(bt, "xy_bidirectional.tags"), out], capture_output=True, timeout=120)
+    assert r.returncode == 0 and O.Tags(out, O.TAGS_COMPACT).L.orc_tags_n_runs(O.Tags(out, O.TAGS_COMPACT).h) > 0
+    r = subprocess.run([os.path.join(pkg, "build_rindex"), "/nonexistent.rl_bwt"], capture_output=True, timeout=120)
+    assert r.returncode == 1
