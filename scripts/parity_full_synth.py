@@ -1,5 +1,6 @@
 """Full-size parity on the synthetic pangenome bench workload (GPU box): the device result of the 1 M-read batch of
-`bench.py --workload synth` against the CPU oracle, every MEM, run count and position.  python3 -u scripts/parity_full_synth.py"""
+`bench.py --workload synth` against the CPU oracle, every MEM, run count and position.
+python3 -u scripts/parity_full_synth.py [n_reads [base_len]]   (base_len 40000000 = the chr22-scale index, n = 640 M)"""
 import os, sys, time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +10,8 @@ import pgx_ffi as P, pgx_workload as W, oracle_ffi as O
 
 wd = "/tmp/pgx_parity_full"; os.makedirs(wd, exist_ok=True)
 text = os.path.join(wd, "synth.txt")
-W.synth_pangenome_text(text)
+base_len = int(sys.argv[2]) if len(sys.argv) > 2 else 4_000_000
+W.synth_pangenome_text(text, base_len=base_len)
 ri, tags = W.build_index_from_text(text, wd, "synth")[:2]
 seqs = W.load_sequences(text)
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
