@@ -19,6 +19,7 @@
 #include <mutex>
 #include <array>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -620,9 +621,46 @@ extern "C" pgx_status pgx_merge_tags(const char *ri_path, const char *const *tag
     PGX_GUARD_BEGIN
     if (!ri_path || !tag_paths || !seq_to_file || !out_path) throw Error(PGX_ERR_ARG, "pgx_merge_tags: null argument");
     if (n_files == 0 || n_files > 250) throw Error(PGX_ERR_ARG, "pgx_merge_tags: between 1 and 250 tag files");
-    pgx_index *h = nullptr;
-    if (pgx_index_open(ri_path, nullptr, PGX_TAGS_AUTO, PGX_MODE_STRICT | PGX_MODE_IMAGE_RL, &h) != PGX_OK) return PGX_ERR_FORMAT; // message already set
-    std::unique_ptr<pgx_index, void (*)(pgx_index *)> guard(h, pgx_index_close);
+    // only the locate side of the index is needed: parse the file, no rank image
+    std::unique_ptr<pgx_index, void (*)(pgx_index *)> guard(new pgx_index(), pgx_index_close);
+    pgx_index *h = guard.get();
+    {
+        std::vector<uint8_t> f;
+        try { f = read_whole_file(ri_path); }
+        catch (const Error &) { throw Error(PGX_ERR_IO, std::string("Cannot open r-index: ") + ri_path); }
+        h->ri.parse(f.data(), f.size());
+        std::memset(&h->img.consts, 0, sizeof h->img.consts);
+        h->mode = PGX_MODE_STRICT;
+        h->has_rank = true;
+    }
+    // the tag streams are parsed by host threads (one per file) while the device computes the document array
+    struct Stream { std::vector<uint64_t> st, vl; std::string err; };
+    std::vector<Stream> streams(n_files);
+    std::vector<std::thread> parsers;
+    for (uint32_t f = 0; f < n_files; f++) {
+        if (!tag_paths[f]) throw Error(PGX_ERR_ARG, "pgx_merge_tags: null tag path");
+        parsers.emplace_back([&streams, tag_paths, f]() {
+            Stream &o = streams[f];
+            try {
+                std::vector<uint8_t> raw = read_whole_file(tag_paths[f]);
+                uint64_t loc = 0;
+                if (raw.size() >= 8) { // int_vector<8> header (bit count) of sdsl::int_vector_buffer<8>, merge_tags.cpp:207
+                    uint64_t bits = 0;
+                    std::memcpy(&bits, raw.data(), 8);
+                    if (bits == (raw.size() - 8) * 8) loc = 8;
+                }
+                o.st.assign(1, 0);
+                while (loc < raw.size()) {
+                    const uint64_t v = bytecode_read(raw.data(), raw.size(), loc, "tag run");
+                    const uint64_t len = (v >> 11) & 0x1FF; // decode_run, length_bits = 9 (src/tag_arrays.cpp:59-70)
+                    if (!len) continue;
+                    o.vl.push_back((v & 0x7FF) | ((v >> 20) << 11)); // offset | rev << 10 | node << 11
+                    o.st.push_back(o.st.back() + len);
+                }
+            } catch (const std::exception &e) { o.err = e.what(); }
+        });
+    }
+    struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } joiner{parsers};
     const uint64_t n = h->ri.sequence_size, tot = h->ri.C.size() > 1 ? h->ri.C[1] - h->ri.C[0] : 0;
     if (n_seq != tot) throw Error(PGX_ERR_ARG, "pgx_merge_tags: seq_to_file has " + std::to_string(n_seq) + " entries, the index holds " +
                                                    std::to_string(tot) + " sequences");
@@ -653,22 +691,9 @@ extern "C" pgx_status pgx_merge_tags(const char *ri_path, const char *const *tag
         da.release();
         // 3. per file: expanded stream, rank of its positions, gather
         for (uint32_t f = 0; f < n_files; f++) {
-            if (!tag_paths[f]) throw Error(PGX_ERR_ARG, "pgx_merge_tags: null tag path");
-            std::vector<uint8_t> raw = read_whole_file(tag_paths[f]);
-            uint64_t loc = 0;
-            if (raw.size() >= 8) { // int_vector<8> header (bit count) of sdsl::int_vector_buffer<8>, merge_tags.cpp:207
-                uint64_t bits = 0;
-                std::memcpy(&bits, raw.data(), 8);
-                if (bits == (raw.size() - 8) * 8) loc = 8;
-            }
-            std::vector<uint64_t> st(1, 0), vl;
-            while (loc < raw.size()) {
-                const uint64_t v = bytecode_read(raw.data(), raw.size(), loc, "tag run");
-                const uint64_t len = (v >> 11) & 0x1FF; // decode_run, length_bits = 9 (src/tag_arrays.cpp:59-70)
-                if (!len) continue;
-                vl.push_back((v & 0x7FF) | ((v >> 20) << 11)); // offset | rev << 10 | node << 11
-                st.push_back(st.back() + len);
-            }
+            parsers[f].join();
+            if (!streams[f].err.empty()) throw Error(PGX_ERR_FORMAT, std::string(tag_paths[f]) + ": " + streams[f].err);
+            const std::vector<uint64_t> &st = streams[f].st, &vl = streams[f].vl;
             const uint64_t nr = vl.size(), total = st.back();
             scan_excl(3, file_of.p, n, f, rank.as<uint64_t>(), scan_tmp, s);
             const uint64_t have = read_u64(rank.as<uint64_t>() + n, s);
