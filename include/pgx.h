@@ -115,9 +115,13 @@ void pgx_index_close(pgx_index *h);
 /* Copy the image to a HIP device (idempotent per device). */
 pgx_status pgx_index_to_device(pgx_index *h, int device);
 
-/* Host views of the flat image (for tests that verify the layout without a GPU).  `which`:
+/* Host views of the flat image (for tests that verify the layout without a GPU, and FastLocate::getSample).  `which`:
  * 0 rank blocks (64 B each), 1 directory (u64), 2 block starts (u64, host only), 3 tag run starts (u64),
- * 4 tag values (u64), 5 tag directory (u32), 6 constants table (see pgx_image.h), 7 block lows (u16). */
+ * 4 tag values (u64), 5 tag directory (u32), 6 constants table (PgxConsts, pgx_image.h), 7 block lows (u16);
+ * locate image (built on first use of one of these selectors, pgx_image.h "locate image"):
+ * 8 rstart (u64, first BWT position of every run + n), 9 rsamp (u64, samples[run]: what getSample returns),
+ * 10 rdir (u32), 11 lpos (u64, ones of `last`), 12 lnext (u64, samples[last_to_run[i] + 1]), 13 ldir (u32),
+ * 14 locate constants (PgxLocConsts). */
 pgx_status pgx_index_image_view(const pgx_index *h, int which, const void **ptr, uint64_t *bytes);
 
 /* ---- index construction (build side; CPU, run once) --------------------------------------- */
@@ -173,6 +177,10 @@ typedef struct {
 } pgx_range;
 pgx_status pgx_count_batch(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
                            pgx_range *out);
+
+/* One step of it -- FastLocate::LF (src/r-index.cpp:650-687) / LF_encoded (:689-711): out[i] = LF(in[i], sym[i]) for n
+ * inclusive ranges; empty inputs and results are {1, 0}.  Same COMPAT restriction as pgx_count_batch. */
+pgx_status pgx_lf_batch(pgx_index *h, int device, const pgx_range *in, const uint8_t *sym, uint64_t n, pgx_range *out);
 
 /* ---- locate: suffix-array samples of the r-index ---------------------------------------- */
 #define PGX_NO_POSITION (~(uint64_t)0)
@@ -256,6 +264,15 @@ void pgx_batch_free(pgx_batch *b);
 pgx_status pgx_find_mems_batch(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets,
                                uint64_t n_reads, uint64_t min_len, uint64_t min_occ, uint32_t flags,
                                pgx_batch **batch_out, pgx_result *result_out);
+
+/* find_mems_function (include/pangenome_index/algorithm.hpp:653-736) for n independent (read, start) pairs: query i
+ * evaluates the function on read read_of[i] at start position x[i] and reports the start position it returns (next_x),
+ * whether it pushed a MEM (has_mem, mem[i]) and the extensions it performed (n_ext, may be NULL).  x[i] > length is
+ * undefined in the reference (:658 wraps) and defined here as "return length".  The batch entry points above are the
+ * product path; this one serves the compat header's per-call find_mems_function and tests of the state machine. */
+pgx_status pgx_find_mems_function_batch(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
+                                        const uint64_t *read_of, const uint64_t *x, uint64_t n, uint64_t min_len, uint64_t min_occ,
+                                        uint64_t *next_x, pgx_mem *mem, uint8_t *has_mem, uint64_t *n_ext);
 
 /* device helpers */
 pgx_status pgx_device_count(int *n);

@@ -533,31 +533,35 @@ static uint64_t rankAt_literal(const orc_ri *r, uint64_t pos, uint8_t symbol) {
     return enc_rank_of_code(r, loc, end_pos, target_code, pos - bstart) + cum[target_code];
 }
 
+/* One LF step: FastLocate::LF (src/r-index.cpp:650-687) / LF_encoded (:689-711) of the inclusive range
+ * [*first, *second] by `sym`; the empty range is {1, 0}.  STRICT: textbook backward-search step over the true ranks. */
+void orc_LF(const orc_ri *r, int mode, uint8_t sym, uint64_t *first, uint64_t *second) {
+    uint64_t lo = *first, hi = *second;
+    if (mode == ORC_MODE_STRICT) {
+        int code = -1;
+        for (int c = 1; c < 6; c++) if (NUC[c] == sym && r->sym_map[sym] != 0) code = c;
+        if (code < 0 || lo > hi) { *first = 1; *second = 0; return; }
+        uint64_t a[6], b[6];
+        orc_rank6_true(r, lo, a);
+        orc_rank6_true(r, hi + 1, b);
+        if (b[code] == a[code]) { *first = 1; *second = 0; return; }
+        *first = a[code] + r->C[r->sym_map[sym]];
+        *second = *first + (b[code] - a[code]) - 1;
+        return;
+    }
+    if (!r->encoded && !r->sym_map[sym]) { *first = 1; *second = 0; return; } /* :653 */
+    if (lo > hi) { *first = 1; *second = 0; return; }                          /* :655-657, :691 */
+    uint64_t f = rankAt_literal(r, lo, sym);
+    uint64_t inside = rankAt_literal(r, hi + 1, sym) - f;
+    if (inside == 0) { *first = 1; *second = 0; return; }
+    *first = f + r->C[r->sym_map[sym]];
+    *second = *first + inside - 1;
+}
+
+/* FastLocate::count / count_encoded, include/pangenome_index/r-index.hpp:540-556: LF per symbol from the end */
 void orc_count(const orc_ri *r, int mode, const uint8_t *read, uint64_t len, uint64_t *first, uint64_t *second) {
     uint64_t lo = 0, hi = r->sequence_size - 1; /* {0, bwt_size() - 1}, r-index.hpp:541,551 */
-    for (uint64_t i = len; i > 0; i--) {
-        const uint8_t sym = read[i - 1];
-        if (mode == ORC_MODE_STRICT) {
-            int code = -1;
-            for (int c = 1; c < 6; c++) if (NUC[c] == sym && r->sym_map[sym] != 0) code = c;
-            if (code < 0 || lo > hi) { lo = 1; hi = 0; continue; }
-            uint64_t a[6], b[6];
-            orc_rank6_true(r, lo, a);
-            orc_rank6_true(r, hi + 1, b);
-            if (b[code] == a[code]) { lo = 1; hi = 0; continue; }
-            lo = a[code] + r->C[r->sym_map[sym]];
-            hi = lo + (b[code] - a[code]) - 1;
-            continue;
-        }
-        /* LF (src/r-index.cpp:650-687) / LF_encoded (:689-711) */
-        if (!r->encoded && !r->sym_map[sym]) { lo = 1; hi = 0; continue; } /* :653 */
-        if (lo > hi) { lo = 1; hi = 0; continue; }
-        uint64_t f = rankAt_literal(r, lo, sym);
-        uint64_t inside = rankAt_literal(r, hi + 1, sym) - f;
-        if (inside == 0) { lo = 1; hi = 0; continue; }
-        lo = f + r->C[r->sym_map[sym]];
-        hi = lo + inside - 1;
-    }
+    for (uint64_t i = len; i > 0; i--) orc_LF(r, mode, read[i - 1], &lo, &hi);
     *first = lo;
     *second = hi;
 }
@@ -695,6 +699,19 @@ static uint64_t find_mems_function(const orc_ri *r, int mode, const uint8_t *pat
     return j + 1;
 #undef PAT
 #undef SMALL
+}
+
+/* one call of find_mems_function (algorithm.hpp:653-736) at start x <= len: returns the next start; *has_mem / *mem = the MEM it pushed */
+uint64_t orc_find_mems_function(const orc_ri *r, int mode, const uint8_t *read, uint64_t len, uint64_t min_len, uint64_t min_occ,
+                                uint64_t x, orc_mem *mem, int *has_mem, uint64_t *n_ext) {
+    orc_mem tmp;
+    memsink_t s = {&tmp, 0, 1, 0};
+    uint64_t dummy = 0;
+    if (!n_ext) n_ext = &dummy;
+    const uint64_t nx = find_mems_function(r, mode, read, len, min_len, min_occ, x, &s, n_ext);
+    if (has_mem) *has_mem = s.total ? 1 : 0;
+    if (mem && s.total) *mem = tmp;
+    return nx;
 }
 
 /* find_all_mems, include/pangenome_index/algorithm.hpp:739-757 */

@@ -92,12 +92,19 @@ uint64_t orc_find_all_mems(const orc_ri *r, int mode, const uint8_t *read, uint6
                            uint64_t min_len, uint64_t min_occ, orc_mem *out, uint64_t cap,
                            uint64_t *n_ext);
 
+/* one call of find_mems_function (algorithm.hpp:653-736) at start position x (x <= len): returns the start position the
+ * function returns, the MEM it pushed (if *has_mem) and adds its extensions to *n_ext (optional) */
+uint64_t orc_find_mems_function(const orc_ri *r, int mode, const uint8_t *read, uint64_t len, uint64_t min_len, uint64_t min_occ,
+                                uint64_t x, orc_mem *mem, int *has_mem, uint64_t *n_ext);
+
 /* ---- query_tags path: FastLocate::count / count_encoded, r-index.hpp:540-556 ---- */
 /* returns the final range; an empty range is (1, 0) like the reference's {1, 0}.
  * COMPAT: literal LF (src/r-index.cpp:650-687, legacy: unknown symbols are rejected :653) or LF_encoded
  * (:689-711 over rankAt_encoded :570-590, which always reads SIX cumulative varints: quirk 3 --
  * wrong-but-deterministic on an encoded index without N).  STRICT: textbook backward search. */
 void orc_count(const orc_ri *r, int mode, const uint8_t *read, uint64_t len, uint64_t *first, uint64_t *second);
+/* one step of it: FastLocate::LF (src/r-index.cpp:650-687) / LF_encoded (:689-711) on the inclusive range [*first, *second] */
+void orc_LF(const orc_ri *r, int mode, uint8_t sym, uint64_t *first, uint64_t *second);
 
 /* ---- locate: src/r-index.cpp:1252-1366, r-index.hpp:424-436,490-501 ---- */
 #define ORC_NO_POSITION (~(uint64_t)0)

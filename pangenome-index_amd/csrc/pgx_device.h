@@ -60,6 +60,9 @@ __global__ void pgx_extend_kernel(PgxDevImage img, const pgx_biint *in, const ui
                                   pgx_biint *out);
 template <bool LDS_IMAGE>
 __global__ void pgx_count_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads, pgx_range *out);
+__global__ void pgx_fmf_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, const uint64_t *read_of, const uint64_t *xs, uint64_t n,
+                               uint64_t min_len, uint64_t min_occ, PgxHeavyResult *out);
+__global__ void pgx_lf_kernel(PgxDevImage img, const pgx_range *in, const uint8_t *sym, uint64_t n, pgx_range *out);
 __global__ void pgx_scan_partial_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, uint64_t *block_sums);
 __global__ void pgx_scan_sums_kernel(uint64_t *block_sums, uint64_t nb);
 __global__ void pgx_scan_apply_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, const uint64_t *block_sums,

@@ -585,6 +585,50 @@ template __global__ void pgx_find_mems_kernel<false, true, true>(PgxDevImage, co
                                                             const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
                                                             uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
 
+// find_mems_function(pattern, min_len, min_occ, x) (algorithm.hpp:653-736) for ONE start position: the MEM it emits (if any), the
+// start position it returns and the extensions it performs.
+template <bool LDS_IMAGE>
+__device__ __forceinline__ PgxHeavyResult pgx_fmf_eval(const PgxDevImage &img, const uint4 *lds_blocks, const uint64_t *lds_dir, const uint16_t *lds_blow,
+                                                       const uint32_t *s_ext, const uint64_t *s_C, const uint8_t *__restrict__ pat, int32_t len, int32_t xs,
+                                                       uint64_t min_len, uint64_t min_occ) {
+    const uint64_t n = img.n;
+    PgxHeavyResult r;
+    r.mem.start = (uint64_t)xs; r.mem.end = 0; r.mem.bwt_start = 0; r.mem.size = 0;
+    r.next_x = (uint32_t)len; r.n_ext = 0; r.has_mem = 0; r.pad = 0;
+    if ((uint64_t)(len - xs) >= min_len) {
+        uint64_t k = 0, kp = 0, s = n;
+        uint32_t ne = 0;
+        bool dead = false;
+        for (int32_t j = xs + (int32_t)min_len - 1; j >= xs; j--) { // step 1 (:666-676)
+            pgx_extend<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, s_ext, s_C, k, kp, s, pat[j], false);
+            ne++;
+            if (s < min_occ || s == 0) { r.next_x = (uint32_t)(j + 1); dead = true; break; }
+        }
+        if (!dead) {
+            uint64_t Jk = k, Js = s;
+            int32_t j = xs + (int32_t)min_len;
+            for (; j < len; j++) { // step 2 (:684-696)
+                pgx_extend<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, s_ext, s_C, k, kp, s, pat[j], true);
+                ne++;
+                if (s < min_occ || s == 0) break;
+                Jk = k; Js = s;
+            }
+            r.has_mem = 1;
+            r.mem.end = (uint64_t)j; r.mem.bwt_start = Jk; r.mem.size = (int64_t)Js; // :713
+            k = 0; kp = 0; s = n;
+            uint32_t nxt = (uint32_t)(xs + 1);
+            for (; j > xs; j--) { // step 3 (:718-735); pattern[len] reads 0
+                pgx_extend<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, s_ext, s_C, k, kp, s, j < len ? pat[j] : (uint8_t)0, false);
+                ne++;
+                if (s < min_occ || s == 0) { nxt = (uint32_t)(j + 1); break; }
+            }
+            r.next_x = nxt;
+        }
+        r.n_ext = ne;
+    }
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------
 // The rest of a heavy read (see pgx_find_mems_kernel): one workgroup per read evaluates find_mems_function(x)
 // (algorithm.hpp:653-736) for EVERY remaining start position x at once -- the calls are independent of each other,
@@ -605,7 +649,6 @@ pgx_find_mems_heavy_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     __shared__ uint64_t s_C[8];
     PGX_LDS_CARVE(img);
     pgx_stage_tables<LDS_IMAGE>(img, s_ext, s_C, lds_blocks, lds_dir, lds_blow);
-    const uint64_t n = img.n;
     PgxHeavyResult *res = scratch + (size_t)blockIdx.x * PGX_FM_HEAVY_MAXLEN;
     for (unsigned long long h = blockIdx.x; h < cnt; h += gridDim.x) {
         const pgx_heavy_item it = heavy_list[h];
@@ -613,40 +656,7 @@ pgx_find_mems_heavy_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         const int32_t len = (int32_t)(offsets[it.rid + 1] - base), x0 = (int32_t)it.x;
         const uint8_t *pat = reads + base;
         for (int32_t xs = x0 + (int32_t)threadIdx.x; xs < len; xs += (int32_t)blockDim.x) {
-            PgxHeavyResult r;
-            r.mem.start = (uint64_t)xs; r.mem.end = 0; r.mem.bwt_start = 0; r.mem.size = 0;
-            r.next_x = (uint32_t)len; r.n_ext = 0; r.has_mem = 0; r.pad = 0;
-            if ((uint64_t)(len - xs) >= min_len) {
-                uint64_t k = 0, kp = 0, s = n;
-                uint32_t ne = 0;
-                bool dead = false;
-                for (int32_t j = xs + (int32_t)min_len - 1; j >= xs; j--) { // step 1 (:666-676)
-                    pgx_extend<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, s_ext, s_C, k, kp, s, pat[j], false);
-                    ne++;
-                    if (s < min_occ || s == 0) { r.next_x = (uint32_t)(j + 1); dead = true; break; }
-                }
-                if (!dead) {
-                    uint64_t Jk = k, Js = s;
-                    int32_t j = xs + (int32_t)min_len;
-                    for (; j < len; j++) { // step 2 (:684-696)
-                        pgx_extend<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, s_ext, s_C, k, kp, s, pat[j], true);
-                        ne++;
-                        if (s < min_occ || s == 0) break;
-                        Jk = k; Js = s;
-                    }
-                    r.has_mem = 1;
-                    r.mem.end = (uint64_t)j; r.mem.bwt_start = Jk; r.mem.size = (int64_t)Js; // :713
-                    k = 0; kp = 0; s = n;
-                    uint32_t nxt = (uint32_t)(xs + 1);
-                    for (; j > xs; j--) { // step 3 (:718-735); pattern[len] reads 0
-                        pgx_extend<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, s_ext, s_C, k, kp, s, j < len ? pat[j] : (uint8_t)0, false);
-                        ne++;
-                        if (s < min_occ || s == 0) { nxt = (uint32_t)(j + 1); break; }
-                    }
-                    r.next_x = nxt;
-                }
-                r.n_ext = ne;
-            }
+            const PgxHeavyResult r = pgx_fmf_eval<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, s_ext, s_C, pat, len, xs, min_len, min_occ);
             res[xs - x0] = r;
         }
         __threadfence_block();
@@ -880,3 +890,46 @@ pgx_count_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint6
 }
 template __global__ void pgx_count_kernel<false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, pgx_range *);
 template __global__ void pgx_count_kernel<true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, pgx_range *);
+
+// One LF step per query (FastLocate::LF src/r-index.cpp:650-687 / LF_encoded :689-711): the inclusive range [first, second]
+// mapped by `sym`; an empty input or result is {1, 0}.  Same tables as pgx_count_kernel.
+__global__ void __launch_bounds__(256)
+pgx_lf_kernel(PgxDevImage img, const pgx_range *__restrict__ in, const uint8_t *__restrict__ sym, uint64_t n, pgx_range *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t e = img.consts->cnt_tab[sym[i]];
+    pgx_range r;
+    r.first = 1; r.second = 0;
+    const uint64_t lo = in[i].first, hi = in[i].second;
+    if (!PGX_EXT_KILL(e) && lo <= hi) { // positions beyond n rank like n (predecessor -> last block, totals)
+        uint64_t A0, A1, dB;
+        pgx_rank_pair<false>(img, nullptr, nullptr, nullptr, lo, hi + 1, PGX_EXT_CV(e), 0u, A0, A1, dB);
+        if (A1 != A0) {
+            r.first = A0 + img.consts->C[PGX_EXT_V(e)];
+            r.second = r.first + (A1 - A0) - 1;
+        }
+    }
+    out[i] = r;
+}
+
+// find_mems_function for n independent (read, start) pairs, one lane each (the compat header's per-call entry point and the
+// tests of the state machine; the batch kernel above is the product path).
+__global__ void __launch_bounds__(256)
+pgx_fmf_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ read_of,
+               const uint64_t *__restrict__ xs, uint64_t n, uint64_t min_len, uint64_t min_occ, PgxHeavyResult *__restrict__ out) {
+    __shared__ uint32_t s_ext[512];
+    __shared__ uint64_t s_C[8];
+    pgx_stage_tables<false>(img, s_ext, s_C, nullptr, nullptr, nullptr);
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t rid = read_of[i], base = offsets[rid];
+    const int32_t len = (int32_t)(offsets[rid + 1] - base);
+    PgxHeavyResult r;
+    if (xs[i] > (uint64_t)len) { // undefined in the reference (len - x wraps, :658); defined here as "return len"
+        r.mem.start = xs[i]; r.mem.end = 0; r.mem.bwt_start = 0; r.mem.size = 0;
+        r.next_x = (uint32_t)len; r.n_ext = 0; r.has_mem = 0; r.pad = 0;
+    } else {
+        r = pgx_fmf_eval<false>(img, nullptr, nullptr, nullptr, s_ext, s_C, reads + base, len, (int32_t)xs[i], min_len, min_occ);
+    }
+    out[i] = r;
+}

@@ -1207,6 +1207,71 @@ extern "C" pgx_status pgx_count_batch(pgx_index *h, int device, const uint8_t *r
     PGX_GUARD_END
 }
 
+extern "C" pgx_status pgx_find_mems_function_batch(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
+                                                    const uint64_t *read_of, const uint64_t *x, uint64_t n, uint64_t min_len, uint64_t min_occ,
+                                                    uint64_t *next_x, pgx_mem *mem, uint8_t *has_mem, uint64_t *n_ext) {
+    PGX_GUARD_BEGIN
+    if (!h || !offsets || (n && (!read_of || !x || !next_x || !mem || !has_mem))) throw Error(PGX_ERR_ARG, "pgx_find_mems_function_batch: null argument");
+    if (!h->has_rank) throw Error(PGX_ERR_ARG, "pgx_find_mems_function_batch: index opened without an r-index");
+    pgx_device_image *d = device_image(h, device);
+    if (!n) return PGX_OK;
+    for (uint64_t i = 0; i < n_reads; i++) {
+        if (offsets[i + 1] < offsets[i]) throw Error(PGX_ERR_ARG, "pgx_find_mems_function_batch: offsets must be non-decreasing");
+        if (offsets[i + 1] - offsets[i] >= (1ull << 31)) throw Error(PGX_ERR_UNSUPPORTED, "read longer than 2^31 bytes");
+    }
+    for (uint64_t i = 0; i < n; i++)
+        if (read_of[i] >= n_reads) throw Error(PGX_ERR_ARG, "pgx_find_mems_function_batch: read index out of range");
+    DevBuf dr, doff, dro, dx, dout;
+    DevBuf *all[] = {&dr, &doff, &dro, &dx, &dout};
+    try {
+        const uint64_t lo = offsets[0], bytes = offsets[n_reads] - lo;
+        if (bytes && !reads) throw Error(PGX_ERR_ARG, "pgx_find_mems_function_batch: null reads");
+        std::vector<uint64_t> reb(n_reads + 1);
+        for (uint64_t i = 0; i <= n_reads; i++) reb[i] = offsets[i] - lo;
+        dr.ensure(bytes + 32); doff.ensure((n_reads + 1) * 8); dro.ensure(n * 8); dx.ensure(n * 8); dout.ensure(n * sizeof(PgxHeavyResult));
+        HIPCHECK(hipMemset((uint8_t *)dr.p + bytes, 0, 32));
+        if (bytes) HIPCHECK(hipMemcpy(dr.p, reads + lo, bytes, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(doff.p, reb.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(dro.p, read_of, n * 8, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(dx.p, x, n * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(pgx_fmf_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, d->img, dr.as<uint8_t>(), doff.as<uint64_t>(), dro.as<uint64_t>(),
+                           dx.as<uint64_t>(), n, min_len, min_occ, dout.as<PgxHeavyResult>());
+        HIPCHECK(hipGetLastError());
+        std::vector<PgxHeavyResult> res(n);
+        HIPCHECK(hipMemcpy(res.data(), dout.p, n * sizeof(PgxHeavyResult), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; i++) {
+            next_x[i] = res[i].next_x; mem[i] = res[i].mem; has_mem[i] = (uint8_t)res[i].has_mem;
+            if (n_ext) n_ext[i] = res[i].n_ext;
+        }
+    } catch (...) { for (DevBuf *b : all) b->release(); throw; }
+    for (DevBuf *b : all) b->release();
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_lf_batch(pgx_index *h, int device, const pgx_range *in, const uint8_t *sym, uint64_t n, pgx_range *out) {
+    PGX_GUARD_BEGIN
+    if (!h || (n && (!in || !sym || !out))) throw Error(PGX_ERR_ARG, "pgx_lf_batch: null argument");
+    if (!h->has_rank) throw Error(PGX_ERR_ARG, "pgx_lf_batch: index opened without an r-index");
+    if (!h->img.consts.count_supported)
+        throw Error(PGX_ERR_UNSUPPORTED, "LF_encoded on an encoded index without N mis-parses block headers in the reference "
+                                         "(rankAt_encoded reads six cumulative varints); open the index in PGX_MODE_STRICT");
+    pgx_device_image *d = device_image(h, device);
+    if (!n) return PGX_OK;
+    DevBuf din, dsym, dout;
+    try {
+        din.ensure(n * sizeof(pgx_range)); dsym.ensure(n); dout.ensure(n * sizeof(pgx_range));
+        HIPCHECK(hipMemcpy(din.p, in, n * sizeof(pgx_range), hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(dsym.p, sym, n, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(pgx_lf_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, d->img, din.as<pgx_range>(), dsym.as<uint8_t>(), n, dout.as<pgx_range>());
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpy(out, dout.p, n * sizeof(pgx_range), hipMemcpyDeviceToHost));
+    } catch (...) { din.release(); dsym.release(); dout.release(); throw; }
+    din.release(); dsym.release(); dout.release();
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
 extern "C" pgx_status pgx_tag_query_batch(pgx_index *h, int device, const uint64_t *start, const uint64_t *end, uint64_t n,
                                           uint64_t *run_nums, uint64_t *pos_offsets, uint64_t *positions, uint64_t positions_cap,
                                           uint64_t *n_overflow) {

@@ -23,6 +23,21 @@ struct MEM {
     int64_t size;
 };
 
+// algorithm.hpp:653-736: one call of the MEM finder at start position x; pushes at most one MEM, returns the next start.
+// (A device launch per call: for real work use find_all_mems_batch, which runs the whole loop of :745-748 on the device.)
+inline size_t find_mems_function(const std::string &pattern, size_t min_len, size_t min_occ, size_t x, FastLocate &fmd_index,
+                                 std::vector<MEM> &output) {
+    const uint64_t offs[2] = {0, pattern.size()}, read_of = 0, xs = x;
+    uint64_t next_x = 0;
+    pgx_mem m{};
+    uint8_t has = 0;
+    if (pgx_find_mems_function_batch(fmd_index.handle(), fmd_index.device(), reinterpret_cast<const uint8_t *>(pattern.data()), offs, 1, &read_of,
+                                     &xs, 1, min_len, min_occ, &next_x, &m, &has, nullptr) != PGX_OK)
+        throw std::runtime_error(pgx_last_error());
+    if (has) output.push_back(MEM{(size_t)m.start, (size_t)m.end, (size_t)m.bwt_start, m.size});
+    return (size_t)next_x;
+}
+
 // find_all_mems for many reads in one device batch; result[i] = MEMs of reads[i] in discovery order
 inline std::vector<std::vector<MEM>> find_all_mems_batch(const std::vector<std::string> &reads, size_t min_len, size_t min_occ,
                                                          FastLocate &fmd_index) {

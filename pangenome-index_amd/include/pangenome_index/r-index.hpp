@@ -75,6 +75,19 @@ public:
     std::pair<size_t, size_t> count_encoded(std::string &pattern) const { return count_impl(pattern); }
     std::pair<size_t, size_t> count(std::string &pattern) { return count_impl(pattern); }
 
+    // src/r-index.cpp:650-711: one LF step of an inclusive BWT range ({1, 0} = empty).  The reference's out-parameters
+    // starts_with_to / first_run are set to false / max like its own implementation does (:658-659, :693-694).
+    std::pair<size_type, size_type> LF(std::pair<size_type, size_type> range, size_t sym) const { return lf_impl(range, sym); }
+    std::pair<size_type, size_type> LF_encoded(std::pair<size_type, size_type> range, size_t sym) const { return lf_impl(range, sym); }
+    std::pair<size_type, size_type> LF(std::pair<size_type, size_type> range, size_t sym, bool &starts_with_to, size_t &first_run) const {
+        starts_with_to = false; first_run = ~(size_t)0;
+        return lf_impl(range, sym);
+    }
+    std::pair<size_type, size_type> LF_encoded(std::pair<size_type, size_type> range, size_t sym, bool &starts_with_to, size_t &first_run) const {
+        starts_with_to = false; first_run = ~(size_t)0;
+        return lf_impl(range, sym);
+    }
+
     // ---- locate (r-index.hpp:385-406, 424-436, 490-501, 616-618; src/r-index.cpp:1252-1366) ----
     typedef std::pair<size_type, size_type> range_type; // gbwt::range_type: inclusive BWT range, empty when second < first
     constexpr static size_type NO_POSITION = ~(size_type)0;
@@ -158,6 +171,15 @@ private:
         std::vector<size_type> out(info_.bwt_size);
         if (pgx_decompress_sa(h_, device_, flags, out.data()) != PGX_OK) throw std::runtime_error(pgx_last_error());
         return out;
+    }
+
+    std::pair<size_type, size_type> lf_impl(std::pair<size_type, size_type> range, size_t sym) const {
+        if (!h_) throw std::runtime_error("FastLocate: no index loaded");
+        const pgx_range in{range.first, range.second};
+        pgx_range out{1, 0};
+        const uint8_t s = (uint8_t)sym;
+        if (pgx_lf_batch(h_, device_, &in, &s, 1, &out) != PGX_OK) throw std::runtime_error(pgx_last_error());
+        return {out.first, out.second};
     }
 
     std::pair<size_t, size_t> count_impl(const std::string &pattern) const {

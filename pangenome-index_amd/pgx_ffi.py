@@ -110,6 +110,8 @@ def lib():
     L.pgx_rank_batch.argtypes = [p, C.c_int, p, u64, C.c_int, p]
     L.pgx_extend_batch.argtypes = [p, C.c_int, p, p, p, u64, p]
     L.pgx_count_batch.argtypes = [p, C.c_int, p, p, u64, p]
+    L.pgx_find_mems_function_batch.argtypes = [p, C.c_int, p, p, u64, p, p, u64, u64, u64, p, p, p, p]
+    L.pgx_lf_batch.argtypes = [p, C.c_int, p, p, u64, p]
     L.pgx_tag_query_batch.argtypes = [p, C.c_int, p, p, u64, p, p, p, u64, C.POINTER(u64)]
     L.pgx_locate_batch.argtypes = [p, C.c_int, p, p, u64, u32, p, p, u64]
     L.pgx_locate_next_batch.argtypes = [p, C.c_int, p, u64, p]
@@ -235,6 +237,28 @@ class Index:
         out = np.zeros((n, 2), dtype=np.uint64)
         _check(self.L.pgx_count_batch(self.h, device, reads_cat.ctypes.data if len(reads_cat) else None, offsets.ctypes.data, n,
                                       out.ctypes.data))
+        return out
+
+    def find_mems_function_batch(self, reads_cat, offsets, read_of, xs, min_len, min_occ, device=0):
+        """find_mems_function (algorithm.hpp:653-736) for (read, start) pairs -> (next_x, mems, has_mem, n_ext)"""
+        reads_cat = np.ascontiguousarray(reads_cat, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ro = np.ascontiguousarray(read_of, dtype=np.uint64)
+        xv = np.ascontiguousarray(xs, dtype=np.uint64)
+        n = len(ro)
+        nx, ne = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        mems, has = np.zeros(n, dtype=MEM_DTYPE), np.zeros(n, dtype=np.uint8)
+        _check(self.L.pgx_find_mems_function_batch(self.h, device, reads_cat.ctypes.data if len(reads_cat) else None, offsets.ctypes.data,
+                                                   len(offsets) - 1, ro.ctypes.data, xv.ctypes.data, n, min_len, min_occ, nx.ctypes.data,
+                                                   mems.ctypes.data, has.ctypes.data, ne.ctypes.data))
+        return nx, mems, has, ne
+
+    def lf_batch(self, ranges, syms, device=0):
+        """FastLocate::LF / LF_encoded: uint64[n, 2] inclusive ranges, one symbol each -> uint64[n, 2]; empty = (1, 0)"""
+        rg = np.ascontiguousarray(ranges, dtype=np.uint64).reshape(-1, 2)
+        sy = np.ascontiguousarray(syms, dtype=np.uint8)
+        out = np.zeros((len(rg), 2), dtype=np.uint64)
+        _check(self.L.pgx_lf_batch(self.h, device, rg.ctypes.data, sy.ctypes.data, len(rg), out.ctypes.data))
         return out
 
     def tag_query_batch(self, start, end, device=0):

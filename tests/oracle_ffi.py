@@ -84,7 +84,10 @@ def lib():
     L.orc_forward_extend.argtypes = [p, C.c_int, BiInt, C.c_uint8]
     L.orc_find_all_mems.restype = u64
     L.orc_find_all_mems.argtypes = [p, C.c_int, C.c_char_p, u64, u64, u64, C.POINTER(Mem), u64, C.POINTER(u64)]
+    L.orc_find_mems_function.restype = u64
+    L.orc_find_mems_function.argtypes = [p, C.c_int, C.c_char_p, u64, u64, u64, u64, C.POINTER(Mem), C.POINTER(C.c_int), C.POINTER(u64)]
     L.orc_count.argtypes = [p, C.c_int, C.c_char_p, u64, C.POINTER(u64), C.POINTER(u64)]
+    L.orc_LF.argtypes = [p, C.c_int, C.c_uint8, C.POINTER(u64), C.POINTER(u64)]
     L.orc_locate_first.restype, L.orc_locate_first.argtypes = u64, [p]
     L.orc_locate_next.restype, L.orc_locate_next.argtypes = u64, [p, u64]
     L.orc_seq_id.restype, L.orc_seq_id.argtypes = u64, [p, u64]
@@ -183,6 +186,13 @@ class RIndex:
         self.L.orc_count(self.h, mode, b, len(b), C.byref(lo), C.byref(hi))
         return lo.value, hi.value
 
+    def LF(self, rng, sym, mode=MODE_COMPAT):
+        """FastLocate::LF / LF_encoded on the inclusive range rng = (first, second)"""
+        sym = ord(sym) if isinstance(sym, str) else sym
+        lo, hi = C.c_uint64(rng[0]), C.c_uint64(rng[1])
+        self.L.orc_LF(self.h, mode, sym, C.byref(lo), C.byref(hi))
+        return lo.value, hi.value
+
     max_length = property(lambda s: s.L.orc_ri_max_length(s.h))
 
     def locate_first(self):
@@ -215,6 +225,13 @@ class RIndex:
         if sa is None:
             return None
         return np.unique(sa // np.uint64(self.max_length))
+
+    def find_mems_function(self, read, min_len, min_occ, x, mode=MODE_COMPAT):
+        """one call at start x -> (next_x, mem tuple or None, extensions)"""
+        b = read.encode() if isinstance(read, str) else bytes(read)
+        m, has, ne = Mem(), C.c_int(0), C.c_uint64(0)
+        nx = self.L.orc_find_mems_function(self.h, mode, b, len(b), min_len, min_occ, x, C.byref(m), C.byref(has), C.byref(ne))
+        return nx, ((m.start, m.end, m.bwt_start, m.size) if has.value else None), ne.value
 
     def find_all_mems(self, read, min_len, min_occ, mode=MODE_COMPAT, with_ext=False):
         b = read.encode() if isinstance(read, str) else bytes(read)

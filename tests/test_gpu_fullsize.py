@@ -1,0 +1,38 @@
+"""Full-size parity of the sigma = 6 synthetic pangenome workload inside the -m gpu tier: SURVEY 8d
+config-3 recipe at 1/10 scale (4 Mbp x 8 haplotypes x 2 strands, n = 64 M, r = 6.3 M), 1 M synthetic 150-bp reads,
+min_len 20 -- about 1.9 M MEMs, 23 M positions, 196 M extensions -- every MEM, run count and position against the CPU
+oracle, under both layouts of the device rank image.  (The same check at chr22 scale, n = 640 M, is
+scripts/parity_full_synth.py; its output is committed under profiles/.)"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import pgx_ffi as P
+import pgx_workload as W
+
+pytestmark = pytest.mark.gpu
+
+
+def test_synth_pangenome_one_million_reads(workdir):
+    text = os.path.join(workdir, "full_synth.txt")
+    W.synth_pangenome_text(text, base_len=4_000_000)
+    ri_path, tags_path = W.build_index_from_text(text, workdir, "full_synth")[:2]
+    seqs = W.load_sequences(text)
+    cat, offs = W.sample_reads(seqs, 1_000_000, 150, seed=42 + 3)
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    assert ri.sigma == 6 and ri.n > 60_000_000
+    ref = O.find_mems_batch(ri, tags, cat, offs, 20, 1, threads=O.lib().orc_max_threads())
+    assert len(ref["mems"]) > 1_500_000 and len(ref["positions"]) > 10_000_000 and ref["n_extensions"] > 150_000_000
+    for force in (P.MODE_IMAGE_DENSE, P.MODE_IMAGE_RL):
+        idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | force)
+        res = idx.find_mems(cat, offs, 20, 1, tags=True)
+        assert np.array_equal(res["mem_offsets"], ref["mem_offsets"])
+        assert res["mems"].tobytes() == ref["mems"].tobytes()
+        assert res["n_extensions"] == ref["n_extensions"]
+        assert np.array_equal(res["tag_run_counts"], ref["tag_run_counts"])
+        assert np.array_equal(res["pos_offsets"], ref["pos_offsets"])
+        assert np.array_equal(res["positions"], ref["positions"])
+        assert res["n_tag_overflow"] == ref["n_tag_overflow"]
+        idx.close()

@@ -192,14 +192,41 @@ def test_tag_queries_all_sort_paths(xy):
     assert seen == {0, 1, 2}
 
 
-def test_config2_one_million_reads(xenc, golden):
-    """BASELINE configs[1]: x index, 1M synthetic 150-bp reads, bit-exact vs the CPU oracle."""
+@pytest.mark.parametrize("min_len", [10, 20])
+def test_config2_one_million_reads(xenc, golden, min_len):
+    """BASELINE configs[1]: x index, 1M synthetic 150-bp reads, bit-exact vs the CPU oracle.  min_len 10 is what bench.py's
+    x workload runs (about 1.5 M MEMs and 1.7 M positions: emit path, slot compaction, CSR scans over > 2048 scan blocks and the
+    whole tag pipeline at full size); at min_len 20 every COMPAT search on this no-N index dies (quirk 1): zero MEMs, only the
+    extension counts and the empty CSR are compared there."""
     idx, ri, tags = xenc
     seqs = W.load_sequences(os.path.join(golden, "x.newline_separated"))
     cat, offs = W.sample_reads(seqs, 1_000_000, 150, seed=42 + 2)
-    ref = O.find_mems_batch(ri, tags, cat, offs, 20, 1, threads=O.lib().orc_max_threads())
-    res = idx.find_mems(cat, offs, 20, 1, tags=True)
+    ref = O.find_mems_batch(ri, tags, cat, offs, min_len, 1, threads=O.lib().orc_max_threads())
+    res = idx.find_mems(cat, offs, min_len, 1, tags=True)
     _assert_same(res, ref, True)
+    if min_len == 10:
+        assert len(ref["mems"]) > 10**6 and ref["mem_offsets"][-1] == len(ref["mems"]) and len(ref["positions"]) > 10**6
+    else:
+        assert len(ref["mems"]) == 0 and ref["n_extensions"] > 10**7
+
+
+def test_find_mems_function_per_start(xy, xenc, golden):
+    """find_mems_function (algorithm.hpp:653-736) evaluated at EVERY start position of a set of reads (not only the starts the
+    loop of find_all_mems visits): next start, pushed MEM and extension count vs the oracle"""
+    for (idx, ri, _), text in ((xy, "bidirectional_test/contigs_xy"), (xenc, "x.newline_separated")):
+        seqs = W.load_sequences(os.path.join(golden, text))
+        cat, offs = W.sample_reads(seqs, 40, 90, seed=5)
+        reads = [bytes(cat[int(offs[i]):int(offs[i + 1])]) for i in range(40)] + [b"", b"ACGT", b"N" * 12]
+        cat, offs = O.pack_reads(reads)
+        read_of = np.concatenate([np.full(len(r) + 1, i, dtype=np.uint64) for i, r in enumerate(reads)])
+        xs = np.concatenate([np.arange(len(r) + 1, dtype=np.uint64) for r in reads])  # x = len included (only min_len 0 works there)
+        for min_len, min_occ in [(5, 1), (0, 1), (12, 2), (200, 1)]:
+            nx, mems, has, ne = idx.find_mems_function_batch(cat, offs, read_of, xs, min_len, min_occ)
+            for q in range(len(xs)):
+                enx, emem, ene = ri.find_mems_function(reads[int(read_of[q])], min_len, min_occ, int(xs[q]))
+                assert int(nx[q]) == enx and int(ne[q]) == ene and bool(has[q]) == (emem is not None), (q, min_len)
+                if emem is not None:
+                    assert tuple(int(v) for v in mems[q]) == emem
 
 
 def test_chunked_batches_equal_unchunked(xenc, xy, golden, monkeypatch):
