@@ -6,18 +6,25 @@ src/find_mems.cpp:94-139 without the printing) over one device-resident batch of
 150-bp reads.  Reads shard by rank with the index replicated and no data-path collective
 (SURVEY 8e), so scaling is "weak": every rank owns `--reads` reads.
 
-Workloads (config.workload):
-  x      BASELINE configs[1]: index built from test_data/x.rl_bwt (committed as tests/golden/x.rl_bwt),
-         1M synthetic reads per GPU.  min_len defaults to 10: at the README's other example (20) the
-         reference's rank-cache quirk on this no-N index finds zero MEMs (DESIGN.md "Workloads").
-  synth  sigma=6 synthetic pangenome (SURVEY 8d config-3 recipe scaled by --base-len): proper FMD
-         index where COMPAT == STRICT; BWT built in-process by SA-IS.
+`python bench.py --gpus N` starts N ranks itself (one child process per GPU, before anything touches a
+GPU in this process) unless it already runs under a launcher (WORLD_SIZE set, e.g. torch.distributed.run).
 
-Prints ONE JSON line on rank 0.  The CPU oracle is used here only for the `cpu_baseline` leg.
+Workloads (config.workload):
+  chr22  (default) BASELINE configs[2] / SURVEY 8d config 3 at full scale: synthetic sigma=6 pangenome, 40 Mbp base x 8
+         haplotypes x 2 strands (n = 640 M, r = 65 M runs, COMPAT == STRICT), rank image resident in HBM,
+         10 M reads per GPU, min_len 20.  The index is built in-process on the host first (SA-IS; minutes).
+  synth  the same recipe at --base-len (default 4 Mbp: n = 64 M, Infinity-Cache resident), 1 M reads.
+  x      BASELINE configs[1]: index built from test_data/x.rl_bwt (committed as tests/golden/x.rl_bwt), 1 M reads;
+         the whole rank image sits in LDS.  min_len defaults to 10: at 20 the reference's rank-cache quirk on this
+         no-N index finds zero MEMs (DESIGN.md "Workloads").  Also reported inside the default run as `secondary`.
+  chrom  BASELINE configs[4] shape: chromosome-sharded indexes + exchange of per-read MEM lists.
+
+Prints ONE JSON line on rank 0.  The CPU oracle is used here only for the `cpu_baseline` legs.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import tempfile
 import time
@@ -25,27 +32,33 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pangenome-index_amd"))
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
+DEFAULTS = {  # workload -> (reads per GPU, min_len, base_len)
+    "chr22": (10_000_000, 20, 40_000_000),
+    "synth": (1_000_000, 20, 4_000_000),
+    "x": (1_000_000, 10, None),
+    "chrom": (1_000_000, 20, 4_000_000),
+}
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="x", choices=["x", "synth", "chrom"])
+    ap.add_argument("--workload", default="chr22", choices=sorted(DEFAULTS))
     ap.add_argument("--chroms", type=int, default=6, help="chrom: number of synthetic chromosomes (sharded over the ranks)")
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--min-len", type=int, default=None)
     ap.add_argument("--min-occ", type=int, default=1)
-    ap.add_argument("--base-len", type=int, default=4_000_000, help="synth: base sequence length")
-    ap.add_argument("--haps", type=int, default=8, help="synth: haplotypes (each in both strands)")
+    ap.add_argument("--base-len", type=int, default=None, help="chr22 / synth / chrom: base sequence length")
+    ap.add_argument("--haps", type=int, default=8, help="chr22 / synth: haplotypes (each in both strands)")
     ap.add_argument("--mode", default="compat", choices=["compat", "strict"])
     ap.add_argument("--no-tags", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="chr22: skip the nested x (configs[1]) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target core-seconds of the CPU sample")
     ap.add_argument("--workdir", default=None)
     ap.add_argument("--pcie", action="store_true",
@@ -53,14 +66,70 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --one-device rehearses the N>1 path on a single-GPU box")
     ap.add_argument("--one-device", action="store_true", help="every rank uses device 0 (rehearsal only)")
-    return ap.parse_args()
+    ap.add_argument("--stub-workload", action="store_true",
+                    help="launcher self-test: no GPU work, every rank contributes a constant (tests/test_bench_launch.py)")
+    args = ap.parse_args(argv)
+    d = DEFAULTS[args.workload]
+    if args.reads is None:
+        args.reads = d[0]
+    if args.min_len is None:
+        args.min_len = d[1]
+    if args.base_len is None:
+        args.base_len = d[2]
+    return args
 
 
-def make_workload(args, rank, world, wd, barrier):
+# ----------------------------------------------------------------------------------------------------------------------
+# --gpus N without an external launcher: N child processes, one rank each, started before this process touches a GPU
+def free_port():
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def fan_out(n, argv):
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        # rank 0 inherits stdout (its one JSON line is the bench's output); the other ranks print nothing on stdout
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("[bench] ranks failed: %s\n" % bad)
+        return 1
+    return 0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def synth_index(W, wd, base_len, haps, rank, barrier):
+    """the sigma = 6 synthetic pangenome index of SURVEY 8d config 3 (scaled by base_len); rank 0 builds, all ranks load"""
+    name = "synth_%d_%d" % (base_len, haps)
+    text = os.path.join(wd, name + ".txt")
+    done = os.path.join(wd, name + ".done")
+    build_s = 0.0
+    if rank == 0 and not os.path.exists(done):
+        t0 = time.time()
+        W.synth_pangenome_text(text, base_len=base_len, n_hap=haps, seed=45)
+        W.build_index_from_text(text, wd, name)
+        open(done, "w").write("ok\n")
+        build_s = time.time() - t0
+        sys.stderr.write("[bench] synthetic index built in %.1f s (host, SA-IS)\n" % build_s)
+    barrier()
+    return os.path.join(wd, name + ".ri"), os.path.join(wd, name + ".compact.tags"), text, build_s
+
+
+def make_workload(args, workload, rank, wd, barrier, n_reads, base_len):
     import pgx_workload as W
 
     golden = os.path.join(ROOT, "tests", "golden")
-    if args.workload == "x":
+    build_s = 0.0
+    if workload == "x":
         name = "x"
         if rank == 0:
             W.build_index_from_rlbwt(os.path.join(golden, "x.rl_bwt"), wd, name)
@@ -70,32 +139,105 @@ def make_workload(args, rank, world, wd, barrier):
         seed = 42 + 2
         desc = "x.rl_bwt index (n=3012, sigma=5), BASELINE configs[1]"
     else:
-        name = "synth_%d_%d" % (args.base_len, args.haps)
-        text = os.path.join(wd, name + ".txt")
-        if rank == 0 and not os.path.exists(os.path.join(wd, name + ".ri")):
-            t0 = time.time()
-            W.synth_pangenome_text(text, base_len=args.base_len, n_hap=args.haps, seed=45)
-            W.build_index_from_text(text, wd, name)
-            sys.stderr.write("[bench] synthetic index built in %.1f s\n" % (time.time() - t0))
-        barrier()
-        ri, tags = os.path.join(wd, name + ".ri"), os.path.join(wd, name + ".compact.tags")
+        ri, tags, text, build_s = synth_index(W, wd, base_len, args.haps, rank, barrier)
         seqs = W.load_sequences(text)
         seed = 42 + 3
-        desc = "synthetic pangenome: %d bp base x %d haplotypes x 2 strands, sigma=6" % (args.base_len, args.haps)
-    cat, offs = W.sample_reads(seqs, args.reads, args.read_len, seed=seed + 1000 * rank)
-    return ri, tags, cat, offs, desc
+        desc = "synthetic pangenome: %d bp base x %d haplotypes x 2 strands, sigma=6" % (base_len, args.haps)
+        if workload == "chr22":
+            desc += " (chr22-scale, SURVEY 8d config 3 = BASELINE configs[2])"
+    cat, offs = W.sample_reads(seqs, n_reads, args.read_len, seed=seed + 1000 * rank)
+    return ri, tags, cat, offs, desc, build_s
+
+
+def measure(P, idx, cat, offs, local, min_len, min_occ, flags, steps, warmup, stream, sync, barrier):
+    """W warm-up steps, then exactly K timed steps between barrier + device synchronisation on both sides"""
+    batch = idx.batch(cat, offs, device=local)  # inputs resident in HBM before the timed region
+    for _ in range(warmup):
+        batch.run(min_len, min_occ, flags, stream)
+    sync()
+    barrier()
+    t0 = time.perf_counter()
+    k_ms = dict(find_mems=0.0, compact=0.0, tag_locate=0.0, tag_gather=0.0, tag_sort=0.0, total=0.0)
+    for _ in range(steps):
+        batch.run(min_len, min_occ, flags, stream)
+        t = batch.timing()  # HIP events recorded on the launch stream inside pgx_batch_run
+        for key in k_ms:
+            k_ms[key] += getattr(t, "ms_" + key)
+    sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    n_mems, n_pos, n_ext = batch.counts()
+    return batch, dt, {k: v / steps for k, v in k_ms.items()}, (n_mems, n_pos, n_ext)
+
+
+def roofline_record(info, cat_len, n_reads, counts, fm_ms, workload_key, min_len, tags):
+    """roofline of the dominant kernel (pgx_find_mems_kernel), SURVEY 8d "Algorithmic bytes": per extension 2 rank probes x
+    (B_blk + 16 B directory) in the reference's layout, per read L+1 input bytes, per MEM 32 output bytes; extensions and MEMs are
+    the kernel's own exact counters (equal to the oracle's, asserted in the parity tests)."""
+    n_mems, _, n_ext = counts
+    b_blk = float(info.ref_block_mean_bytes)
+    algo_bytes = n_ext * 2.0 * (b_blk + 16.0) + float(cat_len + n_reads) + 32.0 * n_mems
+    achieved = algo_bytes / (fm_ms * 1e-3) / 1e9 if fm_ms > 0 else 0.0
+    in_lds = bool(info.image_in_lds)
+    rec = {
+        # what bounds the kernel: with the rank image staged in LDS nothing of it comes from HBM (issue slots / LDS bound it);
+        # otherwise random 128-byte line fetches from HBM (or the Infinity Cache when the image fits it)
+        "bound": "lds/valu" if in_lds else "hbm",
+        "kernel": "pgx_find_mems_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "frac_note": ("algorithmic bytes of the reference layout over kernel time, relative to the HBM peak; the image is in LDS, so this is "
+                      "a nominal ratio, not an achieved HBM fraction") if in_lds else
+                     "algorithmic bytes of the reference layout (SURVEY 8d) over kernel time, relative to the HBM peak",
+        "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": fm_ms,
+        "bytes_per_extension": 2.0 * (b_blk + 16.0), "extensions_per_launch": n_ext,
+    }
+    # counter traffic only from a PMC record of THIS workload (scripts/profile_round.sh writes what it measured)
+    tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload_key)
+    if os.path.exists(tfile):
+        try:
+            t = json.load(open(tfile))
+            same = (int(t.get("bwt_size", -1)) == int(info.bwt_size) and int(t.get("reads", -1)) == int(n_reads)
+                    and int(t.get("min_len", -1)) == int(min_len) and int(t.get("image_kind", -1)) == int(info.image_kind)
+                    and bool(t.get("tags", True)) == bool(tags))
+            if same:
+                rec["traffic"] = t.get("find_mems_hbm_bytes_per_launch")
+                rec["traffic_source"] = "profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % workload_key
+        except Exception:
+            pass
+    return rec
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(fan_out(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.min_len is None:
-        args.min_len = 10 if args.workload == "x" else 20
+
+    import datetime
 
     import torch
     import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=40))
+    red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    if args.stub_workload:  # launcher self-test (CPU tier): no GPU, the line still goes through the same reductions
+        ones = torch.ones(1, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(ones)
+        if rank == 0:
+            print(json.dumps({"metric": "stub", "value": float(world), "unit": "ranks", "n_gpus": world, "n_ranks_seen": int(ones.item()),
+                              "steps": args.steps, "warmup": args.warmup}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     import pgx_ffi as P
 
@@ -104,13 +246,11 @@ def main():
     if args.one_device:
         local = 0
     torch.cuda.set_device(local)
+    # RCCL (or gloo in a rehearsal) sees every rank: sum of ones
+    ones = torch.ones(1, dtype=torch.float64, device=red_dev)
     if world > 1:
-        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
-    red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
+        dist.all_reduce(ones)
+    n_ranks_seen = int(ones.item())
 
     own_tmp = None
     if args.workdir:
@@ -118,41 +258,29 @@ def main():
         os.makedirs(wd, exist_ok=True)
     else:
         # all ranks of one node share the directory rank 0 fills
-        wd = os.path.join(tempfile.gettempdir(), "pgx_bench_%s" % os.environ.get("MASTER_PORT", str(os.getppid())))
+        wd = os.path.join(tempfile.gettempdir(), "pgx_bench_%s" % os.environ.get("MASTER_PORT", str(os.getpid())))
         os.makedirs(wd, exist_ok=True)
         own_tmp = wd
 
     if args.workload == "chrom":
         return run_chrom(args, rank, world, local, wd, barrier, dist, red_dev)
-    ri, tags, cat, offs, desc = make_workload(args, rank, world, wd, barrier)
+    t_prep = time.time()
+    ri, tags, cat, offs, desc, build_s = make_workload(args, args.workload, rank, wd, barrier, args.reads, args.base_len)
     mode = P.MODE_COMPAT if args.mode == "compat" else P.MODE_STRICT
     idx = P.Index(ri, None if args.no_tags else tags, mode=mode)
     info = idx.info()
     idx.to_device(local)
-    batch = idx.batch(cat, offs, device=local)  # inputs resident in HBM before the timed region
+    prep_s = time.time() - t_prep
     flags = P.RUN_TIMING | (0 if args.no_tags else P.RUN_TAGS)
     stream = torch.cuda.current_stream().cuda_stream
 
-    for _ in range(args.warmup):
-        batch.run(args.min_len, args.min_occ, flags, stream)
-    torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    k_ms = dict(find_mems=0.0, compact=0.0, tag_locate=0.0, tag_gather=0.0, tag_sort=0.0, total=0.0)
-    for _ in range(args.steps):
-        batch.run(args.min_len, args.min_occ, flags, stream)
-        t = batch.timing()
-        for key in k_ms:
-            k_ms[key] += getattr(t, "ms_" + key)
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
+    batch, dt, k_ms, counts = measure(P, idx, cat, offs, local, args.min_len, args.min_occ, flags, args.steps, args.warmup, stream,
+                                      torch.cuda.synchronize, barrier)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    n_mems, n_pos, n_ext = batch.counts()
-    tot = torch.tensor([float(n_mems), float(n_pos), float(n_ext)], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([float(c) for c in counts], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     tot = [float(v) for v in tot.tolist()]
@@ -160,26 +288,13 @@ def main():
     if rank == 0:
         K, n = args.steps, args.reads
         reads_total = n * world * K
-        # roofline of the dominant kernel (pgx_find_mems_kernel), SURVEY 8d "Algorithmic bytes":
-        #   per extension 2 rank probes x (B_blk + 16 B directory), per read L+1 input bytes,
-        #   per MEM 32 output bytes; E_read and MEMs are the kernel's own exact counters.
-        b_blk = float(info.ref_block_mean_bytes)
-        read_bytes = float(len(cat) + n)
-        algo_bytes = n_ext * 2.0 * (b_blk + 16.0) + read_bytes + 32.0 * n_mems
-        fm_ms = k_ms["find_mems"] / K
-        achieved = algo_bytes / (fm_ms * 1e-3) / 1e9 if fm_ms > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get("find_mems_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        image = "LDS" if info.image_in_lds else ("dense bit planes" if info.image_kind == P.IMAGE_DENSE else "run-length blocks")
         line = {
             "metric": "find_mems reads/sec (150 bp batch)",
             "value": reads_total / dt,
             "unit": "reads/s",
             "n_gpus": world,
+            "n_ranks_seen": n_ranks_seen,
             "steps": K,
             "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3,
@@ -189,35 +304,35 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": ("x.rl_bwt index, %d synthetic %d-bp reads per GPU" % (n, args.read_len)) if args.workload == "x"
-                else desc + ", %d reads per GPU" % n,
+                "workload": {"chr22": "BASELINE configs[2]: chr22-scale synthetic pangenome index (n = %d), %d synthetic %d-bp reads per GPU, 1 MI355X per rank" % (info.bwt_size, n, args.read_len),
+                             "synth": desc + ", %d reads per GPU" % n,
+                             "x": "BASELINE configs[1]: x.rl_bwt index, %d synthetic %d-bp reads per GPU" % (n, args.read_len)}[args.workload],
                 "index": desc, "reads_per_gpu": n, "read_len": args.read_len, "min_len": args.min_len,
                 "min_occ": args.min_occ, "mode": args.mode, "tags": not args.no_tags,
                 "sharding": "reads sharded by rank, index replicated, no collective",
                 "bwt_size": int(info.bwt_size), "bwt_runs": int(info.n_runs), "image_in_lds": bool(info.image_in_lds),
+                "rank_image": "%s, %.0f MB%s" % (image, info.image_bytes / 1e6, "" if info.image_in_lds else ", resident in HBM"),
+                "tag_image_MB": info.tag_image_bytes / 1e6,
+                "index_build_host_s": round(build_s, 1), "prep_s": round(prep_s, 1),
             },
             "mems_per_s": tot[0] * K / dt,
             "extensions_per_s": tot[2] * K / dt,
             "mems_per_step": tot[0], "positions_per_step": tot[1], "extensions_per_step": tot[2],
-            "kernel_ms_per_step": {k: v / K for k, v in k_ms.items()},
-            "roofline": {
-                "bound": "hbm", "kernel": "pgx_find_mems_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
-                "kernel_ms": fm_ms, "bytes_per_extension": 2.0 * (b_blk + 16.0),
-            },
+            "kernel_ms_per_step": k_ms,
+            "roofline": roofline_record(info, len(cat), n, counts, k_ms["find_mems"], args.workload, args.min_len, not args.no_tags),
         }
         if args.pcie:
-            t1 = time.perf_counter()
-            reps = 3
-            for _ in range(reps):
-                res = idx.find_mems(cat, offs, args.min_len, args.min_occ, tags=not args.no_tags, device=local)
-            line["pcie_inclusive_reads_per_s"] = n * reps / (time.perf_counter() - t1)
+            line["pcie_inclusive_reads_per_s"] = pcie_rate(idx, cat, offs, args, local)
             line["pcie_inclusive_note"] = "pgx_find_mems_batch: H2D of reads+offsets, all kernels, D2H of MEMs/positions, host CSR copies"
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args, ri, tags, cat, offs)
-        print(json.dumps(line), flush=True)
+            line["cpu_baseline"] = cpu_baseline(args, ri, None if args.no_tags else tags, cat, offs, args.min_len)
     batch.free()
     idx.close()
+    del cat, offs
+    if rank == 0:
+        if args.workload == "chr22" and world == 1 and not args.no_secondary:
+            line["secondary"] = secondary_x(args, P, wd, local, stream, torch)
+        print(json.dumps(line), flush=True)
     barrier()
     if world > 1:
         dist.destroy_process_group()
@@ -225,6 +340,39 @@ def main():
         import shutil
 
         shutil.rmtree(own_tmp, ignore_errors=True)
+
+
+def pcie_rate(idx, cat, offs, args, local, min_len=None, reps=3):
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        idx.find_mems(cat, offs, args.min_len if min_len is None else min_len, args.min_occ, tags=not args.no_tags, device=local)
+    return (len(offs) - 1) * reps / (time.perf_counter() - t1)
+
+
+def secondary_x(args, P, wd, local, stream, torch):
+    """BASELINE configs[1] (x index, 1 M reads, min_len 10: where the >= 10x CPU target is stated) measured in the same run"""
+    n, min_len = DEFAULTS["x"][0], DEFAULTS["x"][1]
+    ri, tags, cat, offs, desc, _ = make_workload(args, "x", 0, wd, lambda: None, n, None)
+    idx = P.Index(ri, None if args.no_tags else tags, mode=P.MODE_COMPAT if args.mode == "compat" else P.MODE_STRICT)
+    info = idx.info()
+    flags = P.RUN_TIMING | (0 if args.no_tags else P.RUN_TAGS)
+    batch, dt, k_ms, counts = measure(P, idx, cat, offs, local, min_len, args.min_occ, flags, args.steps, args.warmup, stream,
+                                      torch.cuda.synchronize, lambda: None)
+    out = {
+        "workload": "BASELINE configs[1]: x.rl_bwt index (n=3012, sigma=5, no N), %d synthetic %d-bp reads, 1 MI355X" % (n, args.read_len),
+        "value": n * args.steps / dt, "unit": "reads/s", "ms_per_step": dt / args.steps * 1e3, "min_len": min_len,
+        "mems_per_step": counts[0], "positions_per_step": counts[1], "extensions_per_step": counts[2], "kernel_ms_per_step": k_ms,
+        "image_in_lds": bool(info.image_in_lds),
+        "roofline": roofline_record(info, len(cat), n, counts, k_ms["find_mems"], "x", min_len, not args.no_tags),
+        "pcie_inclusive_reads_per_s": pcie_rate(idx, cat, offs, args, local, min_len=min_len),
+        "caveat": "no-N index: COMPAT searches die at every T (SURVEY 8a quirk 1), reads/s is inflated relative to a proper FMD index",
+    }
+    batch.free()
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, ri, None if args.no_tags else tags, cat, offs, min_len, seconds=min(args.cpu_seconds, 8.0))
+        out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["value"]
+    idx.close()
+    return out
 
 
 def run_chrom(args, rank, world, local, wd, barrier, dist, red_dev):
@@ -284,7 +432,8 @@ def run_chrom(args, rank, world, local, wd, barrier, dist, red_dev):
             "config": {"workload": "chromosome-sharded: %d synthetic chromosomes over %d ranks, %d reads searched in every shard, "
                                    "all_gather of per-read MEM lists" % (K, world, args.reads),
                        "chrom_lengths": lengths, "owners": owners, "min_len": args.min_len, "min_occ": args.min_occ,
-                       "exchange": "torch.distributed all_gather (%s), host-staged records" % args.dist_backend},
+                       "exchange": "torch.distributed all_gather (%s), %s" % (args.dist_backend, "device-resident records over RCCL" if dev == "cuda"
+                                                                              else "host-staged records")},
             "mems_per_step": int(mo[-1]), "mems_per_s": float(mo[-1]) * args.steps / dt,
         }), flush=True)
     for b in batches.values():
@@ -318,26 +467,28 @@ def host_cores(omp_max):
     return max(1, n)
 
 
-def cpu_baseline(args, ri, tags, cat, offs):
+def cpu_baseline(args, ri, tags, cat, offs, min_len, seconds=None):
     """The oracle (kind "port": the reference cannot be built here) on a bounded sample of the same
     reads, all host cores via OpenMP over reads; timed regions = find_all_mems + tag queries."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi as O
 
+    seconds = args.cpu_seconds if seconds is None else seconds
     r = O.RIndex(ri)
-    t = None if args.no_tags else O.Tags(tags, O.TAGS_COMPACT)
+    t = None if tags is None else O.Tags(tags, O.TAGS_COMPACT)
     mode = O.MODE_COMPAT if args.mode == "compat" else O.MODE_STRICT
     cores = host_cores(O.lib().orc_max_threads())
     L = args.read_len
+    n_reads = len(offs) - 1
     # one thread first (the reference's own execution model): calibrates the per-core rate
-    one = min(args.reads, 5000)
-    res1 = O.find_mems_batch(r, t, cat[: one * L], offs[: one + 1], args.min_len, args.min_occ, mode=mode, threads=1)
+    one = min(n_reads, 5000)
+    res1 = O.find_mems_batch(r, t, cat[: one * L], offs[: one + 1], min_len, args.min_occ, mode=mode, threads=1)
     sec1 = max(res1["seconds_mems"] + res1["seconds_tags"], 1e-6)
     # all cores on a sample worth ~cpu_seconds core-seconds (bounded by the batch), best of 3
-    sample = int(min(args.reads, max(one, (one / sec1) * args.cpu_seconds)))
+    sample = int(min(n_reads, max(one, (one / sec1) * seconds)))
     best = None
     for _ in range(3):
-        res = O.find_mems_batch(r, t, cat[: sample * L], offs[: sample + 1], args.min_len, args.min_occ, mode=mode, threads=cores)
+        res = O.find_mems_batch(r, t, cat[: sample * L], offs[: sample + 1], min_len, args.min_occ, mode=mode, threads=cores)
         sec = res["seconds_mems"] + res["seconds_tags"]
         best = sec if best is None else min(best, sec)
     return {"value": sample / best, "unit": "reads/s", "cores": cores, "kind": "port",

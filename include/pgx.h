@@ -131,6 +131,10 @@ pgx_status pgx_build_rindex(const char *rlbwt_path, const char *out_ri_path, int
 /* BWT of a newline-terminated sequence collection (what grlBWT produces for the reference):
  * writes the grlBWT .rl_bwt layout read by bwt_buff_reader. */
 pgx_status pgx_build_rlbwt(const char *text_path, const char *out_rlbwt_path);
+/* Both steps in one call (out_rlbwt_path may be NULL): the suffix array the BWT is made from also yields the SA samples
+ * directly, so the sampling walk of FastLocate(std::string) (src/r-index.cpp:993-1130) is not repeated; the .ri written
+ * is byte-identical to pgx_build_rlbwt + pgx_build_rindex. */
+pgx_status pgx_build_index_from_text(const char *text_path, const char *out_rlbwt_path, const char *out_ri_path, int encoded);
 /* Write a compact sdsl tag file (format 3, src/tag_arrays.cpp:940-974 + :622-654) from parallel
  * arrays of run values (already `offset | rev<<10 | node<<11`) and run lengths. */
 pgx_status pgx_write_compact_tags(const char *out_path, const uint64_t *values,

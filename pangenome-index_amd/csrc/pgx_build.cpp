@@ -113,10 +113,16 @@ struct Sais {
 // convention of the reference's fixtures and of tests/test_rindex.cpp:35-60: rotations of the text
 // with distinct increasing terminators).  Output: grlBWT run file (u64 bytes/symbol = 1,
 // u64 bytes/length, then (symbol, length) records).
-extern "C" pgx_status pgx_build_rlbwt(const char *text_path, const char *out_rlbwt_path) {
-    PGX_GUARD_BEGIN
-    if (!text_path || !out_rlbwt_path) throw Error(PGX_ERR_ARG, "pgx_build_rlbwt: null argument");
-    std::vector<uint8_t> text = read_whole_file(text_path);
+// Suffix array of the collection (row 0 = the extra terminator, row p + 1 = BWT position p) and its BWT runs.
+struct TextBwt {
+    std::vector<uint8_t> text;                        // newline-terminated
+    std::vector<int32_t> SA;                          // n + 1 entries
+    std::vector<std::pair<uint8_t, uint64_t>> runs;   // grlBWT-style maximal runs (endmarkers not split)
+    uint64_t max_len = 1;
+};
+static void build_text_bwt(const char *text_path, TextBwt &o) {
+    o.text = read_whole_file(text_path);
+    std::vector<uint8_t> &text = o.text;
     if (!text.empty() && text.back() != '\n') text.push_back('\n');
     const uint64_t n = text.size();
     if (n + 1 >= (1ull << 31)) throw Error(PGX_ERR_UNSUPPORTED, "text longer than 2^31 - 2 symbols");
@@ -129,31 +135,41 @@ extern "C" pgx_status pgx_build_rlbwt(const char *text_path, const char *out_rlb
     int32_t K = (int32_t)m + 1;
     for (int c = 0; c < 256; c++)
         if (present[c] && c != '\n') rank_of[c] = K++;
-    std::vector<int32_t> s(n + 1), SA(n + 1);
+    std::vector<int32_t> s(n + 1);
+    o.SA.resize(n + 1);
     int32_t seq = 0;
     for (uint64_t i = 0; i < n; i++) s[i] = text[i] == '\n' ? ++seq : rank_of[text[i]];
     s[n] = 0;
-    Sais::run(s.data(), SA.data(), (int32_t)(n + 1), K);
+    Sais::run(s.data(), o.SA.data(), (int32_t)(n + 1), K);
     s.clear();
     s.shrink_to_fit();
-    std::vector<std::pair<uint8_t, uint64_t>> runs;
-    uint64_t max_len = 1;
     for (uint64_t i = 1; i <= n; i++) { // SA[0] is the extra terminator
-        uint64_t p = (uint64_t)SA[i];
+        uint64_t p = (uint64_t)o.SA[i];
         uint8_t c = p ? text[p - 1] : text[n - 1];
-        if (!runs.empty() && runs.back().first == c) { runs.back().second++; max_len = std::max(max_len, runs.back().second); }
-        else runs.emplace_back(c, 1);
+        if (!o.runs.empty() && o.runs.back().first == c) { o.runs.back().second++; o.max_len = std::max(o.max_len, o.runs.back().second); }
+        else o.runs.emplace_back(c, 1);
     }
+}
+static void write_rlbwt(const char *out_rlbwt_path, const TextBwt &b) {
     uint64_t bl = 1;
-    while (bl < 8 && (max_len >> (8 * bl))) bl++;
+    while (bl < 8 && (b.max_len >> (8 * bl))) bl++;
     std::vector<uint8_t> out;
+    out.reserve(16 + b.runs.size() * (1 + bl));
     put<uint64_t>(out, 1);
     put<uint64_t>(out, bl);
-    for (auto &r : runs) {
+    for (auto &r : b.runs) {
         out.push_back(r.first);
-        for (uint64_t b = 0; b < bl; b++) out.push_back((uint8_t)(r.second >> (8 * b)));
+        for (uint64_t k = 0; k < bl; k++) out.push_back((uint8_t)(r.second >> (8 * k)));
     }
     write_whole_file(out_rlbwt_path, out);
+}
+
+extern "C" pgx_status pgx_build_rlbwt(const char *text_path, const char *out_rlbwt_path) {
+    PGX_GUARD_BEGIN
+    if (!text_path || !out_rlbwt_path) throw Error(PGX_ERR_ARG, "pgx_build_rlbwt: null argument");
+    TextBwt b;
+    build_text_bwt(text_path, b);
+    write_rlbwt(out_rlbwt_path, b);
     return PGX_OK;
     PGX_GUARD_END
 }
@@ -177,10 +193,11 @@ static std::vector<std::pair<uint8_t, uint64_t>> read_rlbwt(const std::string &p
     return runs;
 }
 
-extern "C" pgx_status pgx_build_rindex(const char *rlbwt_path, const char *out_ri_path, int encoded) {
-    PGX_GUARD_BEGIN
-    if (!rlbwt_path || !out_ri_path) throw Error(PGX_ERR_ARG, "pgx_build_rindex: null argument");
-    auto file_runs = read_rlbwt(rlbwt_path);
+// FastLocate(std::string) + serialize[_encoded].  The SA samples come from the reference's own procedure (a psi walk over
+// every sequence, src/r-index.cpp:993-1130) or, when the caller still holds the suffix array the BWT was made from (`tb`),
+// straight from it: the sample of BWT position p is the (sequence, offset) of suffix SA[p] -- the same values, without
+// n binary searches over the run starts.
+static void build_rindex_core(const std::vector<std::pair<uint8_t, uint64_t>> &file_runs, const TextBwt *tb, const char *out_ri_path, int encoded) {
     // calculate_C, r-index.hpp:440-482: sym_map = rank among present byte values; C = exclusive sums
     uint64_t freq[256] = {0}, n = 0;
     for (auto &r : file_runs) { freq[r.first] += r.second; n += r.second; }
@@ -241,7 +258,35 @@ extern "C" pgx_status pgx_build_rindex(const char *rlbwt_path, const char *out_r
     struct Sample { uint64_t seq_id, seq_offset, run_id; };
     std::vector<Sample> heads, tails;
     uint64_t max_length = 1; // Header(): max_length(1)
-    {
+    if (tb) {
+        // sequence starts in the text; an endmarker belongs to its sequence (offset = length)
+        std::vector<uint64_t> seq_start;
+        seq_start.push_back(0);
+        for (uint64_t i = 0; i + 1 < tb->text.size(); i++)
+            if (tb->text[i] == '\n') seq_start.push_back(i + 1);
+        if (seq_start.size() != n_seq || tb->text.size() != n) throw Error(PGX_ERR_FORMAT, "suffix array and BWT runs disagree");
+        for (uint64_t i = 0; i < n_seq; i++) max_length = std::max(max_length, (i + 1 < n_seq ? seq_start[i + 1] : n) - seq_start[i]);
+        auto sample_at = [&](uint64_t p, uint64_t r) { // BWT position p = suffix SA[p + 1]
+            const uint64_t t = (uint64_t)tb->SA[p + 1];
+            const uint64_t q = (uint64_t)(std::upper_bound(seq_start.begin(), seq_start.end(), t) - seq_start.begin()) - 1;
+            return Sample{q, t - seq_start[q], r};
+        };
+        const uint64_t R = run_start.size();
+        heads.resize(R);
+        tails.resize(R);
+        unsigned nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 16u));
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t]() {
+                for (uint64_t r = R * t / nt; r < R * (t + 1) / nt; r++) {
+                    heads[r] = sample_at(run_start[r], r);
+                    tails[r] = sample_at(run_start[r] + run_len(r) - 1, r);
+                }
+            });
+        for (auto &t : th) t.join();
+        // the reference's walk also records a tail at BWT position n_seq - 1 whether or not a run ends there (:1036)
+        if (n_seq && run_start[run_of(n_seq - 1)] + run_len(run_of(n_seq - 1)) - 1 != n_seq - 1) tails.push_back(sample_at(n_seq - 1, run_of(n_seq - 1)));
+    } else {
         // run ids of the first n_seq BWT positions by symbol change (src/r-index.cpp:993-1008)
         std::vector<uint64_t> endmarker_runs(n_seq, 0);
         {
@@ -295,7 +340,7 @@ extern "C" pgx_status pgx_build_rindex(const char *rlbwt_path, const char *out_r
     }
     if (heads.size() < total_runs || tails.size() < total_runs)
         throw Error(PGX_ERR_FORMAT, "rl_bwt is not the BWT of a newline-terminated collection (sampling walk incomplete)");
-    std::stable_sort(heads.begin(), heads.end(), [](const Sample &a, const Sample &b) { return a.run_id < b.run_id; });
+    if (!tb) std::stable_sort(heads.begin(), heads.end(), [](const Sample &a, const Sample &b) { return a.run_id < b.run_id; }); // (already in run order otherwise)
     std::sort(tails.begin(), tails.end(), [](const Sample &a, const Sample &b) {
         return a.seq_id < b.seq_id || (a.seq_id == b.seq_id && a.seq_offset < b.seq_offset);
     });
@@ -366,6 +411,23 @@ extern "C" pgx_status pgx_build_rindex(const char *rlbwt_path, const char *out_r
         }
     }
     write_whole_file(out_ri_path, out);
+}
+
+extern "C" pgx_status pgx_build_rindex(const char *rlbwt_path, const char *out_ri_path, int encoded) {
+    PGX_GUARD_BEGIN
+    if (!rlbwt_path || !out_ri_path) throw Error(PGX_ERR_ARG, "pgx_build_rindex: null argument");
+    build_rindex_core(read_rlbwt(rlbwt_path), nullptr, out_ri_path, encoded);
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_build_index_from_text(const char *text_path, const char *out_rlbwt_path, const char *out_ri_path, int encoded) {
+    PGX_GUARD_BEGIN
+    if (!text_path || !out_ri_path) throw Error(PGX_ERR_ARG, "pgx_build_index_from_text: null argument");
+    TextBwt b;
+    build_text_bwt(text_path, b);
+    if (out_rlbwt_path) write_rlbwt(out_rlbwt_path, b);
+    build_rindex_core(b.runs, &b, out_ri_path, encoded);
     return PGX_OK;
     PGX_GUARD_END
 }

@@ -104,6 +104,7 @@ def lib():
     L.pgx_index_image_view.argtypes = [p, C.c_int, C.POINTER(p), C.POINTER(u64)]
     L.pgx_build_rindex.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     L.pgx_build_rlbwt.argtypes = [C.c_char_p, C.c_char_p]
+    L.pgx_build_index_from_text.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
     L.pgx_write_compact_tags.argtypes = [C.c_char_p, p, p, u64]
     L.pgx_convert_tags.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     L.pgx_merge_tags.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), u32, p, u64, C.c_int, C.c_char_p]
@@ -155,6 +156,11 @@ def build_rindex(rlbwt_path, out_path, encoded=True):
 
 def build_rlbwt(text_path, out_path):
     _check(lib().pgx_build_rlbwt(text_path.encode(), out_path.encode()))
+
+
+def build_index_from_text(text_path, out_rlbwt_path, out_ri_path, encoded=True):
+    _check(lib().pgx_build_index_from_text(text_path.encode(), out_rlbwt_path.encode() if out_rlbwt_path else None, out_ri_path.encode(),
+                                           1 if encoded else 0))
 
 
 def write_compact_tags(out_path, values, lengths):

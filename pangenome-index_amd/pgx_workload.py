@@ -8,6 +8,7 @@ import struct
 
 import numpy as np
 
+import pgx_ffi
 from pgx_ffi import build_rindex, build_rlbwt, write_compact_tags
 
 _COMP = np.arange(256, dtype=np.uint8)
@@ -58,8 +59,13 @@ def build_index_from_rlbwt(rlbwt_path, workdir, name, encoded=True, with_tags=Tr
 def build_index_from_text(text_path, workdir, name, encoded=True, with_tags=True):
     os.makedirs(workdir, exist_ok=True)
     rl = os.path.join(workdir, name + ".rl_bwt")
-    build_rlbwt(text_path, rl)
-    return build_index_from_rlbwt(rl, workdir, name, encoded, with_tags) + (rl,)
+    ri = os.path.join(workdir, name + (".ri" if encoded else ".legacy.ri"))
+    pgx_ffi.build_index_from_text(text_path, rl, ri, encoded)  # one suffix array for the BWT and the SA samples
+    tags = None
+    if with_tags:
+        tags = os.path.join(workdir, name + ".compact.tags")
+        synthetic_tags_from_runs(rl, tags)
+    return ri, tags, rl
 
 
 def load_sequences(text_path):

@@ -42,6 +42,23 @@ def test_rlbwt_builder_reproduces_fixture_bwt(workdir, text, rlbwt):
         assert ra.rank6_true(pos) == rb.rank6_true(pos)
 
 
+@pytest.mark.parametrize("encoded", [True, False])
+def test_index_from_text_equals_two_step_build(workdir, encoded):
+    """pgx_build_index_from_text takes the SA samples from the suffix array it built the BWT with; the .ri must be byte-identical to
+    pgx_build_rlbwt + pgx_build_rindex (the reference's sampling walk), which reproduces the reference's own .ri files"""
+    import filecmp
+    texts = [os.path.join(G, t) for t in ("x.newline_separated", "med_test.txt", "bidirectional_test/contigs_xy",
+                                          "bidirectional_test/small_test/test.txt", "two_contig_graph/contigs_XY.txt")]
+    synth = os.path.join(workdir, "ift.txt")
+    W.synth_pangenome_text(synth, base_len=30000, n_hap=3, seed=9, n_runs=2, n_run_len=(50, 800))
+    for t in texts + [synth]:
+        rl, a, b = (os.path.join(workdir, "ift." + e) for e in ("rl_bwt", "a.ri", "b.ri"))
+        P.build_rlbwt(t, rl)
+        P.build_rindex(rl, a, encoded)
+        P.build_index_from_text(t, None, b, encoded)
+        assert filecmp.cmp(a, b, shallow=False), t
+
+
 def _tail_from_sym_map(raw):
     """offset of the serialised sym_map (int_vector<8> of 256 entries = u64 2048 then 256 bytes)"""
     key = struct.pack("<Q", 2048)
