@@ -40,7 +40,8 @@ typedef enum {
 /* optional bits or-ed into `mode`: force the layout of the device rank image (default: chosen from the index size;
  * results never depend on it).  PGX_ERR_UNSUPPORTED if dense is forced on a legacy-layout index without N in COMPAT. */
 #define PGX_MODE_IMAGE_RL 0x100u    /* run-length blocks + directory (any size)                     */
-#define PGX_MODE_IMAGE_DENSE 0x200u /* uncompressed bit planes, n bytes of device memory             */
+#define PGX_MODE_IMAGE_DENSE 0x200u /* uncompressed bit planes, n bytes of device memory (64 symbols per 64-byte block)       */
+#define PGX_MODE_IMAGE_DENSE2 0x400u /* two bit planes + exception runs, n / 3 bytes (384 symbols per 128-byte block; n < 2^32) */
 #define PGX_MODE_MASK 0xFFu
 
 /* tag file formats (SURVEY section 5 "Tag formats") */
@@ -89,7 +90,8 @@ typedef struct {
     double ref_block_mean_bytes; /* mean encoded block size of the reference layout (B_blk) */
     uint64_t max_length;    /* Header::max_length: packed position = seq * max_length + offset (r-index.hpp:424) */
     uint64_t n_samples;     /* samples.size() = runs in the reference's numbering */
-    uint32_t image_kind;    /* 0 = run-length blocks + directory, 1 = dense bit planes (64 symbols per 64-byte block) */
+    uint32_t image_kind;    /* 0 = run-length blocks + directory, 1 = dense bit planes (64 symbols per 64-byte block),
+                             * 2 = dense2 (384 symbols per 128-byte block, two planes + exception runs) */
     uint32_t reserved0;
 } pgx_index_info;
 
@@ -121,7 +123,7 @@ pgx_status pgx_index_to_device(pgx_index *h, int device);
  * locate image (built on first use of one of these selectors, pgx_image.h "locate image"):
  * 8 rstart (u64, first BWT position of every run + n), 9 rsamp (u64, samples[run]: what getSample returns),
  * 10 rdir (u32), 11 lpos (u64, ones of `last`), 12 lnext (u64, samples[last_to_run[i] + 1]), 13 ldir (u32),
- * 14 locate constants (PgxLocConsts). */
+ * 14 locate constants (PgxLocConsts); 15 exception runs of the dense2 rank image (u32). */
 pgx_status pgx_index_image_view(const pgx_index *h, int which, const void **ptr, uint64_t *bytes);
 
 /* ---- index construction (build side; CPU, run once) --------------------------------------- */

@@ -27,8 +27,15 @@ struct PgxDevImage {
     uint32_t dir_shift;
     uint32_t excl_mask;
     uint32_t tag_dir_shift;
-    uint32_t dense; // 1: blocks are dense bit-plane blocks (PGX_IMAGE_DENSE), dir / blow unused
+    uint32_t dense; // image kind: 0 run-length blocks, 1 dense bit-plane blocks (PGX_IMAGE_DENSE), 2 dense2 (PGX_IMAGE_DENSE2); dir / blow unused unless 0
+    const uint32_t *exc; // dense2: exception runs
+    // k-mer seed table (dense images in global memory): entry idx = bi-interval after backward-extending the full interval by
+    // the k bytes of a window, last byte first (pgx_seed_build_kernel); 0 = no table
+    uint32_t seed_k;
+    const uint4 *seed; // 4^seed_k entries {k lo, k' lo, s lo, k hi | k' hi << 8 | s hi << 16 | depth << 24}
 };
+#define PGX_SEED_UNUSABLE 255u // depth value of entries the kernels must not use (a coordinate does not fit the entry)
+#define PGX_SEED_MAX_K 13
 
 // heavy reads (pgx_kernels.hip): handed from pgx_find_mems_kernel to pgx_find_mems_heavy_kernel
 struct pgx_heavy_item {
@@ -49,7 +56,8 @@ __global__ void pgx_find_mems_heavy_kernel(PgxDevImage img, const uint8_t *reads
                                            unsigned long long *n_ext_total, const pgx_heavy_item *heavy_list,
                                            const unsigned long long *heavy_count, uint32_t heavy_cap, PgxHeavyResult *scratch);
 
-template <bool LDS_IMAGE, bool DENSE, bool NARROW>
+__global__ void pgx_seed_build_kernel(PgxDevImage img, const uint4 *src, uint4 *dst, uint32_t level, uint64_t n_dst, uint64_t limit);
+template <bool LDS_IMAGE, int DENSE, bool NARROW, bool SEED> // DENSE = image kind
 __global__ void pgx_find_mems_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
                                      uint64_t min_len, uint64_t min_occ, const uint64_t *slot_off, pgx_mem *slots,
                                      uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor, uint64_t first_read,

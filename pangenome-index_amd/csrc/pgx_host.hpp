@@ -112,6 +112,7 @@ struct HostImage {
     std::vector<uint64_t> dir;
     std::vector<uint64_t> bstart; // host only (tests): absolute block starts
     std::vector<uint16_t> blow;   // device: low dir_shift bits of each block start
+    std::vector<uint32_t> exc;    // DENSE2: exception runs (pgx_image.h)
     std::vector<uint64_t> tstart, tvals;
     std::vector<uint32_t> tdir;
     uint64_t n_runs = 0;

@@ -51,6 +51,23 @@
 #define PGX_DIR_MAX_SHIFT 12
 #define PGX_IMAGE_RL 0u
 #define PGX_IMAGE_DENSE 1u
+#define PGX_IMAGE_DENSE2 2u
+/* DENSE2 rank image (image_kind = PGX_IMAGE_DENSE2, BWTs shorter than 2^32): 384 symbols per 128-byte block = one cache
+ * line serves a rank probe, n / 3 bytes in all (a chr22-scale BWT of 640 M symbols: 213 MB, which stays resident in the
+ * 256 MB memory-side cache; the 64-byte-per-64-symbols layout above needs 640 MB and is served from HBM).  A probe reads
+ * the 32-byte header and ONE 32-byte sub-block (64 bytes, like a dense block):
+ *   dw 0..4    counts of A C G T N in BWT[0, 384 b)  (32 bits each; the count of \n is 384 b minus their sum)
+ *   dw 5       exception runs of the block: first one in exc[] (bits 0..23), how many (bits 24..31)
+ *   dw 6, 7    64 bits: in-block counts before symbol 128 (bits 0..26) and before symbol 256 (bits 27..53), each three
+ *              9-bit fields: symbols with plane-0 bit set, with plane-1 bit set, with both
+ *   sub-block s (s = 0, 1, 2; bytes 32 + 32 s ..): 4 dwords of plane 0, 4 dwords of plane 1 over symbols [128 s, 128 s + 128):
+ *              bit i of a plane = bit of the 2-bit symbol code, A = 0, C = 1, G = 2, T = 3; the rare other symbols
+ *              (\n, N) are stored as 0 and listed in exc[]
+ *   exc[e]     start within the block (bits 0..8) | run length (bits 9..17) | kind (bit 18: 0 = \n, 1 = N)
+ * rank = header count + sub-block count + popcounts of plane combinations under a prefix mask, corrected by the
+ * exception runs of the block. */
+#define PGX_D2_SYMS 384u
+#define PGX_D2_BLOCK_BYTES 128u
 
 /* ext_tab entry (one per byte value and direction): how to extend by that byte */
 #define PGX_EXT_CV(e) ((e) & 7u)            /* nuc code whose rank gives the new interval     */

@@ -360,25 +360,114 @@ static void build_dense_image(const RiFile &ri, HostImage &img) {
     c.image_kind = PGX_IMAGE_DENSE;
 }
 
+// dense2 image: 384 symbols per 128-byte block as three sub-blocks of two bit planes + exception runs for \n and N (pgx_image.h)
+static void build_dense2_image(const RiFile &ri, HostImage &img) {
+    PgxConsts &c = img.consts;
+    if (c.n >> 32) throw Error(PGX_ERR_UNSUPPORTED, "BWT too long for the dense2 image");
+    const uint64_t nb = c.n / PGX_D2_SYMS + 1;
+    img.blocks.assign(nb * PGX_D2_BLOCK_BYTES, 0);
+    img.bstart.clear();
+    img.dir.assign(1, 0);
+    img.blow.clear();
+    img.exc.clear();
+    uint32_t *dw = reinterpret_cast<uint32_t *>(img.blocks.data());
+    uint64_t c6[6] = {0, 0, 0, 0, 0, 0};
+    static const int hdr_slot[6] = {-1, 0, 1, 2, 4, 3}; // \n A C G N T -> header dword (A C G T N; \n is implied)
+    static const int two_bit[6] = {0, 0, 1, 2, 0, 3};   // plane code (\n and N are exceptions stored as 0)
+    auto put_header = [&](uint64_t b) {
+        uint32_t *h = dw + b * 32;
+        for (int i = 1; i < 6; i++) h[hdr_slot[i]] = (uint32_t)c6[i];
+        if (img.exc.size() >> 24) throw Error(PGX_ERR_UNSUPPORTED, "too many exception runs for the dense2 image");
+        h[5] = (uint32_t)img.exc.size();
+    };
+    auto finish_block = [&](uint64_t b) { // sub-block counts from the finished planes
+        uint32_t *h = dw + b * 32;
+        uint64_t sub = 0;
+        uint32_t n0 = 0, n1 = 0, n3 = 0;
+        for (int s = 0; s < 2; s++) {
+            for (int k = 0; k < 4; k++) {
+                const uint32_t a = h[8 + 8 * s + k], d = h[12 + 8 * s + k];
+                n0 += (uint32_t)__builtin_popcount(a); n1 += (uint32_t)__builtin_popcount(d); n3 += (uint32_t)__builtin_popcount(a & d);
+            }
+            sub |= ((uint64_t)n0 | ((uint64_t)n1 << 9) | ((uint64_t)n3 << 18)) << (27 * s);
+        }
+        h[6] = (uint32_t)sub; h[7] = (uint32_t)(sub >> 32);
+    };
+    uint64_t pos = 0, n_runs = 0;
+    put_header(0);
+    for (const auto &blk : ri.blocks)
+        for (const auto &ru : blk.runs) {
+            n_runs++;
+            const uint32_t code = ru.first;
+            uint64_t left = ru.second;
+            while (left) {
+                const uint64_t b = pos / PGX_D2_SYMS;
+                const uint32_t off = (uint32_t)(pos % PGX_D2_SYMS);
+                const uint64_t take = std::min<uint64_t>(left, PGX_D2_SYMS - off);
+                uint32_t *h = dw + b * 32;
+                const int tb = two_bit[code];
+                if (tb)
+                    for (uint32_t i = off; i < off + take; i++) {
+                        uint32_t *sb = h + 8 + 8 * (i >> 7); // sub-block: 4 dwords of plane 0, then 4 of plane 1
+                        const uint32_t r = i & 127u;
+                        if (tb & 1) sb[r >> 5] |= 1u << (r & 31);
+                        if (tb & 2) sb[4 + (r >> 5)] |= 1u << (r & 31);
+                    }
+                if (code == 0 || code == 4) {
+                    const uint32_t kind = code == 4 ? 1u : 0u;
+                    // extend the block's last exception run when this one continues it
+                    if ((h[5] >> 24) && (img.exc.back() >> 18) == kind && (img.exc.back() & 511u) + ((img.exc.back() >> 9) & 511u) == off)
+                        img.exc.back() += (uint32_t)take << 9;
+                    else {
+                        img.exc.push_back(off | ((uint32_t)take << 9) | (kind << 18));
+                        h[5] += 1u << 24; // at most 192 alternating runs in 384 symbols
+                    }
+                }
+                c6[code] += take;
+                left -= take;
+                pos += take;
+                if (pos % PGX_D2_SYMS == 0) { finish_block(b); put_header(pos / PGX_D2_SYMS); }
+            }
+        }
+    if (pos != c.n) throw Error(PGX_ERR_FORMAT, "FastLocate: run lengths do not add up to the BWT size");
+    finish_block(nb - 1);
+    if (img.exc.empty()) img.exc.push_back(0); // never indexed; keeps the device buffer non-empty
+    img.n_runs = n_runs;
+    c.n_blocks = (uint32_t)nb;
+    c.dir_shift = 0;
+    c.dir_entries = 1;
+    c.image_kind = PGX_IMAGE_DENSE2;
+}
+
 // layout of the device rank image: dense bit planes when that costs little memory or the run-length image would
 // not stay cache resident either; PGX_MODE_IMAGE_* / the environment variable PGX_IMAGE force one
-static bool choose_dense(const RiFile &ri, uint32_t mode_bits, const PgxConsts &c) {
+// returns PGX_IMAGE_RL / PGX_IMAGE_DENSE / PGX_IMAGE_DENSE2
+static uint32_t choose_image(const RiFile &ri, uint32_t mode_bits, const PgxConsts &c) {
     const bool can = c.excl_mask == 0;
-    uint32_t force = mode_bits & (PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE);
+    const uint32_t all = PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE | PGX_MODE_IMAGE_DENSE2;
+    uint32_t force = mode_bits & all;
     if (!force)
-        if (const char *e = std::getenv("PGX_IMAGE")) force = std::string(e) == "dense" ? PGX_MODE_IMAGE_DENSE : std::string(e) == "rl" ? PGX_MODE_IMAGE_RL : 0u;
-    if (force == (PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE)) throw Error(PGX_ERR_ARG, "pgx_index_open: both image layouts forced");
-    if (force & PGX_MODE_IMAGE_DENSE) {
+        if (const char *e = std::getenv("PGX_IMAGE")) {
+            const std::string v(e);
+            force = v == "dense" ? PGX_MODE_IMAGE_DENSE : v == "dense2" ? PGX_MODE_IMAGE_DENSE2 : v == "rl" ? PGX_MODE_IMAGE_RL : 0u;
+        }
+    if (force & (force - 1)) throw Error(PGX_ERR_ARG, "pgx_index_open: more than one image layout forced");
+    if (force & (PGX_MODE_IMAGE_DENSE | PGX_MODE_IMAGE_DENSE2)) {
         if (!can) throw Error(PGX_ERR_UNSUPPORTED, "dense image: not available for a legacy-layout index without N in COMPAT mode");
-        return true;
+        if ((force & PGX_MODE_IMAGE_DENSE2) && (c.n >> 32)) throw Error(PGX_ERR_UNSUPPORTED, "dense2 image: BWT of 2^32 symbols or more");
+        return (force & PGX_MODE_IMAGE_DENSE2) ? PGX_IMAGE_DENSE2 : PGX_IMAGE_DENSE;
     }
-    if ((force & PGX_MODE_IMAGE_RL) || !can) return false;
+    if ((force & PGX_MODE_IMAGE_RL) || !can) return PGX_IMAGE_RL;
+    // tiny BWTs: the 64-byte layout, staged in LDS by the kernels (cheapest decode; pgx_runtime.hip: 80 padded bytes per block)
+    const uint64_t dense_blocks = (c.n >> 6) + 1;
+    if (dense_blocks * 80 + 16 <= 48 * 1024) return PGX_IMAGE_DENSE;
+    // everything else below 2^32 symbols: one 128-byte line per probe, n / 3 bytes (cache resident up to chromosome scale)
+    if (!(c.n >> 32)) return PGX_IMAGE_DENSE2;
     uint64_t runs = 0;
     for (const auto &b : ri.blocks) runs += b.runs.size();
-    const uint64_t dense_bytes = ((c.n >> 6) + 1) * PGX_BLOCK_BYTES, rl_bytes = (runs / PGX_BLOCK_RUNS + 1) * (PGX_BLOCK_BYTES + 4);
-    const uint64_t cache = 192ull << 20; // stays resident in the 256 MB memory-side cache next to reads and tags
-    if (dense_bytes <= cache) return true;
-    return rl_bytes > cache && dense_bytes <= (64ull << 30);
+    const uint64_t dense_bytes = dense_blocks * PGX_BLOCK_BYTES, rl_bytes = (runs / PGX_BLOCK_RUNS + 1) * (PGX_BLOCK_BYTES + 4);
+    const uint64_t cache = 192ull << 20; // what stays resident in the 256 MB memory-side cache next to reads and tags
+    return (rl_bytes > cache && dense_bytes <= (64ull << 30)) ? PGX_IMAGE_DENSE : PGX_IMAGE_RL;
 }
 
 void build_rank_image(const RiFile &ri, uint32_t mode_bits, HostImage &img) {
@@ -389,7 +478,9 @@ void build_rank_image(const RiFile &ri, uint32_t mode_bits, HostImage &img) {
     c.mode = mode;
     build_ext_tables(ri, mode, c);
     build_count_table(ri, mode, c);
-    if (choose_dense(ri, mode_bits, c)) { build_dense_image(ri, img); return; }
+    const uint32_t kind = choose_image(ri, mode_bits, c);
+    if (kind == PGX_IMAGE_DENSE) { build_dense_image(ri, img); return; }
+    if (kind == PGX_IMAGE_DENSE2) { build_dense2_image(ri, img); return; }
     // Device blocks must refine the reference's blocks only when a header slot carries the
     // reference-block cumulative endmarker count (legacy layout, absent symbol, COMPAT).
     const bool refine = c.excl_mask != 0;
@@ -575,7 +666,7 @@ extern "C" int pgx_abi_version(void) { return PGX_ABI_VERSION; }
 void pgx_release_device_images(pgx_index *h); // pgx_runtime.hip
 
 static pgx_index *open_impl(const uint8_t *ri, uint64_t ri_n, const uint8_t *tags, uint64_t tags_n, uint32_t tags_format, uint32_t mode) {
-    if ((mode & PGX_MODE_MASK) > PGX_MODE_STRICT || (mode & ~(PGX_MODE_MASK | PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE)))
+    if ((mode & PGX_MODE_MASK) > PGX_MODE_STRICT || (mode & ~(PGX_MODE_MASK | PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE | PGX_MODE_IMAGE_DENSE2)))
         throw Error(PGX_ERR_ARG, "pgx_index_open: bad mode");
     if (!ri && !tags) throw Error(PGX_ERR_ARG, "pgx_index_open: neither an r-index nor a tag array given");
     std::unique_ptr<pgx_index> h(new pgx_index());
@@ -598,7 +689,7 @@ extern "C" pgx_status pgx_index_open(const char *ri_path, const char *tags_path,
                                      uint32_t mode, pgx_index **out) {
     PGX_GUARD_BEGIN
     if (!ri_path || !out) throw Error(PGX_ERR_ARG, "pgx_index_open: null argument");
-    if ((mode & PGX_MODE_MASK) > PGX_MODE_STRICT || (mode & ~(PGX_MODE_MASK | PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE)))
+    if ((mode & PGX_MODE_MASK) > PGX_MODE_STRICT || (mode & ~(PGX_MODE_MASK | PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE | PGX_MODE_IMAGE_DENSE2)))
         throw Error(PGX_ERR_ARG, "pgx_index_open: bad mode");
     *out = nullptr;
     std::vector<uint8_t> f, t;
@@ -657,9 +748,10 @@ extern "C" pgx_status pgx_index_info_get(const pgx_index *h, pgx_index_info *inf
     info->n_tag_runs = c.n_tag_runs;
     info->tag_dir_entries = c.tag_dir_entries;
     info->tag_dir_shift = c.tag_dir_shift;
-    info->image_bytes = h->img.blocks.size() + h->img.dir.size() * 8 + h->img.blow.size() * 2;
+    info->image_bytes = h->img.blocks.size() + h->img.dir.size() * 8 + h->img.blow.size() * 2 + h->img.exc.size() * 4;
     info->tag_image_bytes = h->img.tstart.size() * 8 + h->img.tvals.size() * 8 + h->img.tdir.size() * 4;
-    info->image_in_lds = info->image_bytes <= 48 * 1024;
+    info->image_in_lds = h->img.consts.image_kind == PGX_IMAGE_DENSE ? (uint64_t)h->img.consts.n_blocks * 80 + 16 <= 48 * 1024
+                                                                     : (h->img.consts.image_kind == PGX_IMAGE_RL && info->image_bytes <= 48 * 1024);
     info->ref_block_mean_bytes = h->ri.ref_block_mean_bytes;
     info->max_length = h->ri.max_length;
     info->n_samples = h->ri.samples.size();
@@ -696,6 +788,7 @@ extern "C" pgx_status pgx_index_image_view(const pgx_index *h, int which, const 
     case 5: *ptr = m.tdir.data(); *bytes = m.tdir.size() * 4; break;
     case 6: *ptr = &m.consts; *bytes = sizeof(PgxConsts); break;
     case 7: *ptr = m.blow.data(); *bytes = m.blow.size() * 2; break;
+    case 15: *ptr = m.exc.data(); *bytes = m.exc.size() * 4; break;
     default: throw Error(PGX_ERR_ARG, "pgx_index_image_view: unknown view");
     }
     return PGX_OK;

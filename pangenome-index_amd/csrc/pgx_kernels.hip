@@ -132,6 +132,92 @@ __device__ __forceinline__ void pgx_dense_pair32(const PgxDenseBlk &k0, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------
+// DENSE2 image (pgx_image.h): 384 symbols per 128-byte block = 32-byte header + three 32-byte sub-blocks of 128 symbols in two
+// bit planes, exception runs for \n and N; positions below 2^32.  A probe loads the header and one sub-block.
+struct PgxDense2Blk {
+    uint4 h0, h1; // header: counts A C G T | N, exceptions, sub-block counts (64 bits)
+    uint4 p0, p1; // the sub-block of the probe: plane 0, plane 1
+};
+__device__ __forceinline__ PgxDense2Blk pgx_dense2_load(const PgxDevImage &img, uint32_t pos, uint32_t &rel) {
+    const uint32_t blk = (uint32_t)(((uint64_t)pos * 0xAAAAAAABull) >> 40); // pos / 384
+    rel = pos - blk * PGX_D2_SYMS;
+    const uint4 *bp = img.blocks + (size_t)blk * 8;
+    PgxDense2Blk b;
+    b.h0 = bp[0]; b.h1 = bp[1];
+    const uint4 *sp = bp + 2 + 2 * (rel >> 7);
+    b.p0 = sp[0]; b.p1 = sp[1];
+    return b;
+}
+// counts of the six nuc codes (\n A C G N T) in BWT[0, pos) for the probe whose block / sub-block was loaded
+__device__ __forceinline__ void pgx_dense2_counts(const PgxDevImage &img, const PgxDense2Blk &b, uint32_t pos, uint32_t rel, uint32_t c[6]) {
+    const uint32_t sub = rel >> 7, r = rel & 127u;
+    // in-block counts before the sub-block (three 9-bit fields per sub-block boundary)
+    const uint64_t sc = ((uint64_t)b.h1.z | ((uint64_t)b.h1.w << 32)) >> (sub == 2u ? 27 : 0);
+    uint32_t n0 = sub ? (uint32_t)sc & 511u : 0u, n1 = sub ? (uint32_t)(sc >> 9) & 511u : 0u, n3 = sub ? (uint32_t)(sc >> 18) & 511u : 0u;
+    const uint32_t a[4] = {b.p0.x, b.p0.y, b.p0.z, b.p0.w}, d[4] = {b.p1.x, b.p1.y, b.p1.z, b.p1.w};
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        const int32_t t = (int32_t)r - 32 * h; // bits of this dword that lie below the position
+        const uint32_t m = t >= 32 ? 0xFFFFFFFFu : (t > 0 ? ((1u << t) - 1u) : 0u);
+        const uint32_t x = a[h] & m, y = d[h] & m;
+        n0 += __popc(x); n1 += __popc(y); n3 += __popc(x & y);
+    }
+    uint32_t e0 = 0, e4 = 0;
+    const uint32_t ec = b.h1.y >> 24;
+    if (ec) { // rare: the block holds endmarkers or N
+        const uint32_t *ep = img.exc + (b.h1.y & 0xFFFFFFu);
+        for (uint32_t i = 0; i < ec; i++) {
+            const uint32_t u = ep[i], st = u & 511u, ln = (u >> 9) & 511u;
+            const uint32_t cnt = rel > st ? min(rel - st, ln) : 0u;
+            if ((u >> 18) & 1u) e4 += cnt; else e0 += cnt;
+        }
+    }
+    const uint32_t hsum = b.h0.x + b.h0.y + b.h0.z + b.h0.w + b.h1.x;
+    c[0] = (pos - rel) - hsum + e0;               // \n: block start minus the five stored counts
+    c[1] = b.h0.x + rel - (n0 + n1 - n3) - e0 - e4; // A
+    c[2] = b.h0.y + n0 - n3;                      // C
+    c[3] = b.h0.z + n1 - n3;                      // G
+    c[4] = b.h1.x + e4;                           // N
+    c[5] = b.h0.w + n3;                           // T
+}
+// both probes of an extension: A0, A1 = count of code cv before p0 / p1; dB = sum over codes of mult[code] * (count before p1 -
+// count before p0).  NARROW: modulo 2^32 (like pgx_dense_pair32); otherwise modulo 2^64 from the exact 32-bit counts.
+template <bool NARROW>
+__device__ __forceinline__ void pgx_dense2_pair(const PgxDevImage &img, uint32_t p0, uint32_t p1, uint32_t cv, uint32_t mrow, uint64_t &A0, uint64_t &A1,
+                                                uint64_t &dB) {
+    uint32_t r0, r1;
+    const PgxDense2Blk k0 = pgx_dense2_load(img, p0, r0), k1 = pgx_dense2_load(img, p1, r1);
+    uint32_t c0[6], c1[6];
+    pgx_dense2_counts(img, k0, p0, r0, c0);
+    pgx_dense2_counts(img, k1, p1, r1, c1);
+    uint32_t a0 = 0, a1 = 0, d32 = 0;
+    uint64_t d64 = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        a0 = (cv == (uint32_t)i) ? c0[i] : a0;
+        a1 = (cv == (uint32_t)i) ? c1[i] : a1;
+        const uint32_t w = (mrow >> (3 * i)) & 7u;
+        if (NARROW) d32 += (c1[i] - c0[i]) * w;
+        else d64 += (uint64_t)((int64_t)c1[i] - (int64_t)c0[i]) * (uint64_t)w;
+    }
+    A0 = a0; A1 = a1; dB = NARROW ? (uint64_t)d32 : d64;
+}
+// one probe (primitives)
+__device__ __forceinline__ void pgx_dense2_rank(const PgxDevImage &img, uint32_t pos, uint32_t cv, uint32_t mrow, uint64_t &A, uint64_t &B) {
+    uint32_t rel;
+    const PgxDense2Blk k = pgx_dense2_load(img, pos, rel);
+    uint32_t c[6];
+    pgx_dense2_counts(img, k, pos, rel, c);
+    uint64_t a = 0, bb = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        a = (cv == (uint32_t)i) ? (uint64_t)c[i] : a;
+        bb += (uint64_t)c[i] * (uint64_t)((mrow >> (3 * i)) & 7u);
+    }
+    A = a; B = bb;
+}
+
+// ------------------------------------------------------------------------------------------
 // rank probe: A = count of code `cv` in BWT[0,pos), B = sum over codes of mult[code] * count(code)
 // (both modulo 2^64; only differences of two probes are ever used).
 template <bool LDS_IMAGE>
@@ -139,6 +225,7 @@ __device__ __forceinline__ void pgx_rank_ab(const PgxDevImage &img, const uint4 
                                             const uint64_t *__restrict__ lds_dir, const uint16_t *__restrict__ lds_blow,
                                             uint64_t pos, uint32_t cv, uint32_t mrow, uint64_t &A, uint64_t &B) {
     if (pos > img.n) pos = img.n; // predecessor(pos >= size) = last block, rel past the end = totals
+    if (img.dense == 2) { pgx_dense2_rank(img, (uint32_t)pos, cv, mrow, A, B); return; }
     if (img.dense) {
         pgx_dense_rank(pgx_dense_load<LDS_IMAGE>(img, lds_blocks, pos), pos, cv, mrow, A, B);
         return;
@@ -247,6 +334,7 @@ __device__ __forceinline__ void pgx_rank_pair(const PgxDevImage &img, const uint
                                               uint64_t &A1, uint64_t &dB) {
     const uint64_t p0 = pos0 > img.n ? img.n : pos0, p1 = pos1 > img.n ? img.n : pos1;
     uint64_t B0 = 0, B1 = 0;
+    if (MAYBE_DENSE && img.dense == 2) { pgx_dense2_pair<false>(img, (uint32_t)p0, (uint32_t)p1, cv, mrow, A0, A1, dB); return; }
     if (MAYBE_DENSE && img.dense) { // two independent block loads, no directory
         const PgxDenseBlk k0 = pgx_dense_load<LDS_IMAGE>(img, lds_blocks, p0), k1 = pgx_dense_load<LDS_IMAGE>(img, lds_blocks, p1);
         pgx_dense_rank(k0, p0, cv, mrow, A0, B0);
@@ -318,6 +406,63 @@ __device__ __forceinline__ void pgx_stage_tables(const PgxDevImage &img, uint32_
     uint16_t *lds_blow = reinterpret_cast<uint16_t *>(pgx_dyn_lds + (size_t)(img).n_blocks * PGX_BLOCK_BYTES + (img).dir_entries * 8)
 
 // ------------------------------------------------------------------------------------------
+// k-mer seeds.  A backward stage of find_mems_function that starts from the full interval (step 1 at j = x + min_len - 1, step 3
+// at j = e) performs its first K extensions over the window P[j - K + 1 .. j], last byte first; the table holds the result of
+// those K extensions for every ACGT window, computed on the device by the same pgx_extend (so every quirk the tables carry is in
+// it), and for windows that leave the index the number of extensions until the interval became empty.  One 16-byte load then
+// replaces K extensions = up to 2 K line fetches, the widest ones of the search; the counters advance by K (or by the death
+// depth), so MEMs, returned start positions and n_extensions stay those of the stepwise search.
+//   index = sum over window bytes b_i (memory order) of code(b_i) << 2 i, code = (byte >> 1) & 3: A 0, C 1, T 2, G 3
+__device__ __forceinline__ uint32_t pgx_seed_codes(uint64_t x, uint64_t &bad) {
+    const uint64_t c = (x >> 1) & 0x0303030303030303ull;
+    const uint64_t b0 = c & 0x0101010101010101ull, b1 = (c >> 1) & 0x0101010101010101ull;
+    // the byte each code stands for; anything else in the window (N, lower case, \0, ...) makes it unusable
+    const uint64_t recon = 0x4141414141414141ull + 2 * (b0 & ~b1) + 0x13 * (b1 & ~b0) + 6 * (b0 & b1);
+    bad = x ^ recon;
+    uint64_t t = (c | (c >> 6)) & 0x000F000F000F000Full;
+    t = (t | (t >> 12)) & 0x000000FF000000FFull;
+    t = (t | (t >> 24)) & 0xFFFFull;
+    return (uint32_t)t;
+}
+__device__ __forceinline__ bool pgx_seed_index(uint64_t lo, uint64_t hi, uint32_t K, uint32_t &idx) {
+    uint64_t badlo, badhi;
+    const uint32_t ilo = pgx_seed_codes(lo, badlo), ihi = pgx_seed_codes(hi, badhi);
+    const uint32_t nlo = K < 8u ? K : 8u, nhi = K > 8u ? K - 8u : 0u;
+    const uint64_t mlo = nlo == 8u ? ~0ull : ((1ull << (8u * nlo)) - 1ull), mhi = nhi == 8u ? ~0ull : ((1ull << (8u * nhi)) - 1ull);
+    idx = (ilo & ((1u << (2u * nlo)) - 1u)) | ((ihi & ((1u << (2u * nhi)) - 1u)) << 16);
+    return ((badlo & mlo) | (badhi & mhi)) == 0ull;
+}
+
+// level `level` (4^level entries, src; level 0 = the full interval) -> level + 1: entry (p << 2 | c) = entry p extended by code c
+__global__ void __launch_bounds__(256)
+pgx_seed_build_kernel(PgxDevImage img, const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t level, uint64_t n_dst, uint64_t limit) {
+    __shared__ uint32_t s_ext[512];
+    __shared__ uint64_t s_C[8];
+    pgx_stage_tables<false>(img, s_ext, s_C, nullptr, nullptr, nullptr);
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_dst) return;
+    uint64_t k = 0, kp = 0, s = img.n;
+    uint32_t depth = 0;
+    if (level) {
+        const uint4 e = src[i >> 2];
+        k = (uint64_t)e.x | ((uint64_t)(e.w & 0xFFu) << 32);
+        kp = (uint64_t)e.y | ((uint64_t)((e.w >> 8) & 0xFFu) << 32);
+        s = (uint64_t)e.z | ((uint64_t)((e.w >> 16) & 0xFFu) << 32);
+        depth = e.w >> 24;
+    }
+    if (s != 0) {
+        const uint32_t byte = (0x47544341u >> (8u * (uint32_t)(i & 3))) & 0xFFu; // "ACTG"[code]
+        pgx_extend<false>(img, nullptr, nullptr, nullptr, s_ext, s_C, k, kp, s, byte, false);
+        if (s == 0) { k = 0; kp = 0; depth = level + 1; }
+        else if (k >= limit || kp >= limit || k + s >= limit || kp + s >= limit || k + s < k || kp + s < kp) { k = 0; kp = 0; s = 0; depth = PGX_SEED_UNUSABLE; }
+    }
+    uint4 o;
+    o.x = (uint32_t)k; o.y = (uint32_t)kp; o.z = (uint32_t)s;
+    o.w = (uint32_t)(k >> 32) | ((uint32_t)(kp >> 32) << 8) | ((uint32_t)(s >> 32) << 16) | (depth << 24);
+    dst[i] = o;
+}
+
+// ------------------------------------------------------------------------------------------
 // find_all_mems for a batch.  State machine of find_mems_function (algorithm.hpp:653-736):
 //   phase 1  backward from j = x+min_len-1 down to x          (:666-676)
 //   phase 2  forward  from j = x+min_len   up to len-1        (:684-696)  -> emit MEM (:713)
@@ -340,7 +485,7 @@ __device__ __forceinline__ void pgx_stage_tables(const PgxDevImage &img, uint32_
 // NARROW (dense images of BWTs shorter than 2^30 only): interval coordinates and rank sums in 32 bits -- half the moves,
 // selects and adds of the loop.  Sound because every true value is < 2^32 there; the junk coordinates the COMPAT quirks can
 // produce are caught at the two additions that could wrap (counter slot 9 is raised and the host repeats the chunk in 64 bits).
-template <bool LDS_IMAGE, bool DENSE, bool NARROW>
+template <bool LDS_IMAGE, int DENSE, bool NARROW, bool SEED>
 __global__ void __launch_bounds__(PGX_FM_THREADS, PGX_FM_WAVES_PER_SIMD)
 pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                      uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
@@ -353,6 +498,8 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     pgx_stage_tables<LDS_IMAGE>(img, s_ext, s_C, lds_blocks, lds_dir, lds_blow);
 
     static_assert(!NARROW || DENSE, "the 32-bit state exists for the dense image only");
+    static_assert(!SEED || (DENSE && !LDS_IMAGE), "k-mer seeds exist for dense images in global memory");
+    static_assert(DENSE != 2 || !LDS_IMAGE, "the dense2 image is never staged in LDS");
     typedef typename std::conditional<NARROW, uint32_t, uint64_t>::type pos_t;
     const int lane = threadIdx.x & 63;
     const pos_t n = (pos_t)img.n;
@@ -367,6 +514,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     uint64_t win = 0, win_hi = 0, win2 = 0, win3 = 0, win_at = ~0ull;
     pos_t A0 = 0, B0 = 0;             // first-probe sums of an extension whose second probe is pending
     bool pend = false;
+    bool fresh = false;              // SEED: the interval is the full one and a backward stage is about to start (the seed table may apply)
     bool ovf = false;                // NARROW: some addition left 32 bits (reported once, when the wave leaves)
     uint64_t rnext = 0, rend = 0;    // wave-uniform reservoir of read ids
     bool exhausted = false;          // wave-uniform: the global cursor has passed n_reads
@@ -392,6 +540,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
             Jk = 0; Js = n; j = x; ph = 2;
         } else {
             j = x + (int32_t)min_len - 1; ph = 1;
+            fresh = true;
         }
     };
     // the state machine below funnels every "next start position" through one begin() (the lambda is inlined per call site)
@@ -403,7 +552,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
         slots[slot + nm] = m;
         nm++;
         k = 0; kp = 0; s = n;
-        if (j > x) ph = 3;
+        if (j > x) { ph = 3; fresh = true; }
         else { x = x + 1; restart = true; } // loop of :722 runs zero times, returns j + 1
     };
 
@@ -451,6 +600,28 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
         st_live += (unsigned long long)__popcll(__ballot(ph > 0));
 #endif
         if (ph > 0) {
+            // ---- k-mer seed of a backward stage that starts now: the entry is loaded next to the block loads of the ordinary
+            //      extension by P[j] (which every lane performs regardless) and replaces its result further down ----
+            bool seed_lane = false;
+            uint4 se = make_uint4(0u, 0u, 0u, 0u);
+            if (SEED) {
+                const uint4 *sp = img.seed;
+                if (fresh) {
+                    const int32_t K = (int32_t)img.seed_k;
+                    const int32_t avail = (ph == 1) ? (j - x + 1) : (j - x); // extensions this stage may still perform
+                    if (avail >= K && j < len) {
+                        const uint64_t a = base + (uint64_t)(j - K + 1);
+                        const uint32_t sh = (uint32_t)(a & 7ull) * 8u;
+                        const uint64_t *wp = reinterpret_cast<const uint64_t *>(reads + (a & ~7ull)); // 32 zero bytes follow the last read
+                        const uint64_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+                        const uint64_t lo = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0, hi = sh ? (w1 >> sh) | (w2 << (64u - sh)) : w1;
+                        uint32_t sidx;
+                        if (pgx_seed_index(lo, hi, (uint32_t)K, sidx)) { seed_lane = true; sp = img.seed + sidx; }
+                    }
+                }
+                fresh = false;
+                se = *sp; // lanes without a seed read entry 0 (one cached line for all of them)
+            }
             uint32_t byte = 0u; // pattern[len] reads as 0 (quirk 4)
             if (j < len) {
                 const uint64_t at = base + (uint64_t)j;
@@ -479,7 +650,21 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
             const pos_t kk = fwd ? kp : k, kq = fwd ? k : kp;
             bool fin;
             pos_t A1, dB;
-            if (NARROW) {
+            if (DENSE == 2) {
+                // dense2: header + one sub-block per probe, all within one 128-byte line (usually the same line for both probes)
+                uint64_t q0, q1, dq;
+                if (NARROW) {
+                    const uint32_t ks = (uint32_t)kk + (uint32_t)s;
+                    ovf |= ks < (uint32_t)kk;
+                    const uint32_t p0 = (uint32_t)kk > (uint32_t)n ? (uint32_t)n : (uint32_t)kk, p1 = ks > (uint32_t)n ? (uint32_t)n : ks;
+                    pgx_dense2_pair<true>(img, p0, p1, cv, mrow, q0, q1, dq);
+                } else {
+                    const uint64_t p0 = kk > n ? n : kk, p1 = (kk + s) > n ? n : (kk + s); // (kk + s wraps only from junk coordinates: either way >= n or tiny)
+                    pgx_dense2_pair<false>(img, (uint32_t)p0, (uint32_t)p1, cv, mrow, q0, q1, dq);
+                }
+                A0 = (pos_t)q0; A1 = (pos_t)q1; dB = (pos_t)dq;
+                fin = true;
+            } else if (NARROW) {
                 const uint32_t ks = (uint32_t)kk + (uint32_t)s;
                 ovf |= ks < (uint32_t)kk; // kk + s left 32 bits (junk coordinates of a COMPAT quirk): the host repeats the chunk in 64 bits
                 const uint32_t p0 = (uint32_t)kk > (uint32_t)n ? (uint32_t)n : (uint32_t)kk, p1 = ks > (uint32_t)n ? (uint32_t)n : ks;
@@ -488,7 +673,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                 pgx_dense_pair32(k0, p0, k1, p1, cv, mrow, a0, a1, d);
                 A0 = (pos_t)a0; A1 = (pos_t)a1; dB = (pos_t)d;
                 fin = true;
-            } else if (DENSE) {
+            } else if (DENSE == 1) {
                 // dense image: the two block addresses are known at once (pos >> 6), so both 64-byte loads are in flight
                 // together and every extension is a single trip
                 const uint64_t p0 = kk > n ? n : kk, p1 = (kk + s) > n ? n : (kk + s);
@@ -532,7 +717,26 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                     k = fwd ? nq : nk;
                     kp = fwd ? nk : nq;
                 }
-                const bool small = ((uint64_t)s < min_occ) || (s == 0); // :671 (unsigned compare) || size <= 0
+                bool small = ((uint64_t)s < min_occ) || (s == 0); // :671 (unsigned compare) || size <= 0
+                if (SEED && seed_lane) {
+                    const uint32_t depth = se.w >> 24;
+                    const pos_t ss = NARROW ? (pos_t)se.z : (pos_t)((uint64_t)se.z | ((uint64_t)((se.w >> 16) & 0xFFu) << 32));
+                    if (ss != 0 && (uint64_t)ss >= min_occ) {
+                        // all K extensions at once: sizes only shrink along a stage, so none of the K - 1 skipped ones was "small"
+                        k = NARROW ? (pos_t)se.x : (pos_t)((uint64_t)se.x | ((uint64_t)(se.w & 0xFFu) << 32));
+                        kp = NARROW ? (pos_t)se.y : (pos_t)((uint64_t)se.y | ((uint64_t)((se.w >> 8) & 0xFFu) << 32));
+                        s = ss;
+                        small = false;
+                        j -= (int32_t)img.seed_k - 1;
+                        next += img.seed_k - 1u;
+                    } else if (ss == 0 && depth != PGX_SEED_UNUSABLE && min_occ <= 1) {
+                        // the window leaves the index at its depth-th extension (only "empty" is small when min_occ <= 1)
+                        k = 0; kp = 0; s = 0;
+                        small = true;
+                        j -= (int32_t)depth - 1;
+                        next += depth - 1u;
+                    } // otherwise (entry unusable, or min_occ decides where the stage ends): the ordinary extension stands
+                }
                 // The transitions of the three steps as selects (the 64 lanes of a wave are in all three steps at once, so
                 // branches would run every path on every trip anyway, each with its own copies and exec-mask juggling):
                 //   step 1  small -> restart at j + 1 | j == x -> J = interval, j = x + min_len, step 2 (or emit) | else j--
@@ -566,22 +770,40 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
 #endif
 }
 
-template __global__ void pgx_find_mems_kernel<false, false, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+template __global__ void pgx_find_mems_kernel<false, 0, false, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
                                                             const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
                                                             uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<false, true, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+template __global__ void pgx_find_mems_kernel<false, 1, false, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
                                                             const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
                                                             uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<true, false, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+template __global__ void pgx_find_mems_kernel<true, 0, false, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
                                                             const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
                                                             uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<true, true, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+template __global__ void pgx_find_mems_kernel<true, 1, false, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
                                                             const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
                                                             uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<true, true, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+template __global__ void pgx_find_mems_kernel<true, 1, true, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
                                                             const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
                                                             uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<false, true, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+template __global__ void pgx_find_mems_kernel<false, 1, true, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
+                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
+template __global__ void pgx_find_mems_kernel<false, 1, false, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
+                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
+template __global__ void pgx_find_mems_kernel<false, 1, true, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
+                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
+template __global__ void pgx_find_mems_kernel<false, 2, false, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
+                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
+template __global__ void pgx_find_mems_kernel<false, 2, true, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
+                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
+template __global__ void pgx_find_mems_kernel<false, 2, false, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
+                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
+template __global__ void pgx_find_mems_kernel<false, 2, true, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
                                                             const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
                                                             uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
 

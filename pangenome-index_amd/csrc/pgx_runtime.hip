@@ -123,7 +123,7 @@ struct HostBuf { // grow-only pinned host buffer (fast D2H; returned to the call
 struct pgx_device_image {
     int device = -1;
     PgxDevImage img{};
-    DevBuf blocks, dir, blow, consts, tstart, tvals, tdir;
+    DevBuf blocks, dir, blow, consts, tstart, tvals, tdir, seed, exc;
     DevBuf rstart, rsamp, rdir, lpos, lnext, ldir; // locate image, uploaded on first use
     PgxLocImage loc{};
     bool has_loc = false;
@@ -135,7 +135,7 @@ void pgx_release_device_images(pgx_index *h) {
         if (!d) continue;
         if (hipSetDevice(d->device) == hipSuccess) {
             d->blocks.release(); d->dir.release(); d->blow.release(); d->consts.release();
-            d->tstart.release(); d->tvals.release(); d->tdir.release();
+            d->tstart.release(); d->tvals.release(); d->tdir.release(); d->seed.release(); d->exc.release();
             d->rstart.release(); d->rsamp.release(); d->rdir.release(); d->lpos.release(); d->lnext.release(); d->ldir.release();
         }
         delete d;
@@ -146,6 +146,37 @@ void pgx_release_device_images(pgx_index *h) {
 static void upload(DevBuf &b, const void *src, size_t bytes) {
     b.ensure(bytes ? bytes : 16);
     if (bytes) HIPCHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+}
+
+// k-mer seed table of a dense image in global memory (pgx_kernels.hip "k-mer seeds"): built level by level on the device,
+// 4^L entries at level L, each one pgx_extend of its parent.  K = log4(n) - 2 (the deepest level at which nearly every window of
+// a random text still occurs), at most PGX_SEED_MAX_K (1 GiB of table), PGX_SEED_K overrides (0 = no table).
+static void build_seed_table(pgx_device_image *d) {
+    PgxDevImage &g = d->img;
+    int K = 0;
+    for (uint64_t v = g.n; v >= 4; v >>= 2) K++;
+    K -= 2;
+    if (K > 12) K = 12;
+    if (const char *e = std::getenv("PGX_SEED_K")) K = std::atoi(e);
+    if (K > PGX_SEED_MAX_K) K = PGX_SEED_MAX_K;
+    if (K < 2) return;
+    const uint64_t limit = g.n < (1ull << 30) ? (1ull << 32) : (1ull << 40); // what an entry (and the 32-bit kernels) can hold
+    DevBuf tmp;
+    try {
+        d->seed.ensure(((size_t)1 << (2 * K)) * sizeof(uint4));
+        tmp.ensure(((size_t)1 << (2 * (K - 1))) * sizeof(uint4));
+        for (int L = 0; L < K; L++) { // level L -> L + 1; level K ends in d->seed
+            uint4 *dst = ((K - (L + 1)) % 2 == 0) ? d->seed.as<uint4>() : tmp.as<uint4>();
+            const uint4 *src = ((K - L) % 2 == 0) ? d->seed.as<uint4>() : tmp.as<uint4>();
+            const uint64_t n_dst = 1ull << (2 * (L + 1));
+            hipLaunchKernelGGL(pgx_seed_build_kernel, dim3((unsigned)((n_dst + 255) / 256)), dim3(256), 0, nullptr, g, src, dst, (uint32_t)L, n_dst, limit);
+            HIPCHECK(hipGetLastError());
+        }
+        HIPCHECK(hipDeviceSynchronize());
+    } catch (...) { tmp.release(); d->seed.release(); throw; }
+    tmp.release();
+    g.seed = d->seed.as<uint4>();
+    g.seed_k = (uint32_t)K;
 }
 
 // one device image per (index, device), created on first use; concurrent first calls from several host threads are serialised
@@ -162,6 +193,7 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
     upload(d->blocks, m.blocks.data(), m.blocks.size());
     upload(d->dir, m.dir.data(), m.dir.size() * 8);
     upload(d->blow, m.blow.data(), m.blow.size() * 2);
+    upload(d->exc, m.exc.data(), m.exc.size() * 4);
     upload(d->consts, &m.consts, sizeof(PgxConsts));
     upload(d->tstart, m.tstart.data(), m.tstart.size() * 8);
     upload(d->tvals, m.tvals.data(), m.tvals.size() * 8);
@@ -183,10 +215,14 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
     g.dir_shift = m.consts.dir_shift;
     g.excl_mask = m.consts.excl_mask;
     g.tag_dir_shift = m.consts.tag_dir_shift;
-    g.dense = m.consts.image_kind == PGX_IMAGE_DENSE ? 1u : 0u;
+    g.dense = m.consts.image_kind; // PGX_IMAGE_RL / _DENSE / _DENSE2
+    g.exc = d->exc.as<uint32_t>();
     size_t img_bytes = m.blocks.size() + m.dir.size() * 8 + m.blow.size() * 2;
-    if (g.dense) img_bytes = (size_t)m.consts.n_blocks * 16 * PGX_DENSE_LDS_U4 + 16; // padded blocks, no directory (pgx_dense_load)
-    d->lds_bytes = img_bytes <= 48 * 1024 ? ((img_bytes + 15) & ~(size_t)15) : 0;
+    if (g.dense == 1) img_bytes = (size_t)m.consts.n_blocks * 16 * PGX_DENSE_LDS_U4 + 16; // padded blocks, no directory (pgx_dense_load)
+    d->lds_bytes = (g.dense != 2 && img_bytes <= 48 * 1024) ? ((img_bytes + 15) & ~(size_t)15) : 0; // the dense2 image is never staged in LDS
+    g.seed_k = 0;
+    g.seed = nullptr;
+    if (g.dense && !d->lds_bytes && h->has_rank) build_seed_table(d.get());
     h->dev[device] = d.release();
     return h->dev[device];
 }
@@ -871,7 +907,13 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     }
     b->mem_count.ensure((n ? n : 1) * 4);
     b->mem_off.ensure((n + 1) * 8);
+    // a quarter of the device's memory (72 GB of the MI355X's 288 GB: ten million 150-bp reads are one chunk), 16 GiB at least
     uint64_t budget_slots = (16ull << 30) / sizeof(pgx_mem);
+    {
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) budget_slots = std::max<uint64_t>(budget_slots, (uint64_t)(mem_total / 4) / sizeof(pgx_mem));
+        else (void)hipGetLastError();
+    }
     if (const char *e = std::getenv("PGX_SLOT_BUDGET_MB")) budget_slots = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10)) * (1ull << 20) / sizeof(pgx_mem);
     if (!b->plan_valid || b->plan_min_len != min_len || b->plan_budget != budget_slots) { // cached across runs
         b->chunks.clear();
@@ -902,14 +944,19 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     if (n) {
         // persistent grid: as many workgroups as the device keeps resident (no inter-workgroup
         // dependency exists, so any grid size is correct; this one avoids a tail of late blocks)
-        const bool in_lds = b->dimg->lds_bytes != 0, dense = img.dense != 0;
-        kfn_wide = in_lds ? (dense ? (const void *)pgx_find_mems_kernel<true, true, false> : (const void *)pgx_find_mems_kernel<true, false, false>)
-                          : (dense ? (const void *)pgx_find_mems_kernel<false, true, false> : (const void *)pgx_find_mems_kernel<false, false, false>);
+        const bool in_lds = b->dimg->lds_bytes != 0, dense = img.dense != 0, d2 = img.dense == 2;
+        const bool seeded = img.seed_k != 0 && min_len >= img.seed_k; // (no stage of a shorter search has room for a seed)
+        kfn_wide = in_lds ? (dense ? (const void *)pgx_find_mems_kernel<true, 1, false, false> : (const void *)pgx_find_mems_kernel<true, 0, false, false>)
+                   : d2   ? (seeded ? (const void *)pgx_find_mems_kernel<false, 2, false, true> : (const void *)pgx_find_mems_kernel<false, 2, false, false>)
+                          : (dense ? (seeded ? (const void *)pgx_find_mems_kernel<false, 1, false, true> : (const void *)pgx_find_mems_kernel<false, 1, false, false>)
+                                   : (const void *)pgx_find_mems_kernel<false, 0, false, false>);
         kfn = kfn_wide;
         // 32-bit interval state for dense images of BWTs shorter than 2^30 (PGX_FM_NARROW=0 switches it off)
         const char *nv = std::getenv("PGX_FM_NARROW");
         if (dense && img.n < (1ull << 30) && !(nv && nv[0] == '0'))
-            kfn = in_lds ? (const void *)pgx_find_mems_kernel<true, true, true> : (const void *)pgx_find_mems_kernel<false, true, true>;
+            kfn = in_lds ? (const void *)pgx_find_mems_kernel<true, 1, true, false>
+                  : d2   ? (seeded ? (const void *)pgx_find_mems_kernel<false, 2, true, true> : (const void *)pgx_find_mems_kernel<false, 2, true, false>)
+                         : (seeded ? (const void *)pgx_find_mems_kernel<false, 1, true, true> : (const void *)pgx_find_mems_kernel<false, 1, true, false>);
         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, PGX_FM_THREADS, b->dimg->lds_bytes));
         HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
         if (occ < 1) occ = 1;

@@ -15,8 +15,8 @@ LIB_PATH = os.environ.get("PGX_LIB") or os.path.join(PKG_DIR, "libpgx.so")  # PG
 
 OK, ERR_IO, ERR_FORMAT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_ARG, ERR_NOMEM = range(8)
 MODE_COMPAT, MODE_STRICT = 0, 1
-MODE_IMAGE_RL, MODE_IMAGE_DENSE = 0x100, 0x200  # or-ed into mode: force the layout of the device rank image
-IMAGE_RL, IMAGE_DENSE = 0, 1
+MODE_IMAGE_RL, MODE_IMAGE_DENSE, MODE_IMAGE_DENSE2 = 0x100, 0x200, 0x400  # or-ed into mode: force the layout of the device rank image
+IMAGE_RL, IMAGE_DENSE, IMAGE_DENSE2 = 0, 1, 2
 TAGS_AUTO, TAGS_BYTECODE, TAGS_COMPACT = 0, 1, 2
 RUN_TAGS, RUN_TIMING = 1, 2
 
@@ -175,7 +175,7 @@ def convert_tags(in_path, out_path, compact=False):
 
 
 _VIEW_DTYPES = {0: np.uint8, 1: np.uint64, 2: np.uint64, 3: np.uint64, 4: np.uint64, 5: np.uint32, 6: np.uint8, 7: np.uint16,
-                8: np.uint64, 9: np.uint64, 10: np.uint32, 11: np.uint64, 12: np.uint64, 13: np.uint32, 14: np.uint8}
+                8: np.uint64, 9: np.uint64, 10: np.uint32, 11: np.uint64, 12: np.uint64, 13: np.uint32, 14: np.uint8, 15: np.uint32}
 LOCATE_SEQ_IDS, LOCATE_UNIQUE = 1, 2
 NO_POSITION = 0xFFFFFFFFFFFFFFFF
 

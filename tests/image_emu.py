@@ -34,7 +34,8 @@ class Consts:
 class ImageEmu:
     def __init__(self, index):
         self.c = Consts(index.image_view(6))
-        self.blocks = index.image_view(0).view(np.uint32).reshape(-1, 16)
+        self.blocks = index.image_view(0).view(np.uint32).reshape(-1, 32 if self.c.image_kind == 2 else 16)
+        self.exc = index.image_view(15) if self.c.image_kind == 2 else None
         self.dir = index.image_view(1)
         self.bstart = index.image_view(2)
         self.blow = index.image_view(7)
@@ -94,9 +95,56 @@ class ImageEmu:
         B = sum((cnt[i] + t[i]) * ((mrow >> (3 * i)) & 7) for i in range(6))
         return A & M64, B & M64
 
+    def dense2_rank(self, pos, cv, mrow):
+        """pgx_dense2_rank: 384 symbols per 128-byte block: header, three sub-blocks of two planes (A C G T = 0 1 2 3), exception
+        runs for \\n and N; a probe reads the header and the sub-block of its position"""
+        blk = (pos * 0xAAAAAAAB) >> 40
+        assert blk == pos // 384 and pos < (1 << 32)
+        dw = [int(x) for x in self.blocks[blk]]
+        rel = pos - blk * 384
+        sub, r = rel >> 7, rel & 127
+        sc = (dw[6] | (dw[7] << 32)) >> (27 if sub == 2 else 0)
+        n0, n1, n3 = (sc & 511, (sc >> 9) & 511, (sc >> 18) & 511) if sub else (0, 0, 0)
+        pc = lambda v: bin(v).count("1")
+        # the stored sub-block counts are the popcounts of the sub-blocks before this one
+        chk = [0, 0, 0]
+        for s in range(sub):
+            for k in range(4):
+                a, d = dw[8 + 8 * s + k], dw[12 + 8 * s + k]
+                chk[0] += pc(a); chk[1] += pc(d); chk[2] += pc(a & d)
+        assert chk == [n0, n1, n3], (blk, sub)
+        for h in range(4):
+            t = r - 32 * h
+            m = 0xFFFFFFFF if t >= 32 else ((1 << t) - 1 if t > 0 else 0)
+            a, d = dw[8 + 8 * sub + h] & m, dw[12 + 8 * sub + h] & m
+            n0 += pc(a); n1 += pc(d); n3 += pc(a & d)
+        e0 = e4 = 0
+        prev_end = 0
+        for i in range(dw[5] >> 24):
+            u = int(self.exc[(dw[5] & 0xFFFFFF) + i])
+            st, ln, kind = u & 511, (u >> 9) & 511, (u >> 18) & 1
+            assert ln >= 1 and st >= prev_end and st + ln <= 384 and u >> 19 == 0
+            prev_end = st + ln
+            for q in range(st, st + ln):  # exception positions are stored as code 0 in both planes
+                sb, rr = 8 + 8 * (q >> 7), q & 127
+                assert not (dw[sb + (rr >> 5)] >> (rr & 31)) & 1 and not (dw[sb + 4 + (rr >> 5)] >> (rr & 31)) & 1
+            take = min(rel - st, ln) if rel > st else 0
+            if kind:
+                e4 += take
+            else:
+                e0 += take
+        hsum = sum(dw[:5])
+        c = [(pos - rel) - hsum + e0, dw[0] + rel - (n0 + n1 - n3) - e0 - e4, dw[1] + n0 - n3, dw[2] + n1 - n3, dw[4] + e4, dw[3] + n3]
+        assert all(v >= 0 for v in c) and sum(c) == pos
+        A = c[cv]
+        B = sum(c[i] * ((mrow >> (3 * i)) & 7) for i in range(6))
+        return A & M64, B & M64
+
     def rank_ab(self, pos, cv, mrow):
         c = self.c
         pos = min(pos, c.n)
+        if c.image_kind == 2:
+            return self.dense2_rank(pos, cv, mrow)
         if c.image_kind == 1:
             return self.dense_rank(pos, cv, mrow)
         b = self.find_block(pos)
@@ -119,6 +167,9 @@ class ImageEmu:
         """pgx_rank_pair: a two-trip loop; trip 0 decodes pos0's block and serves pos1 too when it covers it"""
         c = self.c
         p0, p1 = min(pos0, c.n), min(pos1, c.n)
+        if c.image_kind == 2:
+            (A0, B0), (A1, B1) = self.dense2_rank(p0, cv, mrow), self.dense2_rank(p1, cv, mrow)
+            return A0, A1, (B1 - B0) & M64
         if c.image_kind == 1:
             (A0, B0), (A1, B1) = self.dense_rank(p0, cv, mrow), self.dense_rank(p1, cv, mrow)
             return A0, A1, (B1 - B0) & M64

@@ -118,7 +118,7 @@ def _chain(idx, pats):
 def test_backward_extension_matches_lf_device(fmd, layout):
     ri = O.RIndex(fmd[layout])
     kmers = _kmers72(fmd["text"])
-    for force in (P.MODE_IMAGE_DENSE, P.MODE_IMAGE_RL):
+    for force in (P.MODE_IMAGE_DENSE, P.MODE_IMAGE_RL, P.MODE_IMAGE_DENSE2):
         idx = P.Index(fmd[layout], mode=P.MODE_COMPAT | force)
         steps, last = _chain(idx, kmers)
         checked = 0
@@ -152,7 +152,7 @@ def test_backward_extension_matches_lf_device(fmd, layout):
 def test_sampled_kmers_fmd_symmetry_device(fmd, layout):
     kmers = _sample_12mers(fmd["text"])
     rcs = [_revcomp(k) for k in kmers]
-    for force in (P.MODE_IMAGE_DENSE, P.MODE_IMAGE_RL):
+    for force in (P.MODE_IMAGE_DENSE, P.MODE_IMAGE_RL, P.MODE_IMAGE_DENSE2):
         idx = P.Index(fmd[layout], mode=P.MODE_COMPAT | force)
         _, a = _chain(idx, kmers)
         _, b = _chain(idx, rcs)

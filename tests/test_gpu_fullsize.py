@@ -1,7 +1,7 @@
 """Full-size parity of the sigma = 6 synthetic pangenome workload inside the -m gpu tier: SURVEY 8d
 config-3 recipe at 1/10 scale (4 Mbp x 8 haplotypes x 2 strands, n = 64 M, r = 6.3 M), 1 M synthetic 150-bp reads,
 min_len 20 -- about 1.9 M MEMs, 23 M positions, 196 M extensions -- every MEM, run count and position against the CPU
-oracle, under both layouts of the device rank image.  (The same check at chr22 scale, n = 640 M, is
+oracle, under every layout of the device rank image.  (The same check at chr22 scale, n = 640 M, is
 scripts/parity_full_synth.py; its output is committed under profiles/.)"""
 import os
 
@@ -25,8 +25,9 @@ def test_synth_pangenome_one_million_reads(workdir):
     assert ri.sigma == 6 and ri.n > 60_000_000
     ref = O.find_mems_batch(ri, tags, cat, offs, 20, 1, threads=O.lib().orc_max_threads())
     assert len(ref["mems"]) > 1_500_000 and len(ref["positions"]) > 10_000_000 and ref["n_extensions"] > 150_000_000
-    for force in (P.MODE_IMAGE_DENSE, P.MODE_IMAGE_RL):
+    for force in (0, P.MODE_IMAGE_DENSE, P.MODE_IMAGE_RL):  # the automatic layout (dense2 + seed table), 64-byte dense blocks, run-length blocks
         idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | force)
+        assert force or idx.info().image_kind == P.IMAGE_DENSE2
         res = idx.find_mems(cat, offs, 20, 1, tags=True)
         assert np.array_equal(res["mem_offsets"], ref["mem_offsets"])
         assert res["mems"].tobytes() == ref["mems"].tobytes()

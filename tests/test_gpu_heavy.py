@@ -45,7 +45,7 @@ def test_reads_from_sequence_ends(workdir):
     cost = [ri.find_all_mems(r, 20, 1, with_ext=True)[1] for r in ends]
     assert max(cost) > 8000 and np.median([ri.find_all_mems(r, 20, 1, with_ext=True)[1] for r in normal[:200]]) < 600
     ref = O.find_mems_batch(ri, tags, cat, offs, 20, 1, threads=O.lib().orc_max_threads())
-    for force in (P.MODE_IMAGE_DENSE, P.MODE_IMAGE_RL):
+    for force in (P.MODE_IMAGE_DENSE, P.MODE_IMAGE_RL, P.MODE_IMAGE_DENSE2):
         idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | force)
         res, heavy = _run(idx, cat, offs, 20, 1)
         _same(res, ref)

@@ -38,12 +38,17 @@ def xy(xy_paths, built):
     return (P.Index(ri, tags), O.RIndex(ri), O.Tags(tags, O.TAGS_BYTECODE))
 
 
-@pytest.fixture(scope="module", params=["dense", "rl"])
+FORCE = {"dense": P.MODE_IMAGE_DENSE, "rl": P.MODE_IMAGE_RL, "dense2": P.MODE_IMAGE_DENSE2}
+KIND = {"dense": P.IMAGE_DENSE, "rl": P.IMAGE_RL, "dense2": P.IMAGE_DENSE2}
+
+
+@pytest.fixture(scope="module", params=["dense", "rl", "dense2"])
 def xenc(x_index, request):
-    """x index (encoded, no N) under both layouts of the device rank image (dense is the automatic choice at this size)"""
+    """x index (encoded, no N) under every layout of the device rank image (dense, staged in LDS, is the automatic choice at this
+    size; dense2 is the layout of everything that does not fit LDS and runs from global memory)"""
     ri, tags = x_index
-    idx = P.Index(ri, tags, mode=P.MODE_COMPAT | (P.MODE_IMAGE_DENSE if request.param == "dense" else P.MODE_IMAGE_RL))
-    assert idx.info().image_kind == (P.IMAGE_DENSE if request.param == "dense" else P.IMAGE_RL)
+    idx = P.Index(ri, tags, mode=P.MODE_COMPAT | FORCE[request.param])
+    assert idx.info().image_kind == KIND[request.param]
     return (idx, O.RIndex(ri), O.Tags(tags, O.TAGS_COMPACT))
 
 
@@ -163,7 +168,7 @@ def test_strict_mode_matches_oracle_strict(x_index, xy_paths, golden):
         ri, tags = O.RIndex(ri_path), O.Tags(tags_path, fmt)
         seqs = W.load_sequences(os.path.join(golden, text))
         cat, offs = W.sample_reads(seqs, 5000, 100, seed=44)
-        for force in (P.MODE_IMAGE_DENSE, P.MODE_IMAGE_RL):
+        for force in (P.MODE_IMAGE_DENSE, P.MODE_IMAGE_RL, P.MODE_IMAGE_DENSE2):
             idx = P.Index(ri_path, tags_path, mode=P.MODE_STRICT | force)
             for min_len, min_occ in [(5, 1), (20, 1), (12, 2)]:
                 ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, mode=O.MODE_STRICT, threads=O.lib().orc_max_threads())
@@ -283,7 +288,7 @@ def test_sigma6_pangenome_both_images(workdir):
         # same MEMs; the extension counts differ (STRICT rejects pattern[len] = 0 at once, COMPAT walks on from the endmarker)
         assert ref["mems"].tobytes() == strict["mems"].tobytes() and ref["n_extensions"] != strict["n_extensions"]
         for mode in (P.MODE_COMPAT | P.MODE_IMAGE_DENSE, P.MODE_COMPAT | P.MODE_IMAGE_RL, P.MODE_STRICT | P.MODE_IMAGE_DENSE,
-                     P.MODE_STRICT | P.MODE_IMAGE_RL):
+                     P.MODE_STRICT | P.MODE_IMAGE_RL, P.MODE_COMPAT | P.MODE_IMAGE_DENSE2, P.MODE_STRICT | P.MODE_IMAGE_DENSE2):
             idx = P.Index(ri_path, tags_path, mode=mode)
             _assert_same(idx.find_mems(cat, offs, min_len, min_occ, tags=True), strict if mode & 1 else ref, True)
             idx.close()
@@ -309,7 +314,7 @@ def test_long_and_ragged_reads(workdir):
     cat, offs = O.pack_reads(reads)
     for min_len, min_occ in [(20, 1), (300, 2)]:
         ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, threads=O.lib().orc_max_threads())
-        for force in (P.MODE_IMAGE_DENSE, P.MODE_IMAGE_RL):
+        for force in (P.MODE_IMAGE_DENSE, P.MODE_IMAGE_RL, P.MODE_IMAGE_DENSE2):
             idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | force)
             _assert_same(idx.find_mems(cat, offs, min_len, min_occ, tags=True), ref, True)
             idx.close()
@@ -363,14 +368,15 @@ def test_concurrent_batches_from_host_threads(x_index, golden):
     assert not errors, errors
 
 
+@pytest.mark.parametrize("layout", ["dense", "dense2"])
 @pytest.mark.parametrize("env", [{"PGX_FM_NARROW": "0"}, {"PGX_FM_NARROW_FORCE_REDO": "1"}])
-def test_wide_state_and_forced_redo(x_index, golden, monkeypatch, env):
+def test_wide_state_and_forced_redo(x_index, golden, monkeypatch, env, layout):
     """dense images of short BWTs run with 32-bit interval state; the 64-bit kernels (PGX_FM_NARROW=0) and the repeat of a
     chunk after a (here: simulated) 32-bit overflow must give the same answers"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     ri_path, tags_path = x_index
-    idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | P.MODE_IMAGE_DENSE)
+    idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | FORCE[layout])
     ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
     seqs = W.load_sequences(os.path.join(golden, "x.newline_separated"))
     cat, offs = W.sample_reads(seqs, 20000, 150, seed=97)

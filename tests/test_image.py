@@ -22,6 +22,8 @@ def _check_rank_and_extend(idx, ri, mode, n_ext=600, step=1):
     # every block: start position = sum of header counts (minus the excluded quirk slots)
     if c.image_kind == P.IMAGE_RL:
         assert len(emu.bstart) == c.n_blocks and emu.bstart[0] == 0
+    elif c.image_kind == P.IMAGE_DENSE2:
+        assert c.n_blocks == c.n // 384 + 1 and len(emu.blocks) == c.n_blocks
     else:
         assert c.n_blocks == (c.n >> 6) + 1 and len(emu.blocks) == c.n_blocks
     for pos in list(range(0, ri.n + 1, step)) + [ri.n, ri.n + 5, 1 << 62]:
@@ -65,13 +67,13 @@ def test_image_xy_legacy_fixture(built, mode):
                                           ("bidirectional_test/small_test/test.rl_bwt", True),
                                           ("bidirectional_test/small_test/test.rl_bwt", False),
                                           ("two_contig_graph/contigs_XY.rl_bwt", True)])
-@pytest.mark.parametrize("image", [P.IMAGE_RL, P.IMAGE_DENSE])
+@pytest.mark.parametrize("image", [P.IMAGE_RL, P.IMAGE_DENSE, P.IMAGE_DENSE2])
 def test_image_built_indexes(workdir, name, encoded, mode, image):
     ri_path, _ = W.build_index_from_rlbwt(os.path.join(G, name), workdir, "img_" + os.path.basename(name), encoded=encoded,
                                           with_tags=False)
     ri = O.RIndex(ri_path)
-    force = P.MODE_IMAGE_DENSE if image == P.IMAGE_DENSE else P.MODE_IMAGE_RL
-    if image == P.IMAGE_DENSE and mode == O.MODE_COMPAT and not encoded and not ri.has_N and ri.sigma == 5:
+    force = {P.IMAGE_DENSE: P.MODE_IMAGE_DENSE, P.IMAGE_DENSE2: P.MODE_IMAGE_DENSE2, P.IMAGE_RL: P.MODE_IMAGE_RL}[image]
+    if image != P.IMAGE_RL and mode == O.MODE_COMPAT and not encoded and not ri.has_N and ri.sigma == 5:
         # legacy layout without N in COMPAT: a header slot carries the reference-block quirk value, so the device blocks
         # must refine the reference's blocks -- no dense image there
         with pytest.raises(P.PgxError) as e:
@@ -121,14 +123,17 @@ def test_long_runs_split_and_merge(workdir):
         if exp is not None:
             assert tri[2] == exp, p
         assert emu.count(p) == ri.count(p)
-    # the same index as dense bit planes (the automatic choice at this size)
-    idx2 = P.Index(ri_path)
-    assert idx2.info().image_kind == P.IMAGE_DENSE
-    emu2 = ImageEmu(idx2)
-    for pos in [0, 1, 63, 64, 65, 69999, 70000, n - 1, n, n + 7] + [int(v) for v in rng.integers(0, n, 300)]:
-        assert emu2.rank6_true(pos) == ri.rank6_true(min(pos, n))
-    for p in ["A" * 100, "GACGT", "TTTTTG"]:
-        assert emu2.count(p) == ri.count(p)
+    # the same index as bit planes: dense2 is the automatic choice at this size (n = 189 k), dense (64-byte blocks) forced
+    for force, kind in ((0, P.IMAGE_DENSE2), (P.MODE_IMAGE_DENSE, P.IMAGE_DENSE)):
+        idx2 = P.Index(ri_path, mode=force)
+        assert idx2.info().image_kind == kind and not idx2.info().image_in_lds
+        emu2 = ImageEmu(idx2)
+        for pos in [0, 1, 63, 64, 65, 383, 384, 385, 69999, 70000, n - 1, n, n + 7] + [int(v) for v in rng.integers(0, n, 300)]:
+            assert emu2.rank6_true(pos) == ri.rank6_true(min(pos, n))
+        for p in ["A" * 100, "GACGT", "TTTTTG", "N" * 300, "NNNNA"]:
+            assert emu2.count(p) == ri.count(p)
+    # the N run (40 000 symbols) is a handful of exception runs per 384-symbol block, not one per symbol
+    assert len(idx2.image_view(0)) // 64 > 100 and len(P.Index(ri_path).image_view(15)) < 2 * (n // 384 + 1)
 
 
 def test_image_layout_choice(workdir, built):
