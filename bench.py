@@ -288,7 +288,8 @@ def main():
     if rank == 0:
         K, n = args.steps, args.reads
         reads_total = n * world * K
-        image = "LDS" if info.image_in_lds else ("dense bit planes" if info.image_kind == P.IMAGE_DENSE else "run-length blocks")
+        kinds = {P.IMAGE_RL: "run-length blocks", P.IMAGE_DENSE: "dense bit planes", P.IMAGE_DENSE2: "dense2 bit planes"}
+        image = ("LDS copy of " if info.image_in_lds else "") + kinds[info.image_kind]
         line = {
             "metric": "find_mems reads/sec (150 bp batch)",
             "value": reads_total / dt,
@@ -311,7 +312,9 @@ def main():
                 "min_occ": args.min_occ, "mode": args.mode, "tags": not args.no_tags,
                 "sharding": "reads sharded by rank, index replicated, no collective",
                 "bwt_size": int(info.bwt_size), "bwt_runs": int(info.n_runs), "image_in_lds": bool(info.image_in_lds),
-                "rank_image": "%s, %.0f MB%s" % (image, info.image_bytes / 1e6, "" if info.image_in_lds else ", resident in HBM"),
+                "rank_image": "%s, %.1f MB%s" % (image, info.image_bytes / 1e6, "" if info.image_in_lds else
+                                                 (", global memory (fits the 256 MB memory-side cache)" if info.image_bytes < 240e6 else ", resident in HBM")),
+                "image_kind": int(info.image_kind),
                 "tag_image_MB": info.tag_image_bytes / 1e6,
                 "index_build_host_s": round(build_s, 1), "prep_s": round(prep_s, 1),
             },

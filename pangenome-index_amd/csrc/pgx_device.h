@@ -35,7 +35,7 @@ struct PgxDevImage {
     const uint4 *seed; // 4^seed_k entries {k lo, k' lo, s lo, k hi | k' hi << 8 | s hi << 16 | depth << 24}
 };
 #define PGX_SEED_UNUSABLE 255u // depth value of entries the kernels must not use (a coordinate does not fit the entry)
-#define PGX_SEED_MAX_K 13
+#define PGX_SEED_MAX_K 14
 
 // heavy reads (pgx_kernels.hip): handed from pgx_find_mems_kernel to pgx_find_mems_heavy_kernel
 struct pgx_heavy_item {

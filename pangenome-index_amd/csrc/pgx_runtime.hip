@@ -149,14 +149,14 @@ static void upload(DevBuf &b, const void *src, size_t bytes) {
 }
 
 // k-mer seed table of a dense image in global memory (pgx_kernels.hip "k-mer seeds"): built level by level on the device,
-// 4^L entries at level L, each one pgx_extend of its parent.  K = log4(n) - 2 (the deepest level at which nearly every window of
-// a random text still occurs), at most PGX_SEED_MAX_K (1 GiB of table), PGX_SEED_K overrides (0 = no table).
+// 4^L entries at level L, each one pgx_extend of its parent.  K = log4(n) - 1, at most 13 (1 GiB of table; chr22 scale, 10 M reads:
+// K = 11 / 12 / 13 / 14: 41.2 / 39.1 / 37.2 / 36.4 ms with the 64-byte dense image), PGX_SEED_K overrides (0 = no table, at most 14).
 static void build_seed_table(pgx_device_image *d) {
     PgxDevImage &g = d->img;
     int K = 0;
     for (uint64_t v = g.n; v >= 4; v >>= 2) K++;
-    K -= 2;
-    if (K > 12) K = 12;
+    K -= 1;
+    if (K > 13) K = 13;
     if (const char *e = std::getenv("PGX_SEED_K")) K = std::atoi(e);
     if (K > PGX_SEED_MAX_K) K = PGX_SEED_MAX_K;
     if (K < 2) return;

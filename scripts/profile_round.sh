@@ -1,19 +1,23 @@
 #!/bin/bash
-# usage (GPU box): bash scripts/profile_round.sh <tag>   -- rocprofv3 kernel stats + PMC traffic for both workloads
-tag=$1
+# usage (GPU box): bash scripts/profile_round.sh <tag> [workloads...]   (default: chr22 x)
+# For each workload: rocprofv3 --kernel-trace --stats of bench.py (kernel durations), then one --pmc pass per counter
+# (FETCH_SIZE, WRITE_SIZE: separate runs, kernel-trace only) -> traffic_<workload>.json, which records what it measured
+# (bwt_size, reads, min_len, image kind, tags) so that bench.py attaches it only to the same workload.
+tag=$1; shift
+WLS=${@:-chr22 x}
 export TMPDIR=/tmp
 R=$PWD/gpurun_out/prof_$tag; mkdir -p $R
-for wl in x synth; do
-  steps=10; [ $wl = synth ] && steps=5
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/${wl}_stats -- python3 bench.py --workload $wl --steps $steps --warmup 2 --no-cpu-baseline --workdir /tmp/pgxwd_$wl > $R/${wl}_bench_under_rocprof.json 2> $R/${wl}_stats.err || echo FAIL stats $wl
+for wl in $WLS; do
+  steps=10; [ $wl = chr22 ] && steps=5
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/${wl}_stats -- python3 bench.py --workload $wl --steps $steps --warmup 2 --no-cpu-baseline --no-secondary --workdir /tmp/wd > $R/${wl}_bench_under_rocprof.json 2> $R/${wl}_stats.err || echo FAIL stats $wl
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/${wl}_$C -- python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --workdir /tmp/pgxwd_$wl > /dev/null 2> $R/${wl}_$C.err || echo FAIL $C $wl
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/${wl}_$C -- python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --workdir /tmp/wd > $R/${wl}_$C.json 2> $R/${wl}_$C.err || echo FAIL $C $wl
   done
 done
-python3 - <<PY
-import csv, glob, json, collections
-R = "$R"
-for wl in ("x", "synth"):
+python3 - $R $WLS <<'PY'
+import csv, glob, json, collections, sys
+R, wls = sys.argv[1], sys.argv[2:]
+for wl in wls:
     out = {}
     for C in ("FETCH_SIZE", "WRITE_SIZE"):
         agg = collections.defaultdict(list)
@@ -21,16 +25,21 @@ for wl in ("x", "synth"):
             for r in csv.DictReader(open(f)):
                 agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
         out[C] = {k: sum(v) / len(v) for k, v in agg.items() if k.startswith("pgx_")}
-    fm = [k for k in out["FETCH_SIZE"] if "find_mems" in k][0]
-    # FETCH_SIZE / WRITE_SIZE are in units of 1024 B (rocprofv3).  FETCH_SIZE = TCC_EA0_RDREQ x 64 B, but every read
-    # request of this kernel moves a whole 128-byte line (MI355X_MICROARCH.md "HBM": FETCH_SIZE tallies 128-B requests
-    # at 64 B; confirmed for THIS access pattern by profiles/r01_ubench_random_gather.txt: random 64-B and 128-B
-    # records are served at the same record rate), so the read side is doubled.  WRITE_SIZE is exact.
-    rec = {"workload": wl, "kernel": fm, "FETCH_SIZE_KB_per_launch": out["FETCH_SIZE"][fm], "WRITE_SIZE_KB_per_launch": out["WRITE_SIZE"].get(fm, 0.0),
+    fm = [k for k in out["FETCH_SIZE"] if "find_mems_kernel" in k][0]
+    bench = json.load(open("%s/%s_FETCH_SIZE.json" % (R, wl)))
+    cfg = bench["config"]
+    # FETCH_SIZE / WRITE_SIZE are in units of 1024 B (rocprofv3).  FETCH_SIZE = TCC_EA0_RDREQ x 64 B, but every read request of
+    # this kernel moves a whole 128-byte line (MI355X_MICROARCH.md "HBM": FETCH_SIZE tallies 128-B requests at 64 B; confirmed
+    # for THIS access pattern by profiles/r01_ubench_random_gather.txt: random 64-B and 128-B records are served at the same
+    # record rate), so the read side is doubled.  WRITE_SIZE is exact.
+    rec = {"workload": wl, "kernel": fm, "bwt_size": cfg["bwt_size"], "reads": cfg["reads_per_gpu"], "min_len": cfg["min_len"], "tags": cfg["tags"],
+           "image_kind": cfg["image_kind"],
+           "rank_image": cfg["rank_image"],
+           "FETCH_SIZE_KB_per_launch": out["FETCH_SIZE"][fm], "WRITE_SIZE_KB_per_launch": out["WRITE_SIZE"].get(fm, 0.0),
            "find_mems_hbm_bytes_per_launch": (2.0 * out["FETCH_SIZE"][fm] + out["WRITE_SIZE"].get(fm, 0.0)) * 1024.0,
            "all_kernels_FETCH_KB": out["FETCH_SIZE"], "all_kernels_WRITE_KB": out["WRITE_SIZE"],
-           "note": "memory-side (fabric) bytes: Infinity-Cache hits are included, so this is an upper bound on HBM bytes"}
+           "note": "memory-side (fabric) bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: Infinity-Cache hits are included, so this is an upper bound on HBM bytes"}
     json.dump(rec, open("%s/traffic_%s.json" % (R, wl), "w"), indent=1)
     print(wl, fm, rec["find_mems_hbm_bytes_per_launch"] / 1e9, "GB per launch")
 PY
-for wl in x synth; do cat $R/${wl}_stats/*/*_kernel_stats.csv | head -8; done
+for wl in $WLS; do cat $R/${wl}_stats/*/*_kernel_stats.csv | head -6 | cut -c1-60,300-; done
