@@ -406,11 +406,25 @@ def run_chrom(args, rank, world, local, wd, barrier, dist, red_dev):
     stream = torch.cuda.current_stream().cuda_stream
     dev = "cuda" if red_dev == "cuda" else "cpu"
 
+    # the exchange: libpgx's own RCCL path (pgx_exchange_mems: device-resident records, count-sized broadcasts, device
+    # interleave kernel) under the nccl backend; the torch / gloo implementation of pgx_shard only in CPU rehearsals
+    comm, owner_of = None, [0] * K
+    for r, cs in enumerate(owners):
+        for c in cs:
+            owner_of[c] = r
+    if dev == "cuda":
+        uid = [P.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        comm = P.Comm(uid[0], rank, world, device=local)
+
     def step():
-        parts = {}
         for c in owners[rank]:
             batches[c].run(args.min_len, args.min_occ, 0, stream)
-            parts[c] = batches[c].device_result() if dev == "cuda" else batches[c].result()  # nccl: records stay in HBM
+        if comm is not None:
+            n_r, n_m = comm.exchange({c: batches[c] for c in owners[rank]}, owner_of, download=False)
+            return [n_m], None, None
+        parts = {c: batches[c].result() for c in owners[rank]}
         return S.exchange_mems(parts, args.reads, K, dist=dist if world > 1 else None, device=dev)
 
     for _ in range(args.warmup):
@@ -435,8 +449,8 @@ def run_chrom(args, rank, world, local, wd, barrier, dist, red_dev):
             "config": {"workload": "chromosome-sharded: %d synthetic chromosomes over %d ranks, %d reads searched in every shard, "
                                    "all_gather of per-read MEM lists" % (K, world, args.reads),
                        "chrom_lengths": lengths, "owners": owners, "min_len": args.min_len, "min_occ": args.min_occ,
-                       "exchange": "torch.distributed all_gather (%s), %s" % (args.dist_backend, "device-resident records over RCCL" if dev == "cuda"
-                                                                              else "host-staged records")},
+                       "exchange": ("pgx_exchange_mems: RCCL all-gather of u32 offsets + count-sized broadcasts of device-resident records + device interleave"
+                                    if comm is not None else "torch.distributed all_gather (%s), host-staged records" % args.dist_backend)},
             "mems_per_step": int(mo[-1]), "mems_per_s": float(mo[-1]) * args.steps / dt,
         }), flush=True)
     for b in batches.values():

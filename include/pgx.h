@@ -244,8 +244,10 @@ pgx_status pgx_batch_create(pgx_index *h, int device, const uint8_t *reads, cons
  * batch costs no allocation per call).  Invalidates the results of the previous run. */
 pgx_status pgx_batch_upload(pgx_batch *b, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads);
 /* Run find_all_mems (+ tag queries) for every read of the batch; results stay on the device.
- * `stream` is a hipStream_t (NULL = default stream).  Asynchronous except for the few scalar
- * read-backs that size intermediate buffers. */
+ * `stream` is a hipStream_t; NULL = the batch's own non-blocking stream (every batch has one: its uploads and downloads
+ * use it too, so batches driven by different host threads overlap on one device -- upload of one, kernels of another,
+ * download of a third).  Asynchronous except for the few scalar read-backs that size intermediate buffers; complete
+ * when it returns. */
 pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min_occ, uint32_t flags, void *stream);
 /* Copy the results of the last run to host memory owned by the batch (valid until next run/free) */
 pgx_status pgx_batch_result(pgx_batch *b, pgx_result *out);
@@ -270,6 +272,43 @@ void pgx_batch_free(pgx_batch *b);
 pgx_status pgx_find_mems_batch(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets,
                                uint64_t n_reads, uint64_t min_len, uint64_t min_occ, uint32_t flags,
                                pgx_batch **batch_out, pgx_result *result_out);
+
+/* The same with the reads sharded over several devices of the node (the unit that shards is the per-read loop of
+ * src/find_mems.cpp:94-139): n_slices contiguous slices of the batch, slice i on devices[i] (a device may be named more than
+ * once) with its own host thread, batch and stream; the index image is replicated, there is no collective.  first_read
+ * (n_slices + 1 entries) receives the slice boundaries; results_out[i] / batches_out[i] are those of slice i: concatenated
+ * in slice order they are bit-identical to the unsharded result.  Free every batch with pgx_batch_free. */
+pgx_status pgx_find_mems_sharded(pgx_index *h, const int *devices, uint32_t n_slices, const uint8_t *reads, const uint64_t *offsets,
+                                 uint64_t n_reads, uint64_t min_len, uint64_t min_occ, uint32_t flags, pgx_batch **batches_out,
+                                 pgx_result *results_out, uint64_t *first_read);
+
+/* ---- chromosome-sharded mode (BASELINE configs[4]): exchange of per-read MEM lists over RCCL ------------------
+ * Every rank (one process per GPU) holds the indexes of some chromosomes ("shards"), searches ALL reads in each of them
+ * (one pgx_batch per shard, same reads) and calls pgx_exchange_mems; every rank receives, for every read, the concatenation in
+ * shard order of the per-shard MEM lists -- each list bit-exact with the reference run on that shard's index.  (This is not
+ * the MEM set of a merged whole-genome index: maximality, BWT coordinates and min_occ are per shard.)  The per-read
+ * offsets and the 32-byte records travel device to device: ncclAllGather of u32 offsets, then one ncclBroadcast per rank of
+ * exactly that rank's record count (no padding), then a device kernel interleaves the records per read.  RCCL is loaded on
+ * first use.  The communicator id comes from rank 0 (pgx_comm_unique_id) and reaches the other ranks by whatever
+ * means the caller has (a file, MPI, torch.distributed's store ...). */
+#define PGX_COMM_ID_BYTES 128
+typedef struct pgx_comm pgx_comm;
+pgx_status pgx_comm_unique_id(uint8_t id[PGX_COMM_ID_BYTES]);
+pgx_status pgx_comm_init(const uint8_t id[PGX_COMM_ID_BYTES], int rank, int world, int device, pgx_comm **out);
+void pgx_comm_free(pgx_comm *c);
+typedef struct {
+    uint64_t n_reads, n_mems;
+    const uint64_t *mem_offsets;  /* n_reads + 1 (device) */
+    const pgx_mem *mems;          /* n_mems (device): read by read, within a read shard by shard, within a shard discovery order */
+    const uint32_t *shard_of_mem; /* n_mems (device) */
+} pgx_exchange_result;
+/* batches[k] holds the finished run of shard shard_ids[k] of THIS rank (n_local of them); owner_of_shard[c] (n_shards entries,
+ * identical on every rank) names the rank that holds shard c.  Collective: every rank of the communicator calls it.  The
+ * result lives in buffers of the communicator until its next exchange. */
+pgx_status pgx_exchange_mems(pgx_comm *c, pgx_batch *const *batches, const uint32_t *shard_ids, uint32_t n_local,
+                             const uint32_t *owner_of_shard, uint32_t n_shards, pgx_exchange_result *out);
+/* copy the last exchange's result to host arrays (any may be NULL) */
+pgx_status pgx_exchange_download(pgx_comm *c, uint64_t *mem_offsets, pgx_mem *mems, uint32_t *shard_of_mem);
 
 /* find_mems_function (include/pangenome_index/algorithm.hpp:653-736) for n independent (read, start) pairs: query i
  * evaluates the function on read read_of[i] at start position x[i] and reports the start position it returns (next_x),

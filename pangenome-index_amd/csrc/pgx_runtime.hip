@@ -25,22 +25,9 @@
 
 #include "pgx_device.h"
 #include "pgx_host.hpp"
+#include "pgx_runtime.hpp"
 
 using namespace pgx;
-
-#define HIPCHECK(expr)                                                                              \
-    do {                                                                                            \
-        hipError_t e_ = (expr);                                                                     \
-        if (e_ != hipSuccess)                                                                       \
-            throw Error(PGX_ERR_HIP, std::string(#expr) + " failed: " + hipGetErrorString(e_));    \
-    } while (0)
-
-#define PGX_GUARD_BEGIN try {
-#define PGX_GUARD_END                                                                               \
-    }                                                                                               \
-    catch (const pgx::Error &e) { pgx::set_last_error(e.what()); return e.code; }                   \
-    catch (const std::bad_alloc &) { pgx::set_last_error("out of host memory"); return PGX_ERR_NOMEM; } \
-    catch (const std::exception &e) { pgx::set_last_error(e.what()); return PGX_ERR_HIP; }
 
 static int checked_device_count() {
     int n = 0;
@@ -57,68 +44,6 @@ static void use_device(int device) {
     if (device < 0 || device >= n) throw Error(PGX_ERR_ARG, "device ordinal out of range");
     HIPCHECK(hipSetDevice(device));
 }
-
-struct DevBuf { // grow-only device buffer
-    void *p = nullptr;
-    size_t cap = 0;
-    void ensure(size_t bytes) {
-        if (bytes <= cap) return;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) {
-            p = nullptr;
-            (void)hipGetLastError();
-            throw Error(PGX_ERR_NOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed: " + hipGetErrorString(e));
-        }
-        cap = want;
-    }
-    // grow while keeping the first `keep` bytes (device-to-device copy)
-    void ensure_keep(size_t bytes, size_t keep) {
-        if (bytes <= cap) return;
-        void *old = p;
-        size_t want = bytes + bytes / 2 + 256;
-        void *np = nullptr;
-        hipError_t e = hipMalloc(&np, want);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            throw Error(PGX_ERR_NOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed: " + hipGetErrorString(e));
-        }
-        if (old && keep) {
-            e = hipMemcpy(np, old, keep, hipMemcpyDeviceToDevice);
-            if (e != hipSuccess) { (void)hipFree(np); throw Error(PGX_ERR_HIP, std::string("hipMemcpy failed: ") + hipGetErrorString(e)); }
-        }
-        if (old) (void)hipFree(old);
-        p = np; cap = want;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
-    }
-    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
-};
-
-struct HostBuf { // grow-only pinned host buffer (fast D2H; returned to the caller as result arrays)
-    void *p = nullptr;
-    size_t cap = 0;
-    void ensure(size_t bytes) {
-        if (bytes <= cap) return;
-        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 4 + 256;
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-        if (e != hipSuccess) {
-            p = nullptr;
-            (void)hipGetLastError();
-            throw Error(PGX_ERR_NOMEM, "hipHostMalloc of " + std::to_string(want) + " bytes failed: " + hipGetErrorString(e));
-        }
-        cap = want;
-    }
-    void release() {
-        if (p) (void)hipHostFree(p);
-        p = nullptr; cap = 0;
-    }
-    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
-};
 
 struct pgx_device_image {
     int device = -1;
@@ -271,6 +196,17 @@ static void scan_excl(int mode, const void *in, uint64_t n, uint64_t min_len, ui
     const int raw = nb <= 2048; // up to 4 M items: no separate scan of the block totals
     if (!raw) hipLaunchKernelGGL(pgx_scan_sums_kernel, dim3(1), dim3(256), 0, s, sums, nb);
     hipLaunchKernelGGL(pgx_scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, mode, in, n, min_len, (const uint64_t *)sums, nb, out, total_out, raw);
+    HIPCHECK(hipGetLastError());
+}
+
+void pgx_use_device(int device) { use_device(device); }
+void pgx_scan_u64(const uint64_t *in, uint64_t n, uint64_t *out, uint64_t *tmp, hipStream_t s) {
+    if (n == 0) { HIPCHECK(hipMemsetAsync(out, 0, 8, s)); return; }
+    const uint64_t nb = (n + PGX_SCAN_BLOCK_ITEMS - 1) / PGX_SCAN_BLOCK_ITEMS;
+    hipLaunchKernelGGL(pgx_scan_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, 1, (const void *)in, n, (uint64_t)0, tmp);
+    const int raw = nb <= 2048;
+    if (!raw) hipLaunchKernelGGL(pgx_scan_sums_kernel, dim3(1), dim3(256), 0, s, tmp, nb);
+    hipLaunchKernelGGL(pgx_scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, 1, (const void *)in, n, (uint64_t)0, (const uint64_t *)tmp, nb, out, (uint64_t *)nullptr, raw);
     HIPCHECK(hipGetLastError());
 }
 
@@ -780,6 +716,7 @@ struct pgx_batch {
     pgx_index *h = nullptr;
     pgx_device_image *dimg = nullptr;
     int device = 0;
+    hipStream_t own = nullptr; // non-blocking stream of this batch: its copies, and its kernels when the caller names no stream
     uint64_t n_reads = 0, read_bytes = 0;
     std::vector<uint64_t> h_offsets; // rebased host copy (chunk planning)
     std::vector<pgx_chunk> chunks;   // plan of the last run (reused while min_len / budget are unchanged)
@@ -811,6 +748,7 @@ static void batch_release(pgx_batch *b) {
         for (HostBuf *x : hb) x->release();
         for (auto &e : b->ev)
             if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        if (b->own) { (void)hipStreamDestroy(b->own); b->own = nullptr; }
     }
     delete b;
 }
@@ -826,13 +764,16 @@ static void batch_upload(pgx_batch *b, const uint8_t *reads, const uint64_t *off
     const uint64_t lo = offsets[0], hi = offsets[n_reads];
     b->read_bytes = hi - lo;
     // device offsets are rebased to 0; 16 bytes of zero padding after the last read
+    // copies go through the batch's own non-blocking stream: batches of other host threads (other streams of the same device)
+    // are not serialised behind them the way copies on the legacy default stream would be
     b->reads.ensure(b->read_bytes + 32);
-    HIPCHECK(hipMemset((uint8_t *)b->reads.p + b->read_bytes, 0, 32));
-    if (b->read_bytes) HIPCHECK(hipMemcpy(b->reads.p, reads + lo, b->read_bytes, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemsetAsync((uint8_t *)b->reads.p + b->read_bytes, 0, 32, b->own));
+    if (b->read_bytes) HIPCHECK(hipMemcpyAsync(b->reads.p, reads + lo, b->read_bytes, hipMemcpyHostToDevice, b->own));
     b->h_offsets.resize(n_reads + 1);
     for (uint64_t i = 0; i <= n_reads; i++) b->h_offsets[i] = offsets[i] - lo;
     b->offsets.ensure((n_reads + 1) * 8);
-    HIPCHECK(hipMemcpy(b->offsets.p, b->h_offsets.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpyAsync(b->offsets.p, b->h_offsets.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, b->own));
+    HIPCHECK(hipStreamSynchronize(b->own));
 }
 
 extern "C" pgx_status pgx_batch_create(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets,
@@ -851,6 +792,7 @@ extern "C" pgx_status pgx_batch_create(pgx_index *h, int device, const uint8_t *
     b->h = h;
     b->dimg = dimg;
     b->device = device;
+    HIPCHECK(hipStreamCreateWithFlags(&b->own, hipStreamNonBlocking));
     batch_upload(b.get(), reads, offsets, n_reads);
     *out = b.release();
     return PGX_OK;
@@ -880,7 +822,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     PGX_GUARD_BEGIN
     if (!b) throw Error(PGX_ERR_ARG, "pgx_batch_run: null batch");
     use_device(b->device);
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = stream ? (hipStream_t)stream : b->own;
     const PgxDevImage &img = b->dimg->img;
     const uint64_t n = b->n_reads;
     const bool want_tags = (flags & PGX_RUN_TAGS) != 0;
@@ -1128,9 +1070,9 @@ extern "C" pgx_status pgx_batch_result(pgx_batch *b, pgx_result *out) {
     use_device(b->device);
     const uint64_t n = b->n_reads, m = b->n_mems;
     b->h_mem_off.ensure((n + 1) * 8);
-    HIPCHECK(hipMemcpy(b->h_mem_off.p, b->mem_off.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpyAsync(b->h_mem_off.p, b->mem_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, b->own));
     b->h_mems.ensure((m ? m : 1) * sizeof(pgx_mem));
-    if (m) HIPCHECK(hipMemcpy(b->h_mems.p, b->mems.p, m * sizeof(pgx_mem), hipMemcpyDeviceToHost));
+    if (m) HIPCHECK(hipMemcpyAsync(b->h_mems.p, b->mems.p, m * sizeof(pgx_mem), hipMemcpyDeviceToHost, b->own));
     std::memset(out, 0, sizeof *out);
     out->n_reads = n;
     out->n_mems = m;
@@ -1141,15 +1083,16 @@ extern "C" pgx_status pgx_batch_result(pgx_batch *b, pgx_result *out) {
         b->h_run_nums.ensure((m ? m : 1) * 8);
         b->h_pos_off.ensure((m + 1) * 8);
         b->h_positions.ensure((b->n_positions ? b->n_positions : 1) * 8);
-        if (m) HIPCHECK(hipMemcpy(b->h_run_nums.p, b->tw.run_nums.p, m * 8, hipMemcpyDeviceToHost));
-        HIPCHECK(hipMemcpy(b->h_pos_off.p, b->tw.pos_off.p, (m + 1) * 8, hipMemcpyDeviceToHost));
-        if (b->n_positions) HIPCHECK(hipMemcpy(b->h_positions.p, b->tw.positions.p, b->n_positions * 8, hipMemcpyDeviceToHost));
+        if (m) HIPCHECK(hipMemcpyAsync(b->h_run_nums.p, b->tw.run_nums.p, m * 8, hipMemcpyDeviceToHost, b->own));
+        HIPCHECK(hipMemcpyAsync(b->h_pos_off.p, b->tw.pos_off.p, (m + 1) * 8, hipMemcpyDeviceToHost, b->own));
+        if (b->n_positions) HIPCHECK(hipMemcpyAsync(b->h_positions.p, b->tw.positions.p, b->n_positions * 8, hipMemcpyDeviceToHost, b->own));
         out->tag_run_counts = b->h_run_nums.as<uint64_t>();
         out->pos_offsets = b->h_pos_off.as<uint64_t>();
         out->positions = b->h_positions.as<uint64_t>();
         out->n_positions = b->n_positions;
         out->n_tag_overflow = b->n_tag_overflow;
     }
+    HIPCHECK(hipStreamSynchronize(b->own)); // (the run itself completed inside pgx_batch_run, on whatever stream it used)
     return PGX_OK;
     PGX_GUARD_END
 }
@@ -1166,6 +1109,36 @@ extern "C" pgx_status pgx_find_mems_batch(pgx_index *h, int device, const uint8_
     if (st != PGX_OK) { pgx_batch_free(b); return st; }
     *batch_out = b;
     return PGX_OK;
+}
+
+// reads sharded over devices: contiguous slices, one host thread + batch + stream per slice, the index image
+// replicated per device, no collective; slice i covers reads [first_read[i], first_read[i + 1])
+extern "C" pgx_status pgx_find_mems_sharded(pgx_index *h, const int *devices, uint32_t n_slices, const uint8_t *reads, const uint64_t *offsets,
+                                            uint64_t n_reads, uint64_t min_len, uint64_t min_occ, uint32_t flags, pgx_batch **batches_out,
+                                            pgx_result *results_out, uint64_t *first_read) {
+    PGX_GUARD_BEGIN
+    if (!h || !devices || !n_slices || !offsets || !batches_out || !results_out || !first_read)
+        throw Error(PGX_ERR_ARG, "pgx_find_mems_sharded: null argument");
+    for (uint32_t i = 0; i < n_slices; i++) { batches_out[i] = nullptr; first_read[i] = n_reads * i / n_slices; }
+    first_read[n_slices] = n_reads;
+    for (uint32_t i = 0; i < n_slices; i++) (void)device_image(h, devices[i]); // images first: one upload per distinct device
+    std::vector<pgx_status> st(n_slices, PGX_OK);
+    std::vector<std::string> err(n_slices);
+    std::vector<std::thread> th;
+    for (uint32_t i = 0; i < n_slices; i++)
+        th.emplace_back([&, i]() {
+            const uint64_t a = first_read[i], b = first_read[i + 1];
+            st[i] = pgx_find_mems_batch(h, devices[i], reads, offsets + a, b - a, min_len, min_occ, flags, &batches_out[i], &results_out[i]);
+            if (st[i] != PGX_OK) err[i] = pgx_last_error(); // (the message is thread-local)
+        });
+    for (auto &t : th) t.join();
+    for (uint32_t i = 0; i < n_slices; i++)
+        if (st[i] != PGX_OK) {
+            for (uint32_t k = 0; k < n_slices; k++) { pgx_batch_free(batches_out[k]); batches_out[k] = nullptr; }
+            throw Error(st[i], "slice " + std::to_string(i) + " (device " + std::to_string(devices[i]) + "): " + err[i]);
+        }
+    return PGX_OK;
+    PGX_GUARD_END
 }
 
 // ------------------------------------------------------------------------------------------

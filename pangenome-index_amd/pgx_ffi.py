@@ -58,6 +58,10 @@ class DeviceArray:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<i8", "data": (int(ptr or 0), False), "version": 2, "strides": None}
 
 
+class ExchangeResult(C.Structure):
+    _fields_ = [("n_reads", u64), ("n_mems", u64), ("mem_offsets", p), ("mems", p), ("shard_of_mem", p)]
+
+
 class Timing(C.Structure):
     _fields_ = [
         ("ms_find_mems", C.c_float), ("ms_compact", C.c_float), ("ms_tag_locate", C.c_float),
@@ -127,6 +131,13 @@ def lib():
     L.pgx_batch_free.argtypes = [p]
     L.pgx_batch_free.restype = None
     L.pgx_find_mems_batch.argtypes = [p, C.c_int, p, p, u64, u64, u64, u32, C.POINTER(p), C.POINTER(Result)]
+    L.pgx_find_mems_sharded.argtypes = [p, p, u32, p, p, u64, u64, u64, u32, p, p, p]
+    L.pgx_comm_unique_id.argtypes = [p]
+    L.pgx_comm_init.argtypes = [p, C.c_int, C.c_int, C.c_int, C.POINTER(p)]
+    L.pgx_comm_free.argtypes = [p]
+    L.pgx_comm_free.restype = None
+    L.pgx_exchange_mems.argtypes = [p, p, p, u32, p, u32, C.POINTER(ExchangeResult)]
+    L.pgx_exchange_download.argtypes = [p, p, p, p]
     L.pgx_device_count.argtypes = [C.POINTER(C.c_int)]
     L.pgx_device_name.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
     _lib = L
@@ -315,6 +326,81 @@ class Index:
             return b.result()
         finally:
             b.free()
+
+
+def _result_dict(r):
+    n, m = int(r.n_reads), int(r.n_mems)
+    out = dict(n_extensions=int(r.n_extensions), n_tag_overflow=int(r.n_tag_overflow))
+    out["mem_offsets"] = _u64_array(r.mem_offsets, n + 1)
+    out["mems"] = (np.frombuffer(C.string_at(r.mems, m * 32), dtype=MEM_DTYPE).copy() if m else np.zeros(0, MEM_DTYPE))
+    if r.pos_offsets:
+        out["tag_run_counts"] = _u64_array(r.tag_run_counts, m)
+        out["pos_offsets"] = _u64_array(r.pos_offsets, m + 1)
+        out["positions"] = _u64_array(r.positions, int(r.n_positions))
+    return out
+
+
+def find_mems_sharded(index, devices, reads_cat, offsets, min_len, min_occ, tags=False):
+    """pgx_find_mems_sharded: contiguous read slices, slice i on devices[i]; returns the per-slice result dicts in slice order"""
+    reads_cat = np.ascontiguousarray(reads_cat, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    k = len(devices)
+    dev = (C.c_int * k)(*devices)
+    batches = (p * k)()
+    results = (Result * k)()
+    first = (u64 * (k + 1))()
+    _check(index.L.pgx_find_mems_sharded(index.h, dev, k, reads_cat.ctypes.data if len(reads_cat) else None, offsets.ctypes.data,
+                                         len(offsets) - 1, min_len, min_occ, RUN_TAGS if tags else 0, batches, results, first))
+    try:
+        return [_result_dict(results[i]) for i in range(k)], list(first)
+    finally:
+        for i in range(k):
+            index.L.pgx_batch_free(batches[i])
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through libpgx: rank 0 makes it, the other ranks receive the bytes out of band"""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(lib().pgx_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """RCCL communicator of the chromosome-sharded exchange (pgx_comm): one per rank = per process = per GPU"""
+
+    def __init__(self, uid, rank, world, device=0):
+        self.L = lib()
+        self.c = p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid)
+        _check(self.L.pgx_comm_init(buf, rank, world, device, C.byref(self.c)))
+
+    def exchange(self, batches, owner_of_shard, download=True):
+        """batches: {shard id: Batch (already run)} of this rank; owner_of_shard[c] = rank holding shard c.
+        Returns (n_reads, n_mems) or, with download, (mem_offsets, mems, shard_of_mem) as host arrays."""
+        ids = sorted(batches)
+        k = len(ids)
+        arr = (p * max(k, 1))(*[batches[c].b for c in ids])
+        sid = (u32 * max(k, 1))(*ids)
+        own = (u32 * len(owner_of_shard))(*owner_of_shard)
+        r = ExchangeResult()
+        _check(self.L.pgx_exchange_mems(self.c, arr, sid, k, own, len(owner_of_shard), C.byref(r)))
+        if not download:
+            return int(r.n_reads), int(r.n_mems)
+        mo = np.zeros(int(r.n_reads) + 1, dtype=np.uint64)
+        mems = np.zeros(int(r.n_mems), dtype=MEM_DTYPE)
+        shard = np.zeros(int(r.n_mems), dtype=np.uint32)
+        _check(self.L.pgx_exchange_download(self.c, mo.ctypes.data, mems.ctypes.data if len(mems) else None, shard.ctypes.data if len(shard) else None))
+        return mo, mems, shard
+
+    def free(self):
+        if getattr(self, "c", None):
+            self.L.pgx_comm_free(self.c)
+            self.c = None
+
+    __del__ = free
 
 
 class Batch:

@@ -4,9 +4,21 @@
 //
 // stdout grammar is the reference's, byte for byte (find_mems.cpp:115-118,138,144-145 and
 // tag_arrays.cpp:885-889); reads are processed in device batches but printed in file order.
-// Options (ours): --device N, --mode compat|strict, --batch N (reads per device batch),
-//                 --tags-format auto|bytecode|compact, --quiet (no per-read stderr line)
+// Options (ours): --device N | --gpus N (devices 0 .. N-1) | --devices a,b,.. ; --streams W (batches in flight per device);
+//                 --mode compat|strict, --batch N (reads per device batch), --tags-format auto|bytecode|compact,
+//                 --quiet (no per-read stderr line)
 // The tag file may be either query format; the reference's find_mems only loads the sdsl-compact one.
+//
+// The per-read loop of the reference (find_mems.cpp:94-139) becomes a pipeline: one reader thread cuts the reads file into
+// batches of consecutive reads; every device has W worker threads, each with its own batch and stream (pgx_batch), which
+// upload, run, download and format the text of whole batches -- so on one device the upload of batch k + 1, the kernels of
+// batch k and the download / formatting of batch k - 1 overlap, and N devices take batches in turn with the index replicated
+// (reads shard, no collective); the main thread writes the finished texts in file order.
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -46,18 +58,61 @@ static inline char *put_str(char *p, const char *s) {
     return p + n;
 }
 
+struct Job { // one batch of consecutive reads
+    uint64_t id = 0, first_seq = 0; // batch number, reads before it in the file
+    std::string cat;
+    std::vector<uint64_t> offs;
+};
+struct Done {
+    std::vector<std::string> outs, errs; // text pieces in read order
+    double mem_s = 0, tag_s = 0;
+    std::string error;
+};
+
+// text of reads [lo, hi) of a finished batch (stdout piece + the per-read stderr lines of find_all_mems, algorithm.hpp:754)
+static void format_range(const pgx_result &r, size_t lo, size_t hi, uint64_t first_seq, bool quiet, std::string &out, std::string &err) {
+    out.clear();
+    err.clear();
+    // exact upper bound of the text of this range: 20 digits per number
+    const uint64_t m_lo = r.mem_offsets[lo], m_hi = r.mem_offsets[hi];
+    const uint64_t p_cnt = r.pos_offsets[m_hi] - r.pos_offsets[m_lo];
+    out.resize((hi - lo) * 32 + (m_hi - m_lo) * 192 + p_cnt * 22 + 64);
+    char *p = &out[0];
+    for (size_t i = lo; i < hi; i++) {
+        const size_t seq = first_seq + i + 1;
+        if (!quiet) { err += "[find_all_mems] total mems="; err += std::to_string(r.mem_offsets[i + 1] - r.mem_offsets[i]); err += '\n'; }
+        p = put_str(p, "Seq: "); p = put_u64(p, seq); *p++ = '\n'; // :115
+        for (uint64_t m = r.mem_offsets[i]; m < r.mem_offsets[i + 1]; m++) {
+            const pgx_mem &mm = r.mems[m];
+            p = put_str(p, "MEM START: "); p = put_u64(p, mm.start);
+            p = put_str(p, ", MEM END: "); p = put_u64(p, mm.end);
+            p = put_str(p, " BWT START: "); p = put_u64(p, mm.bwt_start);
+            p = put_str(p, " SIZE: ");
+            if (mm.size < 0) { *p++ = '-'; p = put_u64(p, (uint64_t)(-(mm.size + 1)) + 1u); } else p = put_u64(p, (uint64_t)mm.size);
+            *p++ = '\n'; // :118
+            p = put_str(p, "Number of unique positions: "); p = put_u64(p, r.pos_offsets[m + 1] - r.pos_offsets[m]); *p++ = '\n'; // tag_arrays.cpp:885
+            for (uint64_t q = r.pos_offsets[m]; q < r.pos_offsets[m + 1]; q++) { p = put_u64(p, r.positions[q]); *p++ = ','; *p++ = ' '; }
+            *p++ = '\n';
+        }
+        *p++ = '\n'; // :138
+    }
+    out.resize((size_t)(p - &out[0]));
+}
+
 int main(int argc, char **argv) {
     if (argc < 6) {
         std::cerr << "usage: find_mems <r_index.ri> <tags> <reads.txt> <min_mem_length> <min_occ>"
-                     " [--device N] [--mode compat|strict] [--batch N] [--tags-format auto|bytecode|compact] [--quiet]" << std::endl;
+                     " [--device N | --gpus N | --devices a,b,..] [--streams W] [--mode compat|strict] [--batch N]"
+                     " [--tags-format auto|bytecode|compact] [--quiet]" << std::endl;
         return EXIT_FAILURE;
     }
     const std::string r_index_file = argv[1], tag_array_index = argv[2], reads_file = argv[3];
     const size_t mem_length = (size_t)std::stoi(argv[4]); // find_mems.cpp:17 (std::stoi -> size_t)
     const size_t min_occ = (size_t)std::stoi(argv[5]);
-    int device = 0;
+    std::vector<int> devices(1, 0);
     uint32_t mode = PGX_MODE_COMPAT, tfmt = PGX_TAGS_AUTO;
-    size_t batch_reads = 1u << 20;
+    size_t batch_reads = 1u << 18;
+    unsigned streams = 3;
     bool quiet = false;
     int first_opt = 6;
     // find_mems_chunked.cpp:15-28 takes an optional sixth positional (chunk_size_mb of its memory-mapped loader): accepted, unused
@@ -65,7 +120,15 @@ int main(int argc, char **argv) {
     for (int i = first_opt; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> std::string { if (i + 1 >= argc) { std::cerr << "missing value for " << a << std::endl; std::exit(EXIT_FAILURE); } return argv[++i]; };
-        if (a == "--device") device = std::stoi(next());
+        if (a == "--device") devices.assign(1, std::stoi(next()));
+        else if (a == "--gpus") { const int g = std::stoi(next()); devices.clear(); for (int d = 0; d < std::max(1, g); d++) devices.push_back(d); }
+        else if (a == "--devices") {
+            devices.clear();
+            std::stringstream ss(next());
+            for (std::string tok; std::getline(ss, tok, ',');) if (!tok.empty()) devices.push_back(std::stoi(tok));
+            if (devices.empty()) { std::cerr << "--devices: empty list" << std::endl; return EXIT_FAILURE; }
+        }
+        else if (a == "--streams") streams = (unsigned)std::max(1, std::stoi(next()));
         else if (a == "--mode") mode = next() == "strict" ? PGX_MODE_STRICT : PGX_MODE_COMPAT;
         else if (a == "--batch") batch_reads = (size_t)std::stoull(next());
         else if (a == "--tags-format") { const std::string f = next(); tfmt = f == "bytecode" ? PGX_TAGS_BYTECODE : f == "compact" ? PGX_TAGS_COMPACT : PGX_TAGS_AUTO; }
@@ -94,127 +157,175 @@ int main(int argc, char **argv) {
     auto time2 = std::chrono::high_resolution_clock::now();
     std::cerr << "Loading r-index into memory took " << std::chrono::duration<double>(time2 - time1).count() << " seconds" << std::endl;
     std::cerr << "Reading the tag array index" << std::endl;
-    if (pgx_index_to_device(h, device) != PGX_OK) { std::cerr << pgx_last_error() << std::endl; return EXIT_FAILURE; }
+    for (int d : devices) // the index is replicated: one image per distinct device
+        if (pgx_index_to_device(h, d) != PGX_OK) { std::cerr << pgx_last_error() << std::endl; return EXIT_FAILURE; }
     auto time3 = std::chrono::high_resolution_clock::now();
     std::cerr << "Loading tag arrays took " << std::chrono::duration<double>(time3 - time2).count() << " seconds" << std::endl;
 
     std::ifstream reads(reads_file, std::ios::binary);
     if (!reads) { std::cerr << "Cannot open reads file: " << reads_file << std::endl; std::exit(EXIT_FAILURE); } // :91
 
-    // The reference formats with iostreams one value at a time; a device batch finishes in milliseconds, so the text
-    // side is what a user waits for: lines are split with memchr from 16 MiB chunks, and each batch is formatted by a
-    // pool of threads (contiguous read ranges, one buffer each) and written in read order.
-    const unsigned n_fmt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    pgx_batch *b = nullptr;
-    std::string cat, carry;
-    std::vector<uint64_t> offs;
-    std::vector<char> chunk(16u << 20);
-    size_t chunk_len = 0, chunk_pos = 0;
-    size_t seq_no = 0;
-    bool eof = false;
-    // next line of the reads file (without the '\n') appended to `cat`; false at end of file
-    auto next_line = [&](bool &empty) -> bool {
-        for (;;) {
-            if (chunk_pos < chunk_len) {
-                const char *base = chunk.data() + chunk_pos;
-                const char *nl = static_cast<const char *>(std::memchr(base, '\n', chunk_len - chunk_pos));
-                if (nl) {
-                    const size_t len = (size_t)(nl - base);
-                    empty = carry.empty() && len == 0;
-                    if (!carry.empty()) { cat += carry; carry.clear(); }
-                    cat.append(base, len);
-                    chunk_pos += len + 1;
+    // ---- queues ----
+    const unsigned n_workers = (unsigned)devices.size() * streams;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned n_fmt = std::max(1u, std::min(16u, hw / n_workers)); // formatting threads per batch
+    std::mutex mu;
+    std::condition_variable cv_jobs, cv_done, cv_space;
+    std::deque<std::unique_ptr<Job>> jobs;
+    std::map<uint64_t, std::unique_ptr<Done>> finished;
+    bool reader_done = false, failed = false;
+    uint64_t n_jobs = 0, next_write = 0;
+    const size_t max_ahead = 2 * n_workers + 2; // batches read or finished but not yet written (bounds memory)
+
+    // The reference reads with std::getline; here lines are split with memchr from 16 MiB chunks.
+    std::thread reader([&]() {
+        std::string carry;
+        std::vector<char> chunk(16u << 20);
+        size_t chunk_len = 0, chunk_pos = 0;
+        bool eof = false;
+        uint64_t seq_no = 0;
+        auto next_line = [&](std::string &cat, bool &empty) -> bool { // next line (without the newline) appended to cat
+            for (;;) {
+                if (chunk_pos < chunk_len) {
+                    const char *base = chunk.data() + chunk_pos;
+                    const char *nl = static_cast<const char *>(std::memchr(base, '\n', chunk_len - chunk_pos));
+                    if (nl) {
+                        const size_t len = (size_t)(nl - base);
+                        empty = carry.empty() && len == 0;
+                        if (!carry.empty()) { cat += carry; carry.clear(); }
+                        cat.append(base, len);
+                        chunk_pos += len + 1;
+                        return true;
+                    }
+                    carry.append(base, chunk_len - chunk_pos); // line continues in the next chunk
+                    chunk_pos = chunk_len;
+                }
+                if (eof) {
+                    if (carry.empty()) return false;
+                    empty = false; // std::getline returns a last line without a terminator
+                    cat += carry;
+                    carry.clear();
                     return true;
                 }
-                carry.append(base, chunk_len - chunk_pos); // line continues in the next chunk
-                chunk_pos = chunk_len;
+                reads.read(chunk.data(), (std::streamsize)chunk.size());
+                chunk_len = (size_t)reads.gcount();
+                chunk_pos = 0;
+                if (chunk_len == 0) eof = true;
             }
-            if (eof) {
-                if (carry.empty()) return false;
-                empty = false; // std::getline returns a last line without a terminator
-                cat += carry;
-                carry.clear();
-                return true;
-            }
-            reads.read(chunk.data(), (std::streamsize)chunk.size());
-            chunk_len = (size_t)reads.gcount();
-            chunk_pos = 0;
-            if (chunk_len == 0) eof = true;
-        }
-    };
-    bool done = false;
-    std::vector<std::string> outs(n_fmt), errs(n_fmt);
-    while (!done) {
-        cat.clear();
-        offs.assign(1, 0);
-        while (offs.size() <= batch_reads) {
-            bool empty = false;
-            if (!next_line(empty)) { done = true; break; }
-            if (empty) continue; // :97
-            offs.push_back(cat.size());
-        }
-        const size_t n = offs.size() - 1;
-        if (n == 0) break;
-        // one long-lived batch: its device and pinned host buffers are reused by every chunk of reads
-        pgx_result r;
-        const uint8_t *rp = reinterpret_cast<const uint8_t *>(cat.data());
-        pgx_status st = b ? pgx_batch_upload(b, rp, offs.data(), n) : pgx_batch_create(h, device, rp, offs.data(), n, &b);
-        if (st == PGX_OK) st = pgx_batch_run(b, mem_length, min_occ, PGX_RUN_TAGS | PGX_RUN_TIMING, nullptr);
-        if (st == PGX_OK) st = pgx_batch_result(b, &r);
-        if (st != PGX_OK) {
-            std::cerr << pgx_last_error() << std::endl;
-            return EXIT_FAILURE;
-        }
-        pgx_timing t;
-        if (pgx_batch_timing(b, &t) == PGX_OK) {
-            total_mem_time += 1e-3 * (t.ms_find_mems + t.ms_compact);
-            total_tag_time += 1e-3 * (t.ms_tag_locate + t.ms_tag_gather + t.ms_tag_sort);
-        }
-        auto format_range = [&](unsigned w) {
-            const size_t lo = n * w / n_fmt, hi = n * (w + 1) / n_fmt;
-            std::string &out = outs[w], &err = errs[w];
-            out.clear();
-            err.clear();
-            // exact upper bound of the text of this range: 20 digits per number
-            const uint64_t m_lo = r.mem_offsets[lo], m_hi = r.mem_offsets[hi];
-            const uint64_t p_cnt = r.pos_offsets[m_hi] - r.pos_offsets[m_lo];
-            out.resize((hi - lo) * 32 + (m_hi - m_lo) * 192 + p_cnt * 22 + 64);
-            char *p = &out[0];
-            for (size_t i = lo; i < hi; i++) {
-                const size_t seq = seq_no + i + 1;
-                if (!quiet) { err += "[find_all_mems] total mems="; err += std::to_string(r.mem_offsets[i + 1] - r.mem_offsets[i]); err += '\n'; } // algorithm.hpp:754
-                p = put_str(p, "Seq: "); p = put_u64(p, seq); *p++ = '\n'; // :115
-                for (uint64_t m = r.mem_offsets[i]; m < r.mem_offsets[i + 1]; m++) {
-                    const pgx_mem &mm = r.mems[m];
-                    p = put_str(p, "MEM START: "); p = put_u64(p, mm.start);
-                    p = put_str(p, ", MEM END: "); p = put_u64(p, mm.end);
-                    p = put_str(p, " BWT START: "); p = put_u64(p, mm.bwt_start);
-                    p = put_str(p, " SIZE: ");
-                    if (mm.size < 0) { *p++ = '-'; p = put_u64(p, (uint64_t)(-(mm.size + 1)) + 1u); } else p = put_u64(p, (uint64_t)mm.size);
-                    *p++ = '\n'; // :118
-                    p = put_str(p, "Number of unique positions: "); p = put_u64(p, r.pos_offsets[m + 1] - r.pos_offsets[m]); *p++ = '\n'; // tag_arrays.cpp:885
-                    for (uint64_t q = r.pos_offsets[m]; q < r.pos_offsets[m + 1]; q++) { p = put_u64(p, r.positions[q]); *p++ = ','; *p++ = ' '; }
-                    *p++ = '\n';
-                }
-                *p++ = '\n'; // :138
-            }
-            out.resize((size_t)(p - &out[0]));
         };
-        if (n_fmt == 1 || n < 4096) {
-            for (unsigned w = 0; w < n_fmt; w++) format_range(w);
-        } else {
-            std::vector<std::thread> pool;
-            for (unsigned w = 0; w < n_fmt; w++) pool.emplace_back(format_range, w);
-            for (auto &th : pool) th.join();
+        bool done = false;
+        while (!done) {
+            std::unique_ptr<Job> j(new Job());
+            j->offs.assign(1, 0);
+            while (j->offs.size() <= batch_reads) {
+                bool empty = false;
+                if (!next_line(j->cat, empty)) { done = true; break; }
+                if (empty) continue; // :97
+                j->offs.push_back(j->cat.size());
+            }
+            const size_t n = j->offs.size() - 1;
+            if (n == 0) break;
+            j->first_seq = seq_no;
+            seq_no += n;
+            std::unique_lock<std::mutex> lk(mu);
+            cv_space.wait(lk, [&]() { return failed || n_jobs - next_write < max_ahead; });
+            if (failed) break;
+            j->id = n_jobs++;
+            jobs.push_back(std::move(j));
+            cv_jobs.notify_one();
         }
-        for (unsigned w = 0; w < n_fmt; w++) {
-            std::fwrite(outs[w].data(), 1, outs[w].size(), stdout);
-            if (!errs[w].empty()) std::fwrite(errs[w].data(), 1, errs[w].size(), stderr);
+        std::lock_guard<std::mutex> lk(mu);
+        reader_done = true;
+        cv_jobs.notify_all();
+        cv_done.notify_all();
+    });
+
+    auto worker = [&](int device) {
+        pgx_batch *b = nullptr; // long-lived: its device and pinned host buffers are reused by every batch of this worker
+        for (;;) {
+            std::unique_ptr<Job> j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_jobs.wait(lk, [&]() { return failed || !jobs.empty() || reader_done; });
+                if (failed || jobs.empty()) break;
+                j = std::move(jobs.front());
+                jobs.pop_front();
+            }
+            std::unique_ptr<Done> d(new Done());
+            const size_t n = j->offs.size() - 1;
+            pgx_result r;
+            const uint8_t *rp = reinterpret_cast<const uint8_t *>(j->cat.data());
+            pgx_status st = b ? pgx_batch_upload(b, rp, j->offs.data(), n) : pgx_batch_create(h, device, rp, j->offs.data(), n, &b);
+            if (st == PGX_OK) st = pgx_batch_run(b, mem_length, min_occ, PGX_RUN_TAGS | PGX_RUN_TIMING, nullptr);
+            if (st == PGX_OK) st = pgx_batch_result(b, &r);
+            if (st != PGX_OK) d->error = pgx_last_error();
+            else {
+                pgx_timing t;
+                if (pgx_batch_timing(b, &t) == PGX_OK) {
+                    d->mem_s = 1e-3 * (t.ms_find_mems + t.ms_compact);
+                    d->tag_s = 1e-3 * (t.ms_tag_locate + t.ms_tag_gather + t.ms_tag_sort);
+                }
+                const unsigned parts = n < 4096 ? 1u : n_fmt;
+                d->outs.resize(parts);
+                d->errs.resize(parts);
+                if (parts == 1) format_range(r, 0, n, j->first_seq, quiet, d->outs[0], d->errs[0]);
+                else {
+                    std::vector<std::thread> pool;
+                    for (unsigned w = 0; w < parts; w++)
+                        pool.emplace_back([&, w]() { format_range(r, n * w / parts, n * (w + 1) / parts, j->first_seq, quiet, d->outs[w], d->errs[w]); });
+                    for (auto &th : pool) th.join();
+                }
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            if (!d->error.empty()) failed = true;
+            finished[j->id] = std::move(d);
+            cv_done.notify_all();
+            if (failed) { cv_jobs.notify_all(); cv_space.notify_all(); }
         }
-        seq_no += n;
+        pgx_batch_free(b);
+    };
+    std::vector<std::thread> workers;
+    for (int d : devices)
+        for (unsigned w = 0; w < streams; w++) workers.emplace_back(worker, d);
+
+    // ---- writer: batches in file order ----
+    std::string error;
+    for (;;) {
+        std::unique_ptr<Done> d;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&]() { return finished.count(next_write) || (reader_done && next_write == n_jobs) || (failed && !finished.count(next_write)); });
+            if (!finished.count(next_write)) break;
+            d = std::move(finished[next_write]);
+            finished.erase(next_write);
+            next_write++;
+            cv_space.notify_all();
+        }
+        if (!d->error.empty()) { error = d->error; break; }
+        for (size_t w = 0; w < d->outs.size(); w++) {
+            std::fwrite(d->outs[w].data(), 1, d->outs[w].size(), stdout);
+            if (!d->errs[w].empty()) std::fwrite(d->errs[w].data(), 1, d->errs[w].size(), stderr);
+        }
+        total_mem_time += d->mem_s;
+        total_tag_time += d->tag_s;
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!error.empty()) failed = true;
+        cv_jobs.notify_all();
+        cv_space.notify_all();
+    }
+    reader.join();
+    for (auto &th : workers) th.join();
+    if (error.empty()) // a batch that failed behind one still in flight when the writer stopped
+        for (auto &kv : finished)
+            if (!kv.second->error.empty()) { error = kv.second->error; break; }
+    if (error.empty() && failed) error = "find_mems: a device batch failed";
+    if (!error.empty()) {
+        std::cerr << error << std::endl;
+        return EXIT_FAILURE;
     }
     std::fflush(stdout);
-    pgx_batch_free(b);
     std::cout.flush();
     std::cout << "\nTotal time for finding all MEMs: " << total_mem_time << " seconds" << std::endl; // :144
     std::cout << "Total time for all tag queries: " << total_tag_time << " seconds" << std::endl;   // :145

@@ -91,6 +91,34 @@ def test_exchange_world_size_2_gloo(built, tmp_path):
 
 
 @pytest.mark.gpu
+def test_exchange_through_the_c_abi_rccl(workdir):
+    """pgx_exchange_mems: RCCL all-gather of the u32 offsets + one broadcast per rank of the records + the device interleave
+    kernel, here with a communicator of one rank that owns all three shards (the GPU box has one device; the same entry point
+    runs the N-rank case of an 8-GPU node), against the definition of the mode computed with the oracle"""
+    import pgx_ffi as P
+
+    paths, cat, offs = _setup(workdir)
+    indexes = [O.RIndex(p) for p in paths]
+    for min_len in (5, 12):
+        mo, mems, shard, _ = _expected(indexes, cat, offs, min_len, 1)
+        idx = [P.Index(p) for p in paths]
+        batches = {c: idx[c].batch(cat, offs) for c in range(3)}
+        for b in batches.values():
+            b.run(min_len, 1, 0)
+        comm = P.Comm(P.comm_unique_id(), 0, 1)
+        got = comm.exchange(batches, [0, 0, 0])
+        assert np.array_equal(got[0], mo) and got[1].tobytes() == mems.tobytes() and np.array_equal(got[2], shard.astype(np.uint32))
+        # a second exchange on the same communicator (buffers are reused) with the shards given in another order
+        got = comm.exchange({2: batches[2], 0: batches[0], 1: batches[1]}, [0, 0, 0])
+        assert np.array_equal(got[0], mo) and got[1].tobytes() == mems.tobytes()
+        with pytest.raises(P.PgxError):
+            comm.exchange({0: batches[0]}, [0, 0, 0])  # this rank owns three shards
+        comm.free()
+        for b in batches.values():
+            b.free()
+
+
+@pytest.mark.gpu
 def test_exchange_with_hip_engine(workdir):
     import pgx_ffi as P
 

@@ -47,7 +47,11 @@ def test_cli_many_reads_small_batches(built, x_index, workdir):
                 f.write("\n")
     ref = O.find_mems_batch(O.RIndex(ri), O.Tags(tags, O.TAGS_COMPACT), cat, offs, 10, 1, threads=4)
     exp = format_find_mems(ref)
-    for extra in ([], ["--batch", "777", "--quiet"], ["--tags-format", "compact", "--device", "0"]):
+    # --devices 0,0: two device slots (here the same GPU twice), each with its own worker threads, batches and streams: the
+    # path `--gpus N` takes on an N-GPU node; the text must come out in file order whichever worker finishes first
+    for extra in ([], ["--batch", "777", "--quiet"], ["--tags-format", "compact", "--device", "0"],
+                  ["--devices", "0,0", "--streams", "2", "--batch", "300"], ["--gpus", "1", "--streams", "1", "--batch", "5000"],
+                  ["--devices", "0,0,0", "--streams", "1", "--batch", "64", "--quiet"]):
         r = _run(CLI, ri, tags, path, 10, 1, *extra)
         assert r.returncode == 0, r.stderr
         assert strip_timing(r.stdout) == exp

@@ -272,6 +272,23 @@ def test_sharded_equals_unsharded(xenc, golden):
     _assert_same(whole, ref, True)
 
 
+def test_sharded_through_the_c_abi(xenc, golden):
+    """pgx_find_mems_sharded: the slices run on host threads of the library, one batch and stream each (here every slice on device 0:
+    the code path of an N-GPU node); concatenated in slice order = the unsharded result"""
+    import pgx_shard as S
+
+    idx, ri, tags = xenc
+    seqs = W.load_sequences(os.path.join(golden, "x.newline_separated"))
+    cat, offs = W.sample_reads(seqs, 40003, 150, seed=101)
+    ref = O.find_mems_batch(ri, tags, cat, offs, 10, 1, threads=O.lib().orc_max_threads())
+    for devices in ([0], [0, 0], [0, 0, 0, 0, 0]):
+        parts, first = P.find_mems_sharded(idx, devices, cat, offs, 10, 1, tags=True)
+        assert first[0] == 0 and first[-1] == 40003 and len(parts) == len(devices)
+        _assert_same(S.merge_results(parts), ref, True)
+    with pytest.raises(P.PgxError):
+        P.find_mems_sharded(idx, [0, 99], cat, offs, 10, 1)
+
+
 def test_sigma6_pangenome_both_images(workdir):
     """sigma = 6 synthetic pangenome (N runs, both strands): COMPAT == STRICT there, and both image layouts must agree
     with the oracle on reads that include N runs, sequence ends and reverse complements"""
