@@ -42,7 +42,7 @@ Rccl &rccl() {
     static std::string err;
     std::call_once(once, []() {
         for (const char *name : {"librccl.so.1", "librccl.so"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); // (a process that already holds an RCCL -- torch's -- gets that one back)
             if (r.lib) break;
         }
         if (!r.lib) { err = std::string("RCCL is not available: ") + dlerror(); return; }

@@ -94,28 +94,48 @@ def test_exchange_world_size_2_gloo(built, tmp_path):
 def test_exchange_through_the_c_abi_rccl(workdir):
     """pgx_exchange_mems: RCCL all-gather of the u32 offsets + one broadcast per rank of the records + the device interleave
     kernel, here with a communicator of one rank that owns all three shards (the GPU box has one device; the same entry point
-    runs the N-rank case of an 8-GPU node), against the definition of the mode computed with the oracle"""
-    import pgx_ffi as P
-
+    runs the N-rank case of an 8-GPU node), against the definition of the mode computed with the oracle.  In a process of its
+    own: RCCL comes with its own runtime state, which should not meet the torch imported by other tests of this module."""
     paths, cat, offs = _setup(workdir)
     indexes = [O.RIndex(p) for p in paths]
+    exp = os.path.join(workdir, "xch_expected.npz")
+    z = {"cat": cat, "offs": offs, "paths": np.array(paths)}
     for min_len in (5, 12):
         mo, mems, shard, _ = _expected(indexes, cat, offs, min_len, 1)
-        idx = [P.Index(p) for p in paths]
-        batches = {c: idx[c].batch(cat, offs) for c in range(3)}
-        for b in batches.values():
-            b.run(min_len, 1, 0)
-        comm = P.Comm(P.comm_unique_id(), 0, 1)
-        got = comm.exchange(batches, [0, 0, 0])
-        assert np.array_equal(got[0], mo) and got[1].tobytes() == mems.tobytes() and np.array_equal(got[2], shard.astype(np.uint32))
-        # a second exchange on the same communicator (buffers are reused) with the shards given in another order
-        got = comm.exchange({2: batches[2], 0: batches[0], 1: batches[1]}, [0, 0, 0])
-        assert np.array_equal(got[0], mo) and got[1].tobytes() == mems.tobytes()
-        with pytest.raises(P.PgxError):
-            comm.exchange({0: batches[0]}, [0, 0, 0])  # this rank owns three shards
-        comm.free()
-        for b in batches.values():
-            b.free()
+        z.update({"mo%d" % min_len: mo, "mems%d" % min_len: mems.view(np.int64), "shard%d" % min_len: shard})
+    np.savez(exp, **z)
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import pgx_ffi as P
+z = np.load(%r)
+paths, cat, offs = [str(p) for p in z["paths"]], z["cat"], z["offs"]
+for min_len in (5, 12):
+    mo, mems, shard = z["mo%%d" %% min_len], z["mems%%d" %% min_len], z["shard%%d" %% min_len]
+    idx = [P.Index(p) for p in paths]
+    batches = {c: idx[c].batch(cat, offs) for c in range(3)}
+    for b in batches.values():
+        b.run(min_len, 1, 0)
+    comm = P.Comm(P.comm_unique_id(), 0, 1)
+    got = comm.exchange(batches, [0, 0, 0])
+    assert np.array_equal(got[0], mo) and np.array_equal(got[1].view(np.int64), mems) and np.array_equal(got[2], shard.astype(np.uint32))
+    # a second exchange on the same communicator (buffers are reused) with the shards given in another order
+    got = comm.exchange({2: batches[2], 0: batches[0], 1: batches[1]}, [0, 0, 0])
+    assert np.array_equal(got[0], mo) and np.array_equal(got[1].view(np.int64), mems)
+    try:
+        comm.exchange({0: batches[0]}, [0, 0, 0])  # this rank owns three shards
+        raise SystemExit("no error for a missing shard")
+    except P.PgxError:
+        pass
+    comm.free()
+    for b in batches.values():
+        b.free()
+    for i in idx:
+        i.close()
+    print("rccl exchange ok", min_len, len(mems))
+""" % (os.path.join(ROOT, "pangenome-index_amd"), exp)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.count("rccl exchange ok") == 2, r.stdout + r.stderr
 
 
 @pytest.mark.gpu
