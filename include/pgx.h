@@ -123,7 +123,9 @@ pgx_status pgx_index_to_device(pgx_index *h, int device);
  * locate image (built on first use of one of these selectors, pgx_image.h "locate image"):
  * 8 rstart (u64, first BWT position of every run + n), 9 rsamp (u64, samples[run]: what getSample returns),
  * 10 rdir (u32), 11 lpos (u64, ones of `last`), 12 lnext (u64, samples[last_to_run[i] + 1]), 13 ldir (u32),
- * 14 locate constants (PgxLocConsts); 15 exception runs of the dense2 rank image (u32). */
+ * 14 locate constants (PgxLocConsts); 15 exception runs of the dense2 rank image (u32);
+ * literal count image of an encoded index without N: 16 block starts (u64), 17 six cumulative counts per
+ * block (u64), 18 runs as the reference's late scan sees them (u64: code << 56 | length), 19 first run of every block (u32). */
 pgx_status pgx_index_image_view(const pgx_index *h, int which, const void **ptr, uint64_t *bytes);
 
 /* ---- index construction (build side; CPU, run once) --------------------------------------- */
@@ -175,8 +177,9 @@ pgx_status pgx_tag_query_batch(pgx_index *h, int device, const uint64_t *start, 
 
 /* FastLocate::count / count_encoded (include/pangenome_index/r-index.hpp:540-556): backward search of
  * every read; out[i] = final BWT range, {1, 0} when empty (the query_tags path, src/query_tags.cpp:88-96).
- * PGX_ERR_UNSUPPORTED in COMPAT mode on an encoded index without N: the reference's rankAt_encoded
- * mis-parses such blocks (it always reads six cumulative varints, src/r-index.cpp:578). */
+ * In COMPAT mode on an encoded index without N the reference's rankAt_encoded mis-parses every block (it always reads
+ * six cumulative varints, src/r-index.cpp:578: SURVEY 8a quirk 3); that wrong-but-deterministic result is reproduced
+ * (a separate image of the reference's blocks as its scan sees them); PGX_MODE_STRICT gives the true ranges. */
 typedef struct {
     uint64_t first;
     uint64_t second;

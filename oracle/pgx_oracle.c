@@ -214,8 +214,9 @@ static inline uint64_t bytecode_read(const uint8_t *s, uint64_t n, uint64_t *i, 
     for (;;) {
         if (*i >= n) { if (over) *over = 1; return res; }
         uint8_t b = s[(*i)++];
-        if (b & 0x80) { res += ((uint64_t)(b & 0x7F)) << off; off += 7; }
-        else { res += ((uint64_t)b) << off; return res; }
+        /* (bits beyond 64 are dropped: only mis-parsed streams -- quirk 3 -- ever get there, a shift by >= 64 is undefined in C) */
+        if (b & 0x80) { if (off < 64) res += ((uint64_t)(b & 0x7F)) << off; off += 7; }
+        else { if (off < 64) res += ((uint64_t)b) << off; return res; }
     }
 }
 

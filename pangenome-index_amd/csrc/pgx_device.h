@@ -125,6 +125,19 @@ __global__ void pgx_locate_walk_kernel(PgxLocImage loc, const uint64_t *qs, cons
                                        const uint64_t *run0, const uint64_t *piece_off, uint64_t n_pieces, const uint64_t *val_off,
                                        int seq_ids, uint64_t *out);
 
+// literal count image: COMPAT count_encoded / LF_encoded on an encoded index without N, block by block as the
+// reference's rankAt_encoded (src/r-index.cpp:570-590) sees it -- true cumulative counts, run scan one varint late
+struct PgxLitImage {
+    const uint64_t *bstart, *cum, *runs; // n_blocks ; 6 n_blocks ; all runs (code << 56 | length)
+    const uint32_t *roff;                // n_blocks + 1
+    const uint32_t *code_of, *cslot_of;  // 256 each
+    uint64_t C[8];
+    uint64_t n, n_blocks;
+};
+// out[i] = LF over `steps` symbols: count mode (in == NULL): the whole read i from {0, n - 1}; LF mode: one symbol sym[i] from in[i]
+__global__ void pgx_lit_count_kernel(PgxLitImage lit, const uint8_t *reads, const uint64_t *offsets, const pgx_range *in, const uint8_t *sym,
+                                     uint64_t n, pgx_range *out);
+
 // merge_tags passes (pgx_merge_kernels.hip)
 __global__ void pgx_mt_file_of_kernel(const uint64_t *da, uint64_t n, uint64_t n_seq, const uint32_t *seq_to_file, uint32_t n_files,
                                       uint8_t *file_of, unsigned long long *n_bad);

@@ -90,6 +90,10 @@ struct RiFile { // FastLocate as stored (src/r-index.cpp:266-376)
     bool encoded = false, hasN = false;
     uint64_t enc_block_size = 10;
     std::vector<RefBlock> blocks;
+    // COMPAT count_encoded / LF_encoded on an encoded index WITHOUT N: rankAt_encoded reads six cumulative
+    // varints where five were written (src/r-index.cpp:578), so its run scan starts one varint late.  lit_runs[b] = the runs
+    // the reference's scan sees in block b (code << 56 | length); empty unless the index has that shape.
+    std::vector<std::vector<uint64_t>> lit_runs;
     uint64_t n_file_blocks = 0; // incl. a trailing never-filled block
     double ref_block_mean_bytes = 0;
     void parse(const uint8_t *p, uint64_t n);
@@ -118,6 +122,14 @@ struct HostImage {
     uint64_t n_runs = 0;
 };
 
+struct LitHostImage { // literal count image (quirk 3), built on first use
+    std::vector<uint64_t> bstart, cum, runs; // block starts; six cumulative counts per block (nuc order); all runs
+    std::vector<uint32_t> roff;              // first run of block b in runs (n_blocks + 1 entries)
+    uint32_t code_of[256], cslot_of[256];    // symbol_to_code (r-index.hpp:664-668: unknown -> 0), sym_map
+    uint64_t C[8];
+    bool built = false;
+};
+
 struct LocHostImage { // locate image (pgx_image.h), built on first use
     PgxLocConsts consts;
     std::vector<uint64_t> rstart, rsamp, lpos, lnext;
@@ -127,6 +139,7 @@ struct LocHostImage { // locate image (pgx_image.h), built on first use
 
 void build_rank_image(const RiFile &ri, uint32_t mode, HostImage &img);
 void build_locate_image(const RiFile &ri, LocHostImage &loc);
+void build_literal_image(const RiFile &ri, LitHostImage &lit);
 void build_tag_image(const TagFile &tf, HostImage &img);
 void build_ext_tables(const RiFile &ri, uint32_t mode, PgxConsts &c);
 
@@ -141,5 +154,6 @@ struct pgx_index {
     uint32_t mode = 0;
     pgx::HostImage img;
     pgx::LocHostImage loc;
+    pgx::LitHostImage lit;
     std::vector<pgx_device_image *> dev; // one per device ordinal (lazily filled)
 };

@@ -97,6 +97,30 @@ void RiFile::parse(const uint8_t *p, uint64_t n) {
             }
             blocks.push_back(std::move(blk));
         }
+        if (!hasN) { // the scan rankAt_encoded performs on this shape (quirk 3): six varints skipped, then headers wherever that lands
+            auto vread = [&](uint64_t &loc) { // gbwt::ByteCode::read without a bound but the stream's
+                uint64_t off = 0, res = 0;
+                for (;;) {
+                    if (loc >= nbytes) return res;
+                    const uint8_t b = s[loc++];
+                    if (off < 64) res += (uint64_t)(b & 0x7F) << off;
+                    if (!(b & 0x80)) return res;
+                    off += 7;
+                }
+            };
+            lit_runs.assign(blocks_start_pos.ones.size(), {});
+            for (uint64_t b = 0; b < lit_runs.size() && b < n_file_blocks; b++) {
+                uint64_t loc = starts.get(b);
+                const uint64_t end = (b + 1 < n_file_blocks) ? starts.get(b + 1) : nbytes;
+                for (int i = 0; i < 6; i++) (void)vread(loc);
+                while (loc < end) {
+                    const uint8_t hd = s[loc++];
+                    const uint64_t code = (hd >> 5) & 7, prefix = hd & 0x1F;
+                    const uint64_t len = prefix < 31 ? prefix + 1 : 32 + vread(loc);
+                    lit_runs[b].push_back((code << 56) | (len & ((1ull << 56) - 1)));
+                }
+            }
+        }
         enc_bytes = (double)nbytes;
     } else { // FastLocate::load src/r-index.cpp:395-402 ; Run_blocks::load r-index.hpp:280-290
         encoded = false;
@@ -309,6 +333,33 @@ static void put_block(std::vector<uint8_t> &blocks, const uint64_t c6[6], const 
     }
     const uint8_t *p = reinterpret_cast<const uint8_t *>(dw);
     blocks.insert(blocks.end(), p, p + PGX_BLOCK_BYTES);
+}
+
+// literal count image (quirk 3; pgx_device.h PgxLitImage): the reference's own 10-run blocks with their true cumulative
+// counts (nuc order; N forced to 0, src/r-index.cpp:80) and the runs its late-starting scan sees
+void build_literal_image(const RiFile &ri, LitHostImage &m) {
+    if (m.built) return;
+    const uint64_t nb = ri.lit_runs.size();
+    m.bstart = ri.blocks_start_pos.ones;
+    m.cum.assign(nb * 6, 0);
+    m.roff.assign(nb + 1, 0);
+    m.runs.clear();
+    static const int slot_of_nuc[6] = {0, 1, 2, 3, -1, 4}; // \n A C G (N) T in sym_map order of a no-N index
+    for (uint64_t b = 0; b < nb; b++) {
+        for (int i = 0; i < 6; i++)
+            if (slot_of_nuc[i] >= 0 && (size_t)slot_of_nuc[i] < ri.blocks[b].cum.size()) m.cum[b * 6 + i] = ri.blocks[b].cum[slot_of_nuc[i]];
+        m.runs.insert(m.runs.end(), ri.lit_runs[b].begin(), ri.lit_runs[b].end());
+        if (m.runs.size() >> 32) throw Error(PGX_ERR_UNSUPPORTED, "literal count image: too many runs");
+        m.roff[b + 1] = (uint32_t)m.runs.size();
+    }
+    for (int c = 0; c < 256; c++) {
+        const int code = code_of_byte((uint8_t)c);
+        m.code_of[c] = code < 0 ? 0u : (uint32_t)code; // symbol_to_code (r-index.hpp:664-668): unknown -> 0
+        m.cslot_of[c] = ri.sym_map[c];
+    }
+    for (int i = 0; i < 8; i++) m.C[i] = i < (int)ri.C.size() ? ri.C[i] : 0;
+    if (m.runs.empty()) m.runs.push_back(0);
+    m.built = true;
 }
 
 // dense image: 64 symbols per 64-byte block as three bit planes under the usual count header (pgx_image.h)
@@ -789,6 +840,16 @@ extern "C" pgx_status pgx_index_image_view(const pgx_index *h, int which, const 
     case 6: *ptr = &m.consts; *bytes = sizeof(PgxConsts); break;
     case 7: *ptr = m.blow.data(); *bytes = m.blow.size() * 2; break;
     case 15: *ptr = m.exc.data(); *bytes = m.exc.size() * 4; break;
+    case 16: case 17: case 18: case 19: {
+        if (!(h->ri.encoded && !h->ri.hasN)) throw Error(PGX_ERR_ARG, "pgx_index_image_view: the literal count image exists for encoded indexes without N only");
+        pgx::LitHostImage &l = const_cast<pgx_index *>(h)->lit;
+        build_literal_image(h->ri, l);
+        if (which == 16) { *ptr = l.bstart.data(); *bytes = l.bstart.size() * 8; }
+        else if (which == 17) { *ptr = l.cum.data(); *bytes = l.cum.size() * 8; }
+        else if (which == 18) { *ptr = l.runs.data(); *bytes = l.runs.size() * 8; }
+        else { *ptr = l.roff.data(); *bytes = l.roff.size() * 4; }
+        break;
+    }
     default: throw Error(PGX_ERR_ARG, "pgx_index_image_view: unknown view");
     }
     return PGX_OK;

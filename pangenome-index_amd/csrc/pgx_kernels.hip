@@ -1155,3 +1155,47 @@ pgx_fmf_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_
     }
     out[i] = r;
 }
+
+// ------------------------------------------------------------------------------------------
+// FastLocate::rankAt_encoded as the reference executes it on an encoded index without N (quirk 3, pgx_device.h PgxLitImage)
+__device__ __forceinline__ uint64_t pgx_lit_rank(const PgxLitImage &lit, uint64_t pos, uint32_t target) {
+    // predecessor: last block start <= pos (positions at or beyond the end fall into the last block)
+    uint64_t lo = 0, hi = lit.n_blocks; // bstart[0] = 0
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (lit.bstart[mid] <= pos) lo = mid; else hi = mid;
+    }
+    const uint64_t rel = pos - lit.bstart[lo];
+    uint64_t rank = 0, cur = 0;
+    for (uint32_t e = lit.roff[lo]; e < lit.roff[lo + 1]; e++) { // EncodedBlock::rank_of_code, src/r-index.cpp:114-131
+        const uint64_t u = lit.runs[e], len = u & ((1ull << 56) - 1);
+        if ((uint32_t)(u >> 56) == target) {
+            if (cur + len > rel) { rank += rel - cur; break; }
+            rank += len;
+        }
+        cur += len;
+        if (cur > rel) break;
+    }
+    return rank + lit.cum[lo * 6 + target];
+}
+__global__ void __launch_bounds__(256)
+pgx_lit_count_kernel(PgxLitImage lit, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets, const pgx_range *__restrict__ in,
+                     const uint8_t *__restrict__ sym, uint64_t n, pgx_range *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t lo, hi, len, base = 0;
+    if (in) { lo = in[i].first; hi = in[i].second; len = 1; }
+    else { lo = 0; hi = lit.n - 1; base = offsets[i]; len = offsets[i + 1] - base; }
+    for (uint64_t t = len; t > 0; t--) { // LF_encoded, src/r-index.cpp:689-711: no symbol is rejected, an empty range stays {1, 0}
+        const uint32_t byte = in ? sym[i] : reads[base + t - 1];
+        if (lo > hi) { lo = 1; hi = 0; continue; }
+        const uint32_t target = lit.code_of[byte];
+        const uint64_t f = pgx_lit_rank(lit, lo, target), inside = pgx_lit_rank(lit, hi + 1, target) - f;
+        if (inside == 0) { lo = 1; hi = 0; continue; }
+        lo = f + lit.C[lit.cslot_of[byte]];
+        hi = lo + inside - 1;
+    }
+    pgx_range r;
+    r.first = lo; r.second = hi;
+    out[i] = r;
+}

@@ -50,6 +50,9 @@ struct pgx_device_image {
     PgxDevImage img{};
     DevBuf blocks, dir, blow, consts, tstart, tvals, tdir, seed, exc;
     DevBuf rstart, rsamp, rdir, lpos, lnext, ldir; // locate image, uploaded on first use
+    DevBuf lit_bstart, lit_cum, lit_runs, lit_roff, lit_tabs; // literal count image (quirk 3), uploaded on first use
+    PgxLitImage lit{};
+    bool has_lit = false;
     PgxLocImage loc{};
     bool has_loc = false;
     size_t lds_bytes = 0; // dynamic LDS of the LDS-image kernels (0 = image stays in global memory)
@@ -61,6 +64,7 @@ void pgx_release_device_images(pgx_index *h) {
         if (hipSetDevice(d->device) == hipSuccess) {
             d->blocks.release(); d->dir.release(); d->blow.release(); d->consts.release();
             d->tstart.release(); d->tvals.release(); d->tdir.release(); d->seed.release(); d->exc.release();
+            d->lit_bstart.release(); d->lit_cum.release(); d->lit_runs.release(); d->lit_roff.release(); d->lit_tabs.release();
             d->rstart.release(); d->rsamp.release(); d->rdir.release(); d->lpos.release(); d->lnext.release(); d->ldir.release();
         }
         delete d;
@@ -151,6 +155,9 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
     h->dev[device] = d.release();
     return h->dev[device];
 }
+
+static bool literal_count(const pgx_index *h);
+static pgx_device_image *literal_image(pgx_index *h, int device);
 
 extern "C" pgx_status pgx_index_to_device(pgx_index *h, int device) {
     PGX_GUARD_BEGIN
@@ -609,8 +616,12 @@ extern "C" pgx_status pgx_merge_tags(const char *ri_path, const char *const *tag
     struct Stream { std::vector<uint64_t> st, vl; std::string err; };
     std::vector<Stream> streams(n_files);
     std::vector<std::thread> parsers;
+    for (uint32_t f = 0; f < n_files; f++)
+        if (!tag_paths[f]) throw Error(PGX_ERR_ARG, "pgx_merge_tags: null tag path"); // before any thread exists
+    // joins whatever was started, also when starting a later thread throws (a joinable std::thread must not be destroyed)
+    struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } joiner{parsers};
+    parsers.reserve(n_files);
     for (uint32_t f = 0; f < n_files; f++) {
-        if (!tag_paths[f]) throw Error(PGX_ERR_ARG, "pgx_merge_tags: null tag path");
         parsers.emplace_back([&streams, tag_paths, f]() {
             Stream &o = streams[f];
             try {
@@ -632,7 +643,6 @@ extern "C" pgx_status pgx_merge_tags(const char *ri_path, const char *const *tag
             } catch (const std::exception &e) { o.err = e.what(); }
         });
     }
-    struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } joiner{parsers};
     const uint64_t n = h->ri.sequence_size, tot = h->ri.C.size() > 1 ? h->ri.C[1] - h->ri.C[0] : 0;
     if (n_seq != tot) throw Error(PGX_ERR_ARG, "pgx_merge_tags: seq_to_file has " + std::to_string(n_seq) + " entries, the index holds " +
                                                    std::to_string(tot) + " sequences");
@@ -895,7 +905,9 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         kfn = kfn_wide;
         // 32-bit interval state for dense images of BWTs shorter than 2^30 (PGX_FM_NARROW=0 switches it off)
         const char *nv = std::getenv("PGX_FM_NARROW");
-        if (dense && img.n < (1ull << 30) && !(nv && nv[0] == '0'))
+        bool c_fits = true; // C[] comes straight from the file: a (corrupt) value beyond 2^32 must not be truncated by the 32-bit state
+        for (int i = 0; i < 8; i++) c_fits = c_fits && !(b->h->img.consts.C[i] >> 32);
+        if (dense && img.n < (1ull << 30) && c_fits && !(nv && nv[0] == '0'))
             kfn = in_lds ? (const void *)pgx_find_mems_kernel<true, 1, true, false>
                   : d2   ? (seeded ? (const void *)pgx_find_mems_kernel<false, 2, true, true> : (const void *)pgx_find_mems_kernel<false, 2, true, false>)
                          : (seeded ? (const void *)pgx_find_mems_kernel<false, 1, true, true> : (const void *)pgx_find_mems_kernel<false, 1, true, false>);
@@ -1197,10 +1209,8 @@ extern "C" pgx_status pgx_count_batch(pgx_index *h, int device, const uint8_t *r
     if (!h || !offsets || (n_reads && (!out || (!reads && offsets[n_reads] != offsets[0]))))
         throw Error(PGX_ERR_ARG, "pgx_count_batch: null argument");
     if (!h->has_rank) throw Error(PGX_ERR_ARG, "pgx_count_batch: index opened without an r-index");
-    if (!h->img.consts.count_supported)
-        throw Error(PGX_ERR_UNSUPPORTED, "count_encoded on an encoded index without N mis-parses block headers in the reference "
-                                         "(rankAt_encoded reads six cumulative varints); open the index in PGX_MODE_STRICT");
-    pgx_device_image *d = device_image(h, device);
+    const bool lit = literal_count(h);
+    pgx_device_image *d = lit ? literal_image(h, device) : device_image(h, device);
     if (!n_reads) return PGX_OK;
     DevBuf dr, doff, dout;
     try {
@@ -1213,7 +1223,10 @@ extern "C" pgx_status pgx_count_batch(pgx_index *h, int device, const uint8_t *r
         dr.ensure(bytes + 16); doff.ensure((n_reads + 1) * 8); dout.ensure(n_reads * sizeof(pgx_range));
         if (bytes) HIPCHECK(hipMemcpy(dr.p, reads + lo, bytes, hipMemcpyHostToDevice));
         HIPCHECK(hipMemcpy(doff.p, reb.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice));
-        if (d->lds_bytes)
+        if (lit)
+            hipLaunchKernelGGL(pgx_lit_count_kernel, dim3(grid_for(n_reads, 256)), dim3(256), 0, 0, d->lit, (const uint8_t *)dr.as<uint8_t>(),
+                               (const uint64_t *)doff.as<uint64_t>(), (const pgx_range *)nullptr, (const uint8_t *)nullptr, n_reads, dout.as<pgx_range>());
+        else if (d->lds_bytes)
             hipLaunchKernelGGL(pgx_count_kernel<true>, dim3(grid_for(n_reads, 256)), dim3(256), d->lds_bytes, 0, d->img, dr.as<uint8_t>(),
                                doff.as<uint64_t>(), n_reads, dout.as<pgx_range>());
         else
@@ -1225,6 +1238,31 @@ extern "C" pgx_status pgx_count_batch(pgx_index *h, int device, const uint8_t *r
     dr.release(); doff.release(); dout.release();
     return PGX_OK;
     PGX_GUARD_END
+}
+
+// COMPAT count_encoded / LF_encoded on an encoded index without N: the reference mis-parses every block (quirk 3); the literal
+// image reproduces what it computes
+static bool literal_count(const pgx_index *h) { return (h->mode & PGX_MODE_MASK) == PGX_MODE_COMPAT && h->ri.encoded && !h->ri.hasN; }
+static pgx_device_image *literal_image(pgx_index *h, int device) {
+    pgx_device_image *d = device_image(h, device);
+    std::lock_guard<std::mutex> lock(g_image_mutex);
+    if (d->has_lit) return d;
+    build_literal_image(h->ri, h->lit);
+    LitHostImage &m = h->lit;
+    upload(d->lit_bstart, m.bstart.data(), m.bstart.size() * 8);
+    upload(d->lit_cum, m.cum.data(), m.cum.size() * 8);
+    upload(d->lit_runs, m.runs.data(), m.runs.size() * 8);
+    upload(d->lit_roff, m.roff.data(), m.roff.size() * 4);
+    d->lit_tabs.ensure(512 * 4);
+    HIPCHECK(hipMemcpy(d->lit_tabs.p, m.code_of, 1024, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(d->lit_tabs.as<uint32_t>() + 256, m.cslot_of, 1024, hipMemcpyHostToDevice));
+    PgxLitImage &g = d->lit;
+    g.bstart = d->lit_bstart.as<uint64_t>(); g.cum = d->lit_cum.as<uint64_t>(); g.runs = d->lit_runs.as<uint64_t>();
+    g.roff = d->lit_roff.as<uint32_t>(); g.code_of = d->lit_tabs.as<uint32_t>(); g.cslot_of = d->lit_tabs.as<uint32_t>() + 256;
+    for (int i = 0; i < 8; i++) g.C[i] = m.C[i];
+    g.n = h->ri.sequence_size; g.n_blocks = m.bstart.size();
+    d->has_lit = true;
+    return d;
 }
 
 extern "C" pgx_status pgx_find_mems_function_batch(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
@@ -1273,17 +1311,19 @@ extern "C" pgx_status pgx_lf_batch(pgx_index *h, int device, const pgx_range *in
     PGX_GUARD_BEGIN
     if (!h || (n && (!in || !sym || !out))) throw Error(PGX_ERR_ARG, "pgx_lf_batch: null argument");
     if (!h->has_rank) throw Error(PGX_ERR_ARG, "pgx_lf_batch: index opened without an r-index");
-    if (!h->img.consts.count_supported)
-        throw Error(PGX_ERR_UNSUPPORTED, "LF_encoded on an encoded index without N mis-parses block headers in the reference "
-                                         "(rankAt_encoded reads six cumulative varints); open the index in PGX_MODE_STRICT");
-    pgx_device_image *d = device_image(h, device);
+    const bool lit = literal_count(h);
+    pgx_device_image *d = lit ? literal_image(h, device) : device_image(h, device);
     if (!n) return PGX_OK;
     DevBuf din, dsym, dout;
     try {
         din.ensure(n * sizeof(pgx_range)); dsym.ensure(n); dout.ensure(n * sizeof(pgx_range));
         HIPCHECK(hipMemcpy(din.p, in, n * sizeof(pgx_range), hipMemcpyHostToDevice));
         HIPCHECK(hipMemcpy(dsym.p, sym, n, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(pgx_lf_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, d->img, din.as<pgx_range>(), dsym.as<uint8_t>(), n, dout.as<pgx_range>());
+        if (lit)
+            hipLaunchKernelGGL(pgx_lit_count_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, d->lit, (const uint8_t *)nullptr, (const uint64_t *)nullptr,
+                               (const pgx_range *)din.as<pgx_range>(), (const uint8_t *)dsym.as<uint8_t>(), n, dout.as<pgx_range>());
+        else
+            hipLaunchKernelGGL(pgx_lf_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, d->img, din.as<pgx_range>(), dsym.as<uint8_t>(), n, dout.as<pgx_range>());
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipMemcpy(out, dout.p, n * sizeof(pgx_range), hipMemcpyDeviceToHost));
     } catch (...) { din.release(); dsym.release(); dout.release(); throw; }

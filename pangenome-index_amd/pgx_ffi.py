@@ -186,7 +186,8 @@ def convert_tags(in_path, out_path, compact=False):
 
 
 _VIEW_DTYPES = {0: np.uint8, 1: np.uint64, 2: np.uint64, 3: np.uint64, 4: np.uint64, 5: np.uint32, 6: np.uint8, 7: np.uint16,
-                8: np.uint64, 9: np.uint64, 10: np.uint32, 11: np.uint64, 12: np.uint64, 13: np.uint32, 14: np.uint8, 15: np.uint32}
+                8: np.uint64, 9: np.uint64, 10: np.uint32, 11: np.uint64, 12: np.uint64, 13: np.uint32, 14: np.uint8, 15: np.uint32,
+                16: np.uint64, 17: np.uint64, 18: np.uint64, 19: np.uint32}
 LOCATE_SEQ_IDS, LOCATE_UNIQUE = 1, 2
 NO_POSITION = 0xFFFFFFFFFFFFFFFF
 

@@ -28,11 +28,13 @@ lines[:, :150] = cat.reshape(n, 150)
 lines.tofile(path)
 print("reads file written", flush=True)
 exe = os.path.join(ROOT, "pangenome-index_amd", "find_mems")
-for dest in ("/dev/null", os.path.join(wd, "out.txt")):
-    t0 = time.time()
-    with open(dest, "wb") as out:
-        r = subprocess.run([exe, ri, tags, path, str(min_len), "1", "--quiet"], stdout=out, stderr=subprocess.PIPE)
-    dt = time.time() - t0
-    size = os.path.getsize(dest) if dest != "/dev/null" else 0
-    print("%s n=%d -> %s: %.2f s wall (%.2f M reads/s end to end), rc=%d, output %.1f MB" % (wl, n, dest, dt, n / dt / 1e6, r.returncode, size / 1e6))
-    print("   stderr tail:", r.stderr.decode().strip().split("\n")[-3:], flush=True)
+# the pipeline: 1 worker = upload, run, download and formatting of one batch after the other (the sum of the stages);
+# 3 workers on one device = the stages of consecutive batches overlap; two device slots = what --gpus 2 does on two GPUs
+for extra in (["--streams", "1", "--batch", "1048576"], ["--streams", "1"], ["--streams", "3"], ["--devices", "0,0", "--streams", "2"]):
+    for dest in ("/dev/null",):
+        t0 = time.time()
+        with open(dest, "wb") as out:
+            r = subprocess.run([exe, ri, tags, path, str(min_len), "1", "--quiet"] + extra, stdout=out, stderr=subprocess.PIPE)
+        dt = time.time() - t0
+        print("%s n=%d %s -> %s: %.2f s wall (%.2f M reads/s end to end), rc=%d" % (wl, n, " ".join(extra), dest, dt, n / dt / 1e6, r.returncode))
+        print("   stderr tail:", r.stderr.decode().strip().split("\n")[-2:], flush=True)

@@ -43,7 +43,7 @@ def _cases(workdir):
     """(ri path, text path, oracle mode/P mode pairs that must be supported)"""
     out = [(os.path.join(BT, "xy.ri"), os.path.join(BT, "contigs_xy"), [0, 1])]  # legacy fixture: COMPAT + STRICT
     enc, _ = W.build_index_from_rlbwt(os.path.join(BT, "contigs_xy.rl_bwt"), workdir, "cnt_xy_enc", with_tags=False)
-    out.append((enc, os.path.join(BT, "contigs_xy"), [1]))  # encoded without N: COMPAT unsupported (quirk 3)
+    out.append((enc, os.path.join(BT, "contigs_xy"), [1]))  # encoded without N: COMPAT goes through the literal image (quirk 3), see below
     text = os.path.join(workdir, "cnt_toy.txt")
     W.synth_pangenome_text(text, base_len=5000, n_hap=2, seed=3, n_runs=2, n_run_len=(20, 100))
     ri6, _, _ = W.build_index_from_text(text, workdir, "cnt_toy", with_tags=False)
@@ -71,13 +71,61 @@ def test_count_tables_cpu(workdir):
                         assert n == _count_truth(text, p), p
 
 
-def test_oracle_reproduces_quirk3(workdir):
-    """on an encoded index without N the reference's count_encoded is wrong-but-deterministic; the
-    oracle restates it literally, the product refuses COMPAT there"""
-    enc, _ = W.build_index_from_rlbwt(os.path.join(BT, "contigs_xy.rl_bwt"), workdir, "cnt_xy_enc2", with_tags=False)
-    e, legacy = O.RIndex(enc), O.RIndex(os.path.join(BT, "xy.ri"))
-    assert legacy.count("ACG") == (969, 988) and e.count("ACG", O.MODE_STRICT) == (969, 988)
-    assert e.count("ACG") != (969, 988)
+def _lit_rank(bstart, cum, runs, roff, pos, target):
+    """pgx_lit_rank (pgx_kernels.hip): the reference's rankAt_encoded on an encoded index without N"""
+    b = int(np.searchsorted(bstart, pos, side="right")) - 1
+    rel = pos - int(bstart[b])
+    rank = cur = 0
+    for e in range(int(roff[b]), int(roff[b + 1])):
+        u = int(runs[e])
+        code, ln = u >> 56, u & ((1 << 56) - 1)
+        if code == target:
+            if cur + ln > rel:
+                rank += rel - cur
+                break
+            rank += ln
+        cur += ln
+        if cur > rel:
+            break
+    return rank + int(cum[b * 6 + target])
+
+
+def test_quirk3_literal_image(workdir):
+    """on an encoded index without N the reference's count_encoded is wrong-but-deterministic (rankAt_encoded reads six
+    cumulative varints where five were written, so its run scan starts one varint late): the oracle restates it literally
+    and the product reproduces it from an image of the reference's blocks as that scan sees them (CPU tier: the image walked
+    like pgx_lit_count_kernel)"""
+    rng = np.random.default_rng(23)
+    for name, text_name in (("bidirectional_test/contigs_xy.rl_bwt", "bidirectional_test/contigs_xy"), ("x.rl_bwt", "x.newline_separated")):
+        enc, _ = W.build_index_from_rlbwt(os.path.join(G, name), workdir, "q3_" + os.path.basename(name), with_tags=False)
+        e = O.RIndex(enc)
+        if "contigs_xy" in name:
+            legacy = O.RIndex(os.path.join(BT, "xy.ri"))
+            assert legacy.count("ACG") == (969, 988) and e.count("ACG", O.MODE_STRICT) == (969, 988)
+            assert e.count("ACG") != (969, 988)
+        idx = P.Index(enc)
+        bstart, cum, runs, roff = (idx.image_view(w) for w in (16, 17, 18, 19))
+        assert len(cum) == 6 * len(bstart) and len(roff) == len(bstart) + 1 and bstart[0] == 0
+        C, sm, n = e.C_array(), e.sym_map(), e.n
+        text = open(os.path.join(G, text_name)).read()
+        for p in _patterns(text, rng, 150) + ["T", "TT", "N", "\x00A"]:
+            lo, hi = 0, n - 1
+            for ch in reversed(p.encode()):
+                if lo > hi:
+                    lo, hi = 1, 0
+                    continue
+                target = b"\nACGNT".find(bytes([ch]))
+                target = 0 if target < 0 else target
+                f = _lit_rank(bstart, cum, runs, roff, lo, target)
+                inside = _lit_rank(bstart, cum, runs, roff, hi + 1, target) - f
+                if inside == 0:
+                    lo, hi = 1, 0
+                    continue
+                lo = f + C[sm[ch]]
+                hi = lo + inside - 1
+            assert (lo, hi) == e.count(p), (name, p)
+    with pytest.raises(P.PgxError):  # the literal image exists for that one shape only
+        P.Index(os.path.join(BT, "xy.ri")).image_view(16)
 
 
 @pytest.mark.gpu
@@ -90,14 +138,16 @@ def test_count_batch_gpu(workdir):
         cat, offs = O.pack_reads(pats)
         for mode, force in ((0, 0), (1, 0), (0, P.MODE_IMAGE_RL), (1, P.MODE_IMAGE_RL)):
             idx = P.Index(ri_path, mode=mode | force)
-            if mode not in modes:
-                with pytest.raises(P.PgxError) as ex:
-                    idx.count_batch(cat, offs)
-                assert ex.value.code == P.ERR_UNSUPPORTED
-                continue
+            # (COMPAT on the encoded index without N: the literal image of quirk 3 answers, wrong-but-deterministic like the reference)
             got = idx.count_batch(cat, offs)
             for i, p in enumerate(pats):
                 assert (int(got[i][0]), int(got[i][1])) == ri.count(p, mode), (ri_path, mode, p)
+            # one LF step from random ranges
+            rg = np.sort(rng.integers(0, ri.n, (500, 2)), axis=1).astype(np.uint64)
+            sy = np.frombuffer(b"ACGTN\n$a", dtype=np.uint8)[rng.integers(0, 8, 500)]
+            lf = idx.lf_batch(rg, sy)
+            for q in range(500):
+                assert (int(lf[q][0]), int(lf[q][1])) == ri.LF((int(rg[q][0]), int(rg[q][1])), int(sy[q]), mode), (ri_path, mode, q)
 
 
 @pytest.mark.gpu
