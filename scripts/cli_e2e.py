@@ -7,7 +7,7 @@ import numpy as np
 import pgx_workload as W
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "x"
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 4_000_000
 wd = "/tmp/pgx_cli_e2e"
 os.makedirs(wd, exist_ok=True)
 if wl == "x":
