@@ -161,6 +161,18 @@ pgx_status pgx_convert_tags(const char *in_path, const char *out_path, int compa
 pgx_status pgx_merge_tags(const char *ri_path, const char *const *tag_paths, uint32_t n_files, const uint32_t *seq_to_file,
                           uint64_t n_seq, int device, const char *out_path);
 
+/* What merge_tags asks the graph (src/merge_tags.cpp:443-445,478-515; include/pangenome_index/algorithm.hpp:600-619): for every
+ * GBWT sequence of the GBZ the graph node id of its first node (gbz.index.extract(i)[0]; 0 for an empty path) and that node's
+ * weakly connected component (numbered by smallest node id), plus the graph's largest node id and component count.  Reads only
+ * the GBWT's node records of the file (simple-sds layout).  first_node / component may be NULL; at most cap entries are written. */
+pgx_status pgx_gbz_paths(const char *gbz_path, uint64_t *n_sequences, uint64_t *first_node, uint32_t *component, uint64_t cap,
+                         uint64_t *max_node_id, uint32_t *n_components);
+/* merge_tags with the reference's own inputs: graph.gbz, whole-genome r-index, per-chromosome tag files.  Sequence s belongs
+ * to the tag file whose first tag lies in the component of the first node of path s (merge_tags.cpp:478-515); the item width
+ * of the output comes from the graph's largest node id (:627-638).  Otherwise as pgx_merge_tags. */
+pgx_status pgx_merge_tags_gbz(const char *gbz_path, const char *ri_path, const char *const *tag_paths, uint32_t n_files, int device,
+                              const char *out_path);
+
 /* ---- primitives (tests; mirror the public FastLocate / TagArray query API) ----------------- */
 /* FastLocate::rank_at_cached_encoded (src/r-index.cpp:619-641): out[i*6 .. i*6+sigma) per position;
  * entries >= sigma are zero.  true_codes!=0 returns the six true code ranks instead. */

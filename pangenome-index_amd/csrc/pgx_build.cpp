@@ -433,12 +433,12 @@ extern "C" pgx_status pgx_build_index_from_text(const char *text_path, const cha
 }
 
 // ------------------------------------------------------------------------------------------
-extern "C" pgx_status pgx_write_compact_tags(const char *out_path, const uint64_t *values, const uint64_t *lengths, uint64_t n_runs) {
-    PGX_GUARD_BEGIN
-    if (!out_path || (n_runs && (!values || !lengths))) throw Error(PGX_ERR_ARG, "pgx_write_compact_tags: null argument");
+namespace pgx {
+// max_node_floor: the item width covers at least this node id (merge_tags takes the graph's largest id, merge_tags.cpp:627-638)
+void write_compact_tags(const char *out_path, const uint64_t *values, const uint64_t *lengths, uint64_t n_runs, uint64_t max_node_floor) {
     std::vector<uint64_t> items;
     SdVector starts, intervals;
-    uint64_t bwt_pos = 0, max_node = 0;
+    uint64_t bwt_pos = 0, max_node = max_node_floor;
     auto emit = [&](uint64_t v, uint64_t len) {
         intervals.ones.push_back(bwt_pos);
         bwt_pos += len;
@@ -459,6 +459,13 @@ extern "C" pgx_status pgx_write_compact_tags(const char *out_path, const uint64_
     starts.write(out);
     intervals.write(out);
     write_whole_file(out_path, out);
+}
+} // namespace pgx
+
+extern "C" pgx_status pgx_write_compact_tags(const char *out_path, const uint64_t *values, const uint64_t *lengths, uint64_t n_runs) {
+    PGX_GUARD_BEGIN
+    if (!out_path || (n_runs && (!values || !lengths))) throw Error(PGX_ERR_ARG, "pgx_write_compact_tags: null argument");
+    write_compact_tags(out_path, values, lengths, n_runs, 0);
     return PGX_OK;
     PGX_GUARD_END
 }

@@ -106,6 +106,16 @@ struct TagFile { // TagArray as stored (src/tag_arrays.cpp:739-776)
     void parse(const uint8_t *p, uint64_t n, uint32_t format_hint);
 };
 
+// what merge_tags takes from the graph (pgx_gbz.cpp)
+struct GbzPaths {
+    std::vector<uint64_t> first_node;        // per GBWT sequence: graph node id of its first node (0 = empty path)
+    std::vector<uint32_t> component_of_node; // by node id; ~0u for ids that do not occur
+    uint32_t n_components = 0;
+    uint64_t max_node_id = 0;
+};
+void parse_gbz_paths(const std::string &path, GbzPaths &g);
+void write_compact_tags(const char *out_path, const uint64_t *values, const uint64_t *lengths, uint64_t n_runs, uint64_t max_node_floor);
+
 std::vector<uint8_t> read_whole_file(const std::string &path);
 void write_whole_file(const std::string &path, const std::vector<uint8_t> &bytes);
 

@@ -595,9 +595,8 @@ extern "C" pgx_status pgx_decompress_sa(pgx_index *h, int device, uint32_t flags
 
 // ------------------------------------------------------------------------------------------
 // merge_tags (pgx_merge_kernels.hip)
-extern "C" pgx_status pgx_merge_tags(const char *ri_path, const char *const *tag_paths, uint32_t n_files, const uint32_t *seq_to_file,
-                                     uint64_t n_seq, int device, const char *out_path) {
-    PGX_GUARD_BEGIN
+static void merge_tags_core(const char *ri_path, const char *const *tag_paths, uint32_t n_files, const uint32_t *seq_to_file, uint64_t n_seq,
+                            int device, const char *out_path, uint64_t max_node_floor) {
     if (!ri_path || !tag_paths || !seq_to_file || !out_path) throw Error(PGX_ERR_ARG, "pgx_merge_tags: null argument");
     if (n_files == 0 || n_files > 250) throw Error(PGX_ERR_ARG, "pgx_merge_tags: between 1 and 250 tag files");
     // only the locate side of the index is needed: parse the file, no rank image
@@ -715,7 +714,60 @@ extern "C" pgx_status pgx_merge_tags(const char *ri_path, const char *const *tag
         throw;
     }
     for (DevBuf *b : all) b->release();
-    return pgx_write_compact_tags(out_path, h_val.data(), h_start.data(), h_val.size());
+    write_compact_tags(out_path, h_val.data(), h_start.data(), h_val.size(), max_node_floor);
+}
+
+extern "C" pgx_status pgx_merge_tags(const char *ri_path, const char *const *tag_paths, uint32_t n_files, const uint32_t *seq_to_file,
+                                     uint64_t n_seq, int device, const char *out_path) {
+    PGX_GUARD_BEGIN
+    merge_tags_core(ri_path, tag_paths, n_files, seq_to_file, n_seq, device, out_path, 0);
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+// first tag of a per-chromosome stream (FileReader::get_first_tag, src/merge_tags.cpp:205-232): its node id
+static uint64_t first_tag_node(const char *path) {
+    std::vector<uint8_t> raw = read_whole_file(path);
+    uint64_t loc = 0;
+    if (raw.size() >= 8) { // int_vector<8> header (bit count) of sdsl::int_vector_buffer<8>
+        uint64_t bits = 0;
+        std::memcpy(&bits, raw.data(), 8);
+        if (bits == (raw.size() - 8) * 8) loc = 8;
+    }
+    if (loc >= raw.size()) throw Error(PGX_ERR_FORMAT, std::string(path) + ": empty tag file");
+    const uint64_t v = bytecode_read(raw.data(), raw.size(), loc, "tag run");
+    return v >> 20; // offset:10 | rev:1 | len:9 | node << 20 (encode_run_length, src/tag_arrays.cpp:28-36)
+}
+
+extern "C" pgx_status pgx_merge_tags_gbz(const char *gbz_path, const char *ri_path, const char *const *tag_paths, uint32_t n_files, int device,
+                                         const char *out_path) {
+    PGX_GUARD_BEGIN
+    if (!gbz_path || !ri_path || !tag_paths || !out_path || !n_files) throw Error(PGX_ERR_ARG, "pgx_merge_tags_gbz: null argument");
+    GbzPaths g;
+    try { parse_gbz_paths(gbz_path, g); }
+    catch (const Error &e) { if (e.code == PGX_ERR_IO) throw Error(PGX_ERR_IO, std::string("Cannot open graph: ") + gbz_path); throw; }
+    // component -> file: the component of the first tag's node of every file (merge_tags.cpp:481-490)
+    std::vector<uint32_t> comp_to_file(g.n_components, ~0u);
+    for (uint32_t f = 0; f < n_files; f++) {
+        if (!tag_paths[f]) throw Error(PGX_ERR_ARG, "pgx_merge_tags_gbz: null tag path");
+        const uint64_t node = first_tag_node(tag_paths[f]);
+        // a node the graph does not have (0: a stream that opens with a gap run) lands in component 0 like the reference's
+        // node_to_comp_map[...] (std::unordered_map::operator[] default-inserts 0, merge_tags.cpp:489)
+        const uint32_t c = (node < g.component_of_node.size() && g.component_of_node[node] != ~0u) ? g.component_of_node[node] : 0u;
+        if (c >= g.n_components) throw Error(PGX_ERR_FORMAT, "pgx_merge_tags_gbz: the graph has no component");
+        if (comp_to_file[c] != ~0u) throw Error(PGX_ERR_FORMAT, std::string(tag_paths[f]) + ": a second tag file for the same graph component");
+        comp_to_file[c] = f;
+    }
+    std::vector<uint32_t> s2f(g.first_node.size());
+    for (uint64_t sq = 0; sq < s2f.size(); sq++) {
+        const uint64_t node = g.first_node[sq];
+        const uint32_t c = node ? g.component_of_node[node] : ~0u;
+        if (c == ~0u || comp_to_file[c] == ~0u)
+            throw Error(PGX_ERR_FORMAT, "path " + std::to_string(sq) + " of the graph starts in a component without a tag file");
+        s2f[sq] = comp_to_file[c];
+    }
+    merge_tags_core(ri_path, tag_paths, n_files, s2f.data(), s2f.size(), device, out_path, g.max_node_id);
+    return PGX_OK;
     PGX_GUARD_END
 }
 

@@ -112,6 +112,8 @@ def lib():
     L.pgx_write_compact_tags.argtypes = [C.c_char_p, p, p, u64]
     L.pgx_convert_tags.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     L.pgx_merge_tags.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), u32, p, u64, C.c_int, C.c_char_p]
+    L.pgx_gbz_paths.argtypes = [C.c_char_p, C.POINTER(u64), p, p, u64, C.POINTER(u64), C.POINTER(u32)]
+    L.pgx_merge_tags_gbz.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, C.c_int, C.c_char_p]
     L.pgx_rank_batch.argtypes = [p, C.c_int, p, u64, C.c_int, p]
     L.pgx_extend_batch.argtypes = [p, C.c_int, p, p, p, u64, p]
     L.pgx_count_batch.argtypes = [p, C.c_int, p, p, u64, p]
@@ -198,6 +200,22 @@ def merge_tags(ri_path, tag_paths, seq_to_file, out_path, device=0):
     s2f = np.ascontiguousarray(seq_to_file, dtype=np.uint32)
     arr = (C.c_char_p * len(tag_paths))(*[t.encode() for t in tag_paths])
     _check(lib().pgx_merge_tags(ri_path.encode(), arr, len(tag_paths), s2f.ctypes.data, len(s2f), device, out_path.encode()))
+
+
+def gbz_paths(gbz_path):
+    """(first node id per GBWT sequence, its component, max node id, number of components) of a GBZ graph"""
+    n, mx, nc = u64(0), u64(0), u32(0)
+    _check(lib().pgx_gbz_paths(gbz_path.encode(), C.byref(n), None, None, 0, C.byref(mx), C.byref(nc)))
+    first = np.zeros(n.value, dtype=np.uint64)
+    comp = np.zeros(n.value, dtype=np.uint32)
+    _check(lib().pgx_gbz_paths(gbz_path.encode(), C.byref(n), first.ctypes.data, comp.ctypes.data, n.value, C.byref(mx), C.byref(nc)))
+    return first, comp, mx.value, nc.value
+
+
+def merge_tags_gbz(gbz_path, ri_path, tag_paths, out_path, device=0):
+    """merge_tags with the reference's inputs: the sequence -> tag file map comes from the graph"""
+    arr = (C.c_char_p * len(tag_paths))(*[t.encode() for t in tag_paths])
+    _check(lib().pgx_merge_tags_gbz(gbz_path.encode(), ri_path.encode(), arr, len(tag_paths), device, out_path.encode()))
 
 
 class Index:

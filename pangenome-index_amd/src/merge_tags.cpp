@@ -1,15 +1,23 @@
-// merge_tags -- the reference CLI (src/merge_tags.cpp:434-869) on MI355X, with the sequence -> tag file map stated by the
-// caller instead of being derived from a GBZ (a GBZ reader is out of scope; see include/pgx.h, pgx_merge_tags):
+// merge_tags -- the reference CLI (src/merge_tags.cpp:434-869) on MI355X.
 //
-//   merge_tags <seq_map.txt> <whole_genome.ri> <tag_dir> [--out FILE] [--device N]
+//   merge_tags <graph.gbz> <whole_genome.ri> <tag_dir> [--out FILE] [--device N]      the reference's argument list (:443-445)
+//   merge_tags <seq_map.txt | --counts ...> <whole_genome.ri> <tag_dir> [...]          the sequence -> tag file map stated directly
+//
+// With a GBZ (recognised by its "GBZ " tag) the map is derived like the reference does: first node of path s -> weakly connected
+// component -> the file of <tag_dir> whose first tag lies in that component (pgx_merge_tags_gbz; every regular file of the
+// directory is a tag file, like get_files_in_dir :408-426).  Otherwise:
 //
 // seq_map.txt: one line per sequence of the whole-genome r-index, in sequence order: the name of the per-chromosome tag
 // file (inside <tag_dir>) that holds the tags of that sequence.  "--counts f0:n0,f1:n1,..." replaces the file when the
 // sequences are grouped (the first n0 sequences belong to f0, the next n1 to f1, ...), which is what concatenating
 // per-chromosome texts gives.  Output: whole_genome_tag_array_compressed.tags (merge_tags.cpp:541), sdsl-compact format.
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
+#include <dirent.h>
 #include <fstream>
+#include <sys/stat.h>
 #include <iostream>
 #include <map>
 #include <string>
@@ -19,8 +27,46 @@
 
 int main(int argc, char **argv) {
     if (argc < 4) {
-        std::cerr << "usage: merge_tags <seq_map.txt | --counts f0:n0,f1:n1,...> <whole_genome.ri> <tag_dir> [--out FILE] [--device N]" << std::endl;
+        std::cerr << "usage: merge_tags <graph.gbz | seq_map.txt | --counts f0:n0,f1:n1,...> <whole_genome.ri> <tag_dir> [--out FILE] [--device N]" << std::endl;
         return EXIT_FAILURE;
+    }
+    {   // the reference's argv: <graph.gbz> <r_index> <tag_dir>
+        char tag4[4] = {0, 0, 0, 0};
+        std::ifstream probe(argv[1], std::ios::binary);
+        if (probe && probe.read(tag4, 4) && std::memcmp(tag4, "GBZ ", 4) == 0) {
+            const std::string ri = argv[2], dir = argv[3];
+            std::string out = "whole_genome_tag_array_compressed.tags"; // written into the working directory (:538)
+            int device = 0;
+            for (int i = 4; i < argc; i++) {
+                const std::string o = argv[i];
+                if (o == "--out" && i + 1 < argc) out = argv[++i];
+                else if (o == "--device" && i + 1 < argc) device = std::stoi(argv[++i]);
+                else { std::cerr << "unknown option " << o << std::endl; return EXIT_FAILURE; }
+            }
+            std::cerr << "Loading the graph file" << std::endl;            // :449
+            std::cerr << "Getting the lists of tag files" << std::endl;    // :452
+            std::vector<std::string> files;
+            if (DIR *d = opendir(dir.c_str())) {
+                while (dirent *e = readdir(d)) {
+                    const std::string p = dir + "/" + e->d_name;
+                    struct stat st;
+                    if (stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode)) files.push_back(p);
+                }
+                closedir(d);
+            } else { std::cerr << "Cannot open tag directory: " << dir << std::endl; return EXIT_FAILURE; }
+            std::sort(files.begin(), files.end());
+            std::cerr << "The list of files are: " << std::endl;          // :459
+            std::vector<const char *> cp;
+            for (auto &p : files) { std::cerr << p << std::endl; cp.push_back(p.c_str()); }
+            std::cerr << "Reading the whole genome r-index file (encoded)" << std::endl; // :465
+            std::cerr << "Finding the node to component mapping" << std::endl;           // :477
+            if (pgx_merge_tags_gbz(argv[1], ri.c_str(), cp.data(), (uint32_t)cp.size(), device, out.c_str()) != PGX_OK) {
+                std::cerr << pgx_last_error() << std::endl;
+                return EXIT_FAILURE;
+            }
+            std::cerr << "Index files merged and ready to use!" << std::endl; // :855
+            return 0;
+        }
     }
     int a = 1;
     std::vector<std::string> seq_file; // per sequence: tag file name
