@@ -486,7 +486,7 @@ pgx_seed_build_kernel(PgxDevImage img, const uint4 *__restrict__ src, uint4 *__r
 // selects and adds of the loop.  Sound because every true value is < 2^32 there; the junk coordinates the COMPAT quirks can
 // produce are caught at the two additions that could wrap (counter slot 9 is raised and the host repeats the chunk in 64 bits).
 template <bool LDS_IMAGE, int DENSE, bool NARROW, bool SEED>
-__global__ void __launch_bounds__(PGX_FM_THREADS, PGX_FM_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(PGX_FM_THREADS, DENSE == 0 ? 3 : PGX_FM_WAVES_PER_SIMD) // the run-length decode does not fit 128 VGPRs without spilling
 pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                      uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
                      pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
@@ -514,7 +514,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     uint64_t win = 0, win_hi = 0, win2 = 0, win3 = 0, win_at = ~0ull;
     pos_t A0 = 0, B0 = 0;             // first-probe sums of an extension whose second probe is pending
     bool pend = false;
-    bool fresh = false;              // SEED: the interval is the full one and a backward stage is about to start (the seed table may apply)
+    uint32_t fresh = 0;              // (a 32-bit flag: as a bool captured by the lambdas below it ended up in scratch memory) SEED: the interval is the full one and a backward stage is about to start (the seed table may apply)
     bool ovf = false;                // NARROW: some addition left 32 bits (reported once, when the wave leaves)
     uint64_t rnext = 0, rend = 0;    // wave-uniform reservoir of read ids
     bool exhausted = false;          // wave-uniform: the global cursor has passed n_reads
@@ -523,7 +523,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
 #endif
 
     // begin(x): entry of find_mems_function; finishing a read records its MEM count
-    auto begin = [&]() {
+    auto begin = [&]() __attribute__((always_inline)) {
         if (x >= len || (uint64_t)(len - x) < min_len) { ph = 0; mem_count[rid] = nm; return; } // :745 / :658
         if (heavy_ext && next - next0 >= heavy_ext && len <= (int32_t)PGX_FM_HEAVY_MAXLEN) { // hand the rest of a heavy read on
             const unsigned long long at = atomicAdd(heavy_count, 1ull);
@@ -540,20 +540,25 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
             Jk = 0; Js = n; j = x; ph = 2;
         } else {
             j = x + (int32_t)min_len - 1; ph = 1;
-            fresh = true;
+            fresh = 1u;
         }
     };
     // the state machine below funnels every "next start position" through one begin() (the lambda is inlined per call site)
-    bool restart = false;
+    uint32_t restart = 0;
     // emit the MEM [x, e) and set up step 3
-    auto emit = [&]() {
+    auto emit = [&]() __attribute__((always_inline)) {
         pgx_mem m;
         m.start = (uint64_t)x; m.end = (uint64_t)j; m.bwt_start = (uint64_t)Jk; m.size = (int64_t)(uint64_t)Js; // e == j at every emit
         slots[slot + nm] = m;
         nm++;
         k = 0; kp = 0; s = n;
-        if (j > x) { ph = 3; fresh = true; }
-        else { x = x + 1; restart = true; } // loop of :722 runs zero times, returns j + 1
+        // (as selects: an if / else that stores 1 into one of two flags is turned into ONE store through a selected address,
+        //  which puts both flags into scratch memory)
+        const bool more = j > x; // otherwise the loop of :722 runs zero times and the function returns j + 1
+        ph = more ? 3 : ph;
+        fresh = more ? 1u : fresh;
+        x = more ? x : x + 1;
+        restart = more ? restart : 1u;
     };
 
     for (;;) {
@@ -619,7 +624,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                         if (pgx_seed_index(lo, hi, (uint32_t)K, sidx)) { seed_lane = true; sp = img.seed + sidx; }
                     }
                 }
-                fresh = false;
+                fresh = 0u;
                 se = *sp; // lanes without a seed read entry 0 (one cached line for all of them)
             }
             uint32_t byte = 0u; // pattern[len] reads as 0 (quirk 4)
@@ -750,7 +755,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                 const int32_t jn = adv ? (p1 ? (at_x ? x + (int32_t)min_len : j - 1) : (p2 ? j + 1 : j - 1)) : j;
                 const bool em = (p2 && (small || jn >= len)) || (to2 && jn >= len);
                 const bool rs_small = small && !p2, rs_end = !p1 && !p2 && adv && jn <= x;
-                restart = rs_small || rs_end;
+                restart = (rs_small || rs_end) ? 1u : 0u;
                 x = rs_small ? j + 1 : (rs_end ? x + 1 : x);
                 ph = to2 ? 2 : ph;
                 j = jn;
