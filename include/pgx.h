@@ -259,6 +259,8 @@ pgx_status pgx_batch_create(pgx_index *h, int device, const uint8_t *reads, cons
  * batch costs no allocation per call).  Invalidates the results of the previous run. */
 pgx_status pgx_batch_upload(pgx_batch *b, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads);
 /* Run find_all_mems (+ tag queries) for every read of the batch; results stay on the device.
+ * (A run whose predecessor on this batch had the same shape is enqueued whole, with buffer sizes taken from that run and the
+ * counts kept on the device, and synchronises once at the end: pgx_batch_spec_stats.)
  * `stream` is a hipStream_t; NULL = the batch's own non-blocking stream (every batch has one: its uploads and downloads
  * use it too, so batches driven by different host threads overlap on one device -- upload of one, kernels of another,
  * download of a third).  Asynchronous except for the few scalar read-backs that size intermediate buffers; complete
@@ -281,6 +283,10 @@ pgx_status pgx_batch_device_result(pgx_batch *b, pgx_device_result *out);
 /* Device-side totals of the last run without downloading arrays */
 pgx_status pgx_batch_counts(pgx_batch *b, uint64_t *n_mems, uint64_t *n_positions, uint64_t *n_extensions);
 pgx_status pgx_batch_timing(pgx_batch *b, pgx_timing *out);
+/* Runs of this batch that were sized speculatively (from the totals of the previous run with the same number of reads and the
+ * same parameters: no mid-run read-back, one synchronisation at the end), and how many of those had to be repeated with exact
+ * sizes because a capacity was too small.  Results never depend on it; PGX_SPEC=0 in the environment switches it off. */
+pgx_status pgx_batch_spec_stats(pgx_batch *b, uint32_t *speculative_runs, uint32_t *fallbacks);
 void pgx_batch_free(pgx_batch *b);
 
 /* Convenience: create + run + result in one call (what the find_mems CLI uses). */

@@ -71,42 +71,47 @@ __global__ void pgx_count_kernel(PgxDevImage img, const uint8_t *reads, const ui
 __global__ void pgx_fmf_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, const uint64_t *read_of, const uint64_t *xs, uint64_t n,
                                uint64_t min_len, uint64_t min_occ, PgxHeavyResult *out);
 __global__ void pgx_lf_kernel(PgxDevImage img, const pgx_range *in, const uint8_t *sym, uint64_t n, pgx_range *out);
-__global__ void pgx_scan_partial_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, uint64_t *block_sums);
+// n_dev (may be NULL): the element count lives on the device, `n` is then the capacity the launch was sized for
+__global__ void pgx_scan_partial_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, uint64_t *block_sums, const uint64_t *n_dev);
 __global__ void pgx_scan_sums_kernel(uint64_t *block_sums, uint64_t nb);
 __global__ void pgx_scan_apply_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, const uint64_t *block_sums,
-                                      uint64_t nb, uint64_t *out, uint64_t *total_out, int raw_sums);
+                                      uint64_t nb, uint64_t *out, uint64_t *total_out, int raw_sums, const uint64_t *n_dev);
 __global__ void pgx_compact_mems_kernel(uint64_t first_read, uint64_t n_reads, const uint64_t *slot_off, uint64_t slot_base,
                                         const pgx_mem *slots, const uint32_t *mem_count, const uint64_t *local_off,
-                                        uint64_t mem_base, pgx_mem *mems);
+                                        uint64_t mem_base, pgx_mem *mems, uint64_t cap_mems, uint64_t *abort);
 #define PGX_TAG_LOCATE_THREADS 1024 // workgroup of pgx_tag_locate_kernel (one list atomic per workgroup)
 #define PGX_SORT_LDS_CAP 2048 // values per wave sorted in an LDS slice (pgx_tag_sort_unique_kernel)
 #define PGX_TAG_SMALL 16      // queries with at most this many runs take the 16-lane path
 #define PGX_SORT_WG_LDS_CAP 16384 // values one workgroup sorts in (dynamic) LDS (pgx_tag_sort_large_kernel)
 
+// every kernel of the tag stage: (count as a value = capacity, device pointer to the actual count or NULL, abort flag or NULL)
 __global__ void pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *mems, const uint64_t *qstart, const uint64_t *qend,
-                                      uint64_t n, uint64_t *run_nums, uint64_t *first_item, uint64_t *need, uint64_t *big_list,
-                                      unsigned long long *n_big, unsigned long long *n_large, uint64_t *single, uint64_t *ucount,
-                                      unsigned long long *n_overflow, uint64_t *small_list, unsigned long long *n_small);
-__global__ void pgx_tag_small_kernel(PgxDevImage img, const uint64_t *list, uint64_t n, const uint64_t *run_nums, const uint64_t *first_item,
-                                     const uint64_t *seg_off, uint64_t *buf, uint64_t *ucount, unsigned long long *n_overflow);
-__global__ void pgx_tag_gather_kernel(PgxDevImage img, const uint64_t *list, uint64_t n_list, const uint64_t *run_nums,
-                                      const uint64_t *first_item, const uint64_t *seg_off, uint64_t *buf,
+                                      uint64_t n, const uint64_t *n_dev, const uint64_t *abort, uint64_t *run_nums, uint64_t *first_item, uint64_t *need,
+                                      uint64_t *big_list, uint64_t *large_list, unsigned long long *n_big, unsigned long long *n_large, uint64_t *single,
+                                      uint64_t *ucount, unsigned long long *n_overflow, uint64_t *small_list, unsigned long long *n_small);
+__global__ void pgx_tag_small_kernel(PgxDevImage img, const uint64_t *list, uint64_t n, const uint64_t *n_dev, const uint64_t *abort, const uint64_t *run_nums,
+                                     const uint64_t *first_item, const uint64_t *seg_off, uint64_t *buf, uint64_t *ucount, unsigned long long *n_overflow);
+__global__ void pgx_tag_gather_kernel(PgxDevImage img, const uint64_t *list, uint64_t n_list, const uint64_t *n_dev, const uint64_t *abort,
+                                      const uint64_t *run_nums, const uint64_t *first_item, const uint64_t *seg_off, uint64_t *buf,
                                       unsigned long long *n_overflow);
-__global__ void pgx_tag_sort_unique_kernel(const uint64_t *list, uint64_t n_list, const uint64_t *run_nums, const uint64_t *seg_off,
-                                           uint64_t *buf, uint64_t *ucount);
-__global__ void pgx_tag_sort_large_kernel(const uint64_t *list, uint64_t n_list, const uint64_t *run_nums, const uint64_t *seg_off,
-                                          uint64_t *buf, uint64_t *scratch, const uint64_t *scratch_off, uint64_t *ucount);
-__global__ void pgx_tag_list_fetch_kernel(const uint64_t *list, uint64_t n_list, const uint64_t *first_item, const uint64_t *run_nums,
-                                          uint64_t *out);
-__global__ void pgx_tag_copy_dups_kernel(const uint64_t *pairs, uint64_t n_pairs, uint64_t n_tag_items, const uint64_t *first_item,
-                                         const uint64_t *run_nums, const uint64_t *seg_off, uint64_t *buf, uint64_t *ucount,
+__global__ void pgx_tag_sort_unique_kernel(const uint64_t *list, uint64_t n_list, const uint64_t *n_dev, const uint64_t *abort, const uint64_t *run_nums,
+                                           const uint64_t *seg_off, uint64_t *buf, uint64_t *ucount);
+__global__ void pgx_tag_sort_large_kernel(const uint64_t *list, uint64_t n_list, const uint64_t *n_dev, const uint64_t *abort, const uint64_t *run_nums,
+                                          const uint64_t *seg_off, uint64_t *buf, uint64_t *scratch, const uint64_t *scratch_off, uint64_t *ucount);
+__global__ void pgx_tag_dedup_kernel(const uint64_t *list, uint64_t n_list, const uint64_t *n_dev, const uint64_t *abort, const uint64_t *first_item,
+                                     const uint64_t *run_nums, unsigned long long *table, uint64_t table_mask, uint64_t *reps, unsigned long long *n_rep,
+                                     uint64_t *pairs, unsigned long long *n_dup);
+__global__ void pgx_tag_copy_dups_kernel(const uint64_t *pairs, uint64_t n_pairs, const uint64_t *n_dev, const uint64_t *abort, uint64_t n_tag_items,
+                                         const uint64_t *first_item, const uint64_t *run_nums, const uint64_t *seg_off, uint64_t *buf, uint64_t *ucount,
                                          unsigned long long *n_overflow);
-__global__ void pgx_tag_compact_kernel(const uint64_t *list, uint64_t n, const uint64_t *ucount, const uint64_t *seg_off, const uint64_t *buf,
-                                       const uint64_t *pos_off, uint64_t *positions, uint64_t max_count);
-__global__ void pgx_tag_compact_single_kernel(uint64_t n, const uint64_t *run_nums, const uint64_t *single, const uint64_t *pos_off,
-                                              uint64_t *positions);
-__global__ void pgx_tag_compact_list_kernel(const uint64_t *list, uint64_t n_list, const uint64_t *ucount, const uint64_t *seg_off,
-                                            const uint64_t *buf, const uint64_t *pos_off, uint64_t *positions, uint64_t max_count);
+__global__ void pgx_tag_compact_kernel(const uint64_t *list, uint64_t n, const uint64_t *n_dev, const uint64_t *abort, const uint64_t *ucount,
+                                       const uint64_t *seg_off, const uint64_t *buf, const uint64_t *pos_off, uint64_t *positions, uint64_t max_count);
+__global__ void pgx_tag_compact_single_kernel(uint64_t n, const uint64_t *n_dev, const uint64_t *abort, const uint64_t *run_nums, const uint64_t *single,
+                                              const uint64_t *pos_off, uint64_t *positions);
+__global__ void pgx_tag_compact_list_kernel(const uint64_t *list, uint64_t n_list, const uint64_t *n_dev, const uint64_t *abort, const uint64_t *ucount,
+                                            const uint64_t *seg_off, const uint64_t *buf, const uint64_t *pos_off, uint64_t *positions, uint64_t max_count);
+__global__ void pgx_spec_check_kernel(const uint64_t *v0, uint64_t c0, const uint64_t *v1, uint64_t c1, const uint64_t *v2, uint64_t c2,
+                                      const uint64_t *v3, uint64_t c3, uint64_t *abort);
 #define PGX_TAG_COMPACT_SMALL 256 // segments up to this many unique values are copied by the 16-lane kernel
 
 // locate image (pgx_image.h), passed by value to the locate kernels

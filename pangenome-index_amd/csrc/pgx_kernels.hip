@@ -989,8 +989,9 @@ __device__ __forceinline__ uint64_t pgx_block_excl_scan(uint64_t v, uint64_t *s_
 
 #define PGX_SCAN_ITEMS 8 // per thread -> 2048 per block
 __global__ void __launch_bounds__(256)
-pgx_scan_partial_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, uint64_t *__restrict__ block_sums) {
+pgx_scan_partial_kernel(int mode, const void *in, uint64_t n_cap, uint64_t min_len, uint64_t *__restrict__ block_sums, const uint64_t *__restrict__ n_dev) {
     __shared__ uint64_t s_wave[4];
+    const uint64_t n = n_dev ? (*n_dev < n_cap ? *n_dev : n_cap) : n_cap; // the actual count may live on the device (speculative sizing)
     const uint64_t b0 = (uint64_t)blockIdx.x * 256 * PGX_SCAN_ITEMS;
     uint64_t v = 0;
     for (int t = 0; t < PGX_SCAN_ITEMS; t++) {
@@ -1019,9 +1020,10 @@ __global__ void __launch_bounds__(256) pgx_scan_sums_kernel(uint64_t *block_sums
 
 // out has n+1 entries; out[n] = total
 __global__ void __launch_bounds__(256)
-pgx_scan_apply_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, const uint64_t *__restrict__ block_sums,
-                      uint64_t nb, uint64_t *__restrict__ out, uint64_t *__restrict__ total_out, int raw_sums) {
+pgx_scan_apply_kernel(int mode, const void *in, uint64_t n_cap, uint64_t min_len, const uint64_t *__restrict__ block_sums,
+                      uint64_t nb, uint64_t *__restrict__ out, uint64_t *__restrict__ total_out, int raw_sums, const uint64_t *__restrict__ n_dev) {
     __shared__ uint64_t s_wave[4];
+    const uint64_t n = n_dev ? (*n_dev < n_cap ? *n_dev : n_cap) : n_cap;
     const uint64_t b0 = (uint64_t)blockIdx.x * 256 * PGX_SCAN_ITEMS;
     // raw_sums: block_sums holds the per-block totals as pgx_scan_partial_kernel wrote them (few blocks: every block adds up
     // the totals before it, which saves the single-block launch in between); otherwise their exclusive scan + grand total
@@ -1065,12 +1067,17 @@ pgx_scan_apply_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, co
 __global__ void __launch_bounds__(256)
 pgx_compact_mems_kernel(uint64_t first_read, uint64_t n_reads, const uint64_t *__restrict__ slot_off, uint64_t slot_base,
                         const pgx_mem *__restrict__ slots, const uint32_t *__restrict__ mem_count,
-                        const uint64_t *__restrict__ local_off, uint64_t mem_base, pgx_mem *__restrict__ mems) {
+                        const uint64_t *__restrict__ local_off, uint64_t mem_base, pgx_mem *__restrict__ mems, uint64_t cap_mems,
+                        uint64_t *__restrict__ abort) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // read first_read + t of this chunk
     if (t >= n_reads) return;
     const uint64_t i = first_read + t;
     const uint32_t c = mem_count[i];
     const uint64_t src = slot_off[i] - slot_base, dst = mem_base + local_off[t];
+    if (dst + c > cap_mems) { // speculative sizing: the MEM array was sized from an earlier run and this one has more
+        if (c && abort) atomicOr((unsigned long long *)abort, 16ull);
+        return;
+    }
     for (uint32_t t = 0; t < c; t++) mems[dst + t] = slots[src + t];
 }
 

@@ -190,7 +190,7 @@ extern "C" pgx_status pgx_device_name(int device, char *buf, size_t buflen) {
 // ------------------------------------------------------------------------------------------
 // exclusive scan helper: out[n+1] on device (out[n] = total); returns nothing, async on `s`
 static void scan_excl(int mode, const void *in, uint64_t n, uint64_t min_len, uint64_t *out, DevBuf &tmp, hipStream_t s,
-                      uint64_t *total_out = nullptr) {
+                      uint64_t *total_out = nullptr, const uint64_t *n_dev = nullptr) {
     if (n == 0) {
         HIPCHECK(hipMemsetAsync(out, 0, 8, s));
         if (total_out) HIPCHECK(hipMemsetAsync(total_out, 0, 8, s));
@@ -199,10 +199,10 @@ static void scan_excl(int mode, const void *in, uint64_t n, uint64_t min_len, ui
     const uint64_t nb = (n + PGX_SCAN_BLOCK_ITEMS - 1) / PGX_SCAN_BLOCK_ITEMS;
     tmp.ensure((nb + 1) * 8);
     uint64_t *sums = tmp.as<uint64_t>();
-    hipLaunchKernelGGL(pgx_scan_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, mode, in, n, min_len, sums);
+    hipLaunchKernelGGL(pgx_scan_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, mode, in, n, min_len, sums, n_dev);
     const int raw = nb <= 2048; // up to 4 M items: no separate scan of the block totals
     if (!raw) hipLaunchKernelGGL(pgx_scan_sums_kernel, dim3(1), dim3(256), 0, s, sums, nb);
-    hipLaunchKernelGGL(pgx_scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, mode, in, n, min_len, (const uint64_t *)sums, nb, out, total_out, raw);
+    hipLaunchKernelGGL(pgx_scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, mode, in, n, min_len, (const uint64_t *)sums, nb, out, total_out, raw, n_dev);
     HIPCHECK(hipGetLastError());
 }
 
@@ -210,10 +210,10 @@ void pgx_use_device(int device) { use_device(device); }
 void pgx_scan_u64(const uint64_t *in, uint64_t n, uint64_t *out, uint64_t *tmp, hipStream_t s) {
     if (n == 0) { HIPCHECK(hipMemsetAsync(out, 0, 8, s)); return; }
     const uint64_t nb = (n + PGX_SCAN_BLOCK_ITEMS - 1) / PGX_SCAN_BLOCK_ITEMS;
-    hipLaunchKernelGGL(pgx_scan_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, 1, (const void *)in, n, (uint64_t)0, tmp);
+    hipLaunchKernelGGL(pgx_scan_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, 1, (const void *)in, n, (uint64_t)0, tmp, (const uint64_t *)nullptr);
     const int raw = nb <= 2048;
     if (!raw) hipLaunchKernelGGL(pgx_scan_sums_kernel, dim3(1), dim3(256), 0, s, tmp, nb);
-    hipLaunchKernelGGL(pgx_scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, 1, (const void *)in, n, (uint64_t)0, (const uint64_t *)tmp, nb, out, (uint64_t *)nullptr, raw);
+    hipLaunchKernelGGL(pgx_scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, 1, (const void *)in, n, (uint64_t)0, (const uint64_t *)tmp, nb, out, (uint64_t *)nullptr, raw, (const uint64_t *)nullptr);
     HIPCHECK(hipGetLastError());
 }
 
@@ -243,44 +243,80 @@ static inline unsigned grid_for(uint64_t n, unsigned per_block) {
 // ------------------------------------------------------------------------------------------
 // tag pipeline shared by pgx_batch_run and pgx_tag_query_batch
 struct TagWork {
-    DevBuf run_nums, first_item, seg_off, gbuf, need, scratch_off, scratch, ucount, pos_off, positions, big_list, scan_tmp, dedup, single, small_list;
-    HostBuf h_dedup; // pinned staging of the large-query keys and lists
+    DevBuf run_nums, first_item, seg_off, gbuf, need, scratch_off, scratch, ucount, pos_off, positions, big_list, large_list, scan_tmp, dedup, dd_table,
+        single, small_list;
     uint64_t n_positions = 0, n_big = 0;
+    // what the last run needed (speculative sizing of the next one, pgx_batch_run): gathered values, positions, list lengths,
+    // largest run count on the large list
+    uint64_t last_G = 0, last_P = 0, last_small = 0, last_big = 0, last_large = 0, last_largest = 0, last_rep = 0, last_dup = 0;
+    bool have_last = false;
     void release() {
-        h_dedup.release();
         DevBuf *all[] = {&run_nums, &first_item, &seg_off, &gbuf, &need, &scratch_off, &scratch, &ucount, &pos_off, &positions,
-                         &big_list, &scan_tmp, &dedup, &single, &small_list};
+                         &big_list, &large_list, &scan_tmp, &dedup, &dd_table, &single, &small_list};
         for (DevBuf *d : all) d->release();
     }
 };
 
-// counters: d_nover overflow count, d_nbig[0] big-list length, d_nbig[1] large-list length, d_nbig[2] largest
-// run count on the large list, d_nbig[3] / d_nbig[4] totals of the two scans (all zeroed by the caller; read back together)
+static inline uint64_t with_slack(uint64_t v) { return v + v / 4 + 64; }
+
+// Device scalars of the stage, sc[] (zeroed by the caller): [0] big-list length [1] large-list length [2] largest run count on the
+// large list [3] total of gathered values G [5] small-list length [6] representatives [7] duplicates [8] positions.
+//
+// Exact mode (spec == false): the host reads the scalars back where they size the next buffer (three synchronisations).
+// Speculative mode: every buffer and grid is sized from the previous run of this batch (+ 25 %), the counts stay on the device
+// (kernels take a capacity and a device pointer to the actual count, pgx_tag_kernels.hip), capacity checks raise *d_abort on the
+// device, and nothing is read back here: the caller reads all scalars once at the end and repeats the run in exact mode if the
+// abort flag came up.  `m` is then the capacity of the per-query arrays and d_m points to the actual number of queries.
 template <class Rec>
-static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const uint64_t *d_qs, const uint64_t *d_qe, uint64_t m,
-                         TagWork &w, unsigned long long *d_nover, unsigned long long *d_nbig, hipStream_t s, Rec &&rec) {
-    w.run_nums.ensure((m ? m : 1) * 8);
-    w.first_item.ensure((m ? m : 1) * 8);
+static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const uint64_t *d_qs, const uint64_t *d_qe, uint64_t m, TagWork &w,
+                         unsigned long long *d_nover, unsigned long long *sc, hipStream_t s, Rec &&rec, bool spec = false,
+                         const uint64_t *d_m = nullptr, uint64_t *d_abort = nullptr) {
+    const uint64_t mm = m ? m : 1;
+    w.run_nums.ensure(mm * 8);
+    w.first_item.ensure(mm * 8);
     w.seg_off.ensure((m + 1) * 8);
-    w.need.ensure((m ? m : 1) * 8);
+    w.need.ensure(mm * 8);
     w.scratch_off.ensure((m + 1) * 8);
-    w.ucount.ensure((m ? m : 1) * 8);
+    w.ucount.ensure(mm * 8);
     w.pos_off.ensure((m + 1) * 8);
-    w.big_list.ensure((m ? m : 1) * 8);
-    w.single.ensure((m ? m : 1) * 8);
-    w.small_list.ensure((m ? m : 1) * 8);
+    w.big_list.ensure(mm * 8);
+    w.large_list.ensure(mm * 8);
+    w.single.ensure(mm * 8);
+    w.small_list.ensure(mm * 8);
+    const uint64_t *u_sc = reinterpret_cast<const uint64_t *>(sc);
+    const uint64_t *dn_small = spec ? u_sc + 5 : nullptr, *dn_big = spec ? u_sc + 0 : nullptr, *dn_large = spec ? u_sc + 1 : nullptr;
+    const uint64_t *dn_rep = spec ? u_sc + 6 : nullptr, *dn_dup = spec ? u_sc + 7 : nullptr;
+    const uint64_t *ab = spec ? d_abort : nullptr;
+    auto fixed_grid = [](uint64_t n, unsigned per_block, unsigned max_blocks) { return (unsigned)std::min<uint64_t>(std::max<uint64_t>((n + per_block - 1) / per_block, 1), max_blocks); };
     if (m) {
-        hipLaunchKernelGGL(pgx_tag_locate_kernel, dim3(grid_for(m, PGX_TAG_LOCATE_THREADS)), dim3(PGX_TAG_LOCATE_THREADS), 0, s, img, d_mems, d_qs, d_qe, m,
-                           w.run_nums.as<uint64_t>(), w.first_item.as<uint64_t>(), w.need.as<uint64_t>(), w.big_list.as<uint64_t>(), d_nbig, d_nbig + 1,
-                           w.single.as<uint64_t>(), w.ucount.as<uint64_t>(), d_nover, w.small_list.as<uint64_t>(), d_nbig + 5);
+        const unsigned g = spec ? fixed_grid(m, PGX_TAG_LOCATE_THREADS, 8192) : grid_for(m, PGX_TAG_LOCATE_THREADS);
+        hipLaunchKernelGGL(pgx_tag_locate_kernel, dim3(g), dim3(PGX_TAG_LOCATE_THREADS), 0, s, img, d_mems, d_qs, d_qe, m, d_m, ab,
+                           w.run_nums.as<uint64_t>(), w.first_item.as<uint64_t>(), w.need.as<uint64_t>(), w.big_list.as<uint64_t>(), w.large_list.as<uint64_t>(),
+                           sc, sc + 1, w.single.as<uint64_t>(), w.ucount.as<uint64_t>(), d_nover, w.small_list.as<uint64_t>(), sc + 5);
         HIPCHECK(hipGetLastError());
     }
-    scan_excl(5, w.run_nums.p, m, 0, w.seg_off.as<uint64_t>(), w.scan_tmp, s, reinterpret_cast<uint64_t *>(d_nbig + 3)); // single runs: no segment
-    uint64_t hv[6] = {0, 0, 0, 0, 0, 0}; // nbig, nlarge, largest large run count, G, (unused), nsmall
-    read_scalars(hv, d_nbig, 48, s);
-    const uint64_t G = hv[3], nbig = hv[0], nlarge = hv[1], nsmall = hv[5];
+    scan_excl(5, w.run_nums.p, m, 0, w.seg_off.as<uint64_t>(), w.scan_tmp, s, reinterpret_cast<uint64_t *>(sc + 3), d_m); // single runs: no segment
+    uint64_t G, nbig, nlarge, nsmall, largest;
+    if (!spec) {
+        uint64_t hv[6] = {0, 0, 0, 0, 0, 0};
+        read_scalars(hv, sc, 48, s);
+        G = hv[3]; nbig = hv[0]; nlarge = hv[1]; nsmall = hv[5]; largest = hv[2];
+    } else { // capacities from the previous run; the device checks what it can before anything is written through them
+        G = with_slack(w.last_G); nbig = with_slack(w.last_big); nlarge = with_slack(w.last_large); nsmall = with_slack(w.last_small);
+        // the large path sorts in dynamic LDS sized for the largest run count: twice the last one (a power of two), at most the
+        // workgroup capacity -- a larger query aborts the speculative run (the caller never speculates beyond that capacity)
+        uint64_t p2 = 64;
+        while (p2 < 2 * w.last_largest && p2 < PGX_SORT_WG_LDS_CAP) p2 <<= 1;
+        largest = p2;
+        // [bit 0] gathered values, [1] large list, [2] largest run count, [3] big list
+        hipLaunchKernelGGL(pgx_spec_check_kernel, dim3(1), dim3(64), 0, s, u_sc + 3, G, u_sc + 1, nlarge, u_sc + 2, largest, u_sc + 0, nbig, d_abort);
+        hipLaunchKernelGGL(pgx_spec_check_kernel, dim3(1), dim3(64), 0, s, u_sc + 5, nsmall, (const uint64_t *)nullptr, (uint64_t)0, (const uint64_t *)nullptr,
+                           (uint64_t)0, (const uint64_t *)nullptr, (uint64_t)0, d_abort);
+        HIPCHECK(hipGetLastError());
+        if (largest > PGX_SORT_WG_LDS_CAP) throw Error(PGX_ERR_ARG, "speculative tag stage with a query beyond the LDS sort capacity"); // (the caller never asks for this)
+    }
     uint64_t S = 0; // global sort scratch: only queries with more than PGX_SORT_WG_LDS_CAP runs need any (rare: one more scan then)
-    if (hv[2] > PGX_SORT_WG_LDS_CAP) {
+    if (largest > PGX_SORT_WG_LDS_CAP) {
         scan_excl(1, w.need.p, m, 0, w.scratch_off.as<uint64_t>(), w.scan_tmp, s);
         S = read_u64(w.scratch_off.as<uint64_t>() + m, s);
     }
@@ -289,106 +325,99 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
     w.gbuf.ensure((G ? G : 1) * 8);
     w.scratch.ensure((S ? S : 1) * 8);
     if (nsmall) { // queries with 2 .. 16 runs (single runs were answered by the locate kernel)
-        hipLaunchKernelGGL(pgx_tag_small_kernel, dim3(grid_for(nsmall, 16)), dim3(256), 0, s, img, (const uint64_t *)w.small_list.as<uint64_t>(), nsmall,
+        const unsigned g = spec ? fixed_grid(nsmall, 16, 16384) : grid_for(nsmall, 16);
+        hipLaunchKernelGGL(pgx_tag_small_kernel, dim3(g), dim3(256), 0, s, img, (const uint64_t *)w.small_list.as<uint64_t>(), nsmall, dn_small, ab,
                            w.run_nums.as<uint64_t>(), w.first_item.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(),
                            w.ucount.as<uint64_t>(), d_nover);
         HIPCHECK(hipGetLastError());
     }
     rec(1);
     if (nbig) {
-        hipLaunchKernelGGL(pgx_tag_gather_kernel, dim3(grid_for(nbig, 4)), dim3(256), 0, s, img, w.big_list.as<uint64_t>(), nbig,
+        const unsigned g = spec ? fixed_grid(nbig, 4, 8192) : grid_for(nbig, 4);
+        hipLaunchKernelGGL(pgx_tag_gather_kernel, dim3(g), dim3(256), 0, s, img, (const uint64_t *)w.big_list.as<uint64_t>(), nbig, dn_big, ab,
                            w.run_nums.as<uint64_t>(), w.first_item.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), d_nover);
-        hipLaunchKernelGGL(pgx_tag_sort_unique_kernel, dim3(grid_for(nbig, 4)), dim3(256), 0, s, w.big_list.as<uint64_t>(), nbig,
+        hipLaunchKernelGGL(pgx_tag_sort_unique_kernel, dim3(g), dim3(256), 0, s, (const uint64_t *)w.big_list.as<uint64_t>(), nbig, dn_big, ab,
                            w.run_nums.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.ucount.as<uint64_t>());
         HIPCHECK(hipGetLastError());
     }
+    uint64_t nrep = 0, ndup = 0;
     if (nlarge) {
-        const uint64_t *large = w.big_list.as<uint64_t>() + (m - nlarge); // the back of the shared list array
         uint64_t p2max = 64;
-        while (p2max < hv[2] && p2max < PGX_SORT_WG_LDS_CAP) p2max <<= 1;
+        while (p2max < largest && p2max < PGX_SORT_WG_LDS_CAP) p2max <<= 1;
         const size_t lds = (size_t)p2max * 8; // smaller segments -> more workgroups per CU
         // opt in to > 64 KiB of dynamic LDS (per device; cheap enough to repeat)
         HIPCHECK(hipFuncSetAttribute((const void *)pgx_tag_sort_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)(PGX_SORT_WG_LDS_CAP * 8)));
-        // Identical large queries are common (every read from the same repeat / N run yields the same SA interval):
-        // sort one representative per distinct (first item, run count) and copy its result to the duplicates.
-        // keys and lists travel through one pinned buffer: [3 * nlarge keys | nlarge representatives | 2 * nlarge pairs]
-        w.h_dedup.ensure(6 * nlarge * 8);
-        uint64_t *keys = w.h_dedup.as<uint64_t>(), *reps = keys + 3 * nlarge, *dup_pairs = reps + nlarge;
-        w.dedup.ensure(3 * nlarge * 8);
-        hipLaunchKernelGGL(pgx_tag_list_fetch_kernel, dim3(grid_for(nlarge, 256)), dim3(256), 0, s, large, nlarge,
-                           w.first_item.as<uint64_t>(), w.run_nums.as<uint64_t>(), w.dedup.as<uint64_t>());
+        // identical large queries are grouped on the device (pgx_tag_dedup_kernel): representatives are sorted, duplicates copy
+        uint64_t tcap = 64;
+        while (tcap < 2 * nlarge) tcap <<= 1;
+        w.dd_table.ensure(tcap * 8);
+        w.dedup.ensure(3 * nlarge * 8); // [representatives | (duplicate, representative) pairs]
+        uint64_t *d_reps = w.dedup.as<uint64_t>(), *d_pairs = d_reps + nlarge;
+        HIPCHECK(hipMemsetAsync(w.dd_table.p, 0, tcap * 8, s));
+        hipLaunchKernelGGL(pgx_tag_dedup_kernel, dim3(fixed_grid(nlarge, 256, 1024)), dim3(256), 0, s, (const uint64_t *)w.large_list.as<uint64_t>(), nlarge, dn_large, ab,
+                           (const uint64_t *)w.first_item.as<uint64_t>(), (const uint64_t *)w.run_nums.as<uint64_t>(), w.dd_table.as<unsigned long long>(), tcap - 1,
+                           d_reps, sc + 6, d_pairs, sc + 7);
         HIPCHECK(hipGetLastError());
-        HIPCHECK(hipMemcpyAsync(keys, w.dedup.p, 3 * nlarge * 8, hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipStreamSynchronize(s));
-        uint64_t nrep = 0, ndup = 0;
-        {
-            // open addressing over (first item, run count): slot -> index of the representative in `reps`
-            uint64_t cap = 16;
-            while (cap < 2 * nlarge) cap <<= 1;
-            std::vector<uint32_t> table(cap, 0xFFFFFFFFu);
-            std::vector<uint32_t> rep_key(nlarge); // representative r was listed at position rep_key[r]
-            for (uint64_t i = 0; i < nlarge; i++) {
-                const uint64_t q = keys[3 * i], f = keys[3 * i + 1], c = keys[3 * i + 2];
-                uint64_t hsh = (f * 0x9E3779B97F4A7C15ull ^ c * 0xC2B2AE3D27D4EB4Full) & (cap - 1);
-                for (;; hsh = (hsh + 1) & (cap - 1)) {
-                    const uint32_t r = table[hsh];
-                    if (r == 0xFFFFFFFFu) {
-                        table[hsh] = (uint32_t)nrep;
-                        rep_key[nrep] = (uint32_t)i;
-                        reps[nrep++] = q;
-                        break;
-                    }
-                    if (keys[3 * (uint64_t)rep_key[r] + 1] == f && keys[3 * (uint64_t)rep_key[r] + 2] == c) {
-                        dup_pairs[2 * ndup] = q;
-                        dup_pairs[2 * ndup + 1] = reps[r];
-                        ndup++;
-                        break;
-                    }
-                }
-            }
+        if (!spec) {
+            uint64_t rd[2] = {0, 0};
+            read_scalars(rd, sc + 6, 16, s);
+            nrep = rd[0]; ndup = rd[1];
+        } else { nrep = nlarge; ndup = nlarge; } // (capacities: the lists cannot be longer than the large list)
+        if (nrep) {
+            hipLaunchKernelGGL(pgx_tag_gather_kernel, dim3(spec ? fixed_grid(nrep, 4, 8192) : grid_for(nrep, 4)), dim3(256), 0, s, img, (const uint64_t *)d_reps, nrep,
+                               dn_rep, ab, w.run_nums.as<uint64_t>(), w.first_item.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), d_nover);
+            hipLaunchKernelGGL(pgx_tag_sort_large_kernel, dim3(spec ? fixed_grid(nrep, 1, 2048) : grid_for(nrep, 1)), dim3(1024), lds, s, (const uint64_t *)d_reps, nrep,
+                               dn_rep, ab, w.run_nums.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.scratch.as<uint64_t>(),
+                               w.scratch_off.as<uint64_t>(), w.ucount.as<uint64_t>());
         }
-        uint64_t *d_reps = w.dedup.as<uint64_t>(), *d_dups = d_reps + nrep;
-        HIPCHECK(hipMemcpyAsync(d_reps, reps, nrep * 8, hipMemcpyHostToDevice, s));
-        if (ndup) HIPCHECK(hipMemcpyAsync(d_dups, dup_pairs, ndup * 16, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(pgx_tag_gather_kernel, dim3(grid_for(nrep, 4)), dim3(256), 0, s, img, (const uint64_t *)d_reps, nrep,
-                           w.run_nums.as<uint64_t>(), w.first_item.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), d_nover);
-        hipLaunchKernelGGL(pgx_tag_sort_large_kernel, dim3(grid_for(nrep, 1)), dim3(1024), lds, s, (const uint64_t *)d_reps, nrep,
-                           w.run_nums.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.scratch.as<uint64_t>(),
-                           w.scratch_off.as<uint64_t>(), w.ucount.as<uint64_t>());
         if (ndup)
-            hipLaunchKernelGGL(pgx_tag_copy_dups_kernel, dim3(grid_for(ndup, 1)), dim3(256), 0, s, (const uint64_t *)d_dups, ndup,
-                               img.n_tag_items, w.first_item.as<uint64_t>(), w.run_nums.as<uint64_t>(), w.seg_off.as<uint64_t>(),
+            hipLaunchKernelGGL(pgx_tag_copy_dups_kernel, dim3(spec ? fixed_grid(ndup, 1, 4096) : grid_for(ndup, 1)), dim3(256), 0, s, (const uint64_t *)d_pairs, ndup,
+                               dn_dup, ab, img.n_tag_items, w.first_item.as<uint64_t>(), w.run_nums.as<uint64_t>(), w.seg_off.as<uint64_t>(),
                                w.gbuf.as<uint64_t>(), w.ucount.as<uint64_t>(), d_nover);
         HIPCHECK(hipGetLastError());
-        // (the lists live in w.h_dedup, which outlives the asynchronous copies above)
     }
-    scan_excl(1, w.ucount.p, m, 0, w.pos_off.as<uint64_t>(), w.scan_tmp, s);
-    w.n_positions = read_u64(w.pos_off.as<uint64_t>() + m, s);
-    w.positions.ensure((w.n_positions ? w.n_positions : 1) * 8);
+    scan_excl(1, w.ucount.p, m, 0, w.pos_off.as<uint64_t>(), w.scan_tmp, s, reinterpret_cast<uint64_t *>(sc + 8), d_m);
+    uint64_t P;
+    if (!spec) {
+        w.n_positions = read_u64(reinterpret_cast<const uint64_t *>(sc + 8), s);
+        P = w.n_positions;
+    } else {
+        P = with_slack(w.last_P);
+        hipLaunchKernelGGL(pgx_spec_check_kernel, dim3(1), dim3(64), 0, s, u_sc + 8, P, (const uint64_t *)nullptr, (uint64_t)0, (const uint64_t *)nullptr, (uint64_t)0,
+                           (const uint64_t *)nullptr, (uint64_t)0, d_abort);
+    }
+    w.positions.ensure((P ? P : 1) * 8);
     if (m) {
         // every query is on exactly one list: single (thread per query), small, big, large (16 lanes per query up to
         // PGX_TAG_COMPACT_SMALL unique values, one workgroup per query beyond)
-        const uint64_t *lists[3] = {w.small_list.as<uint64_t>(), w.big_list.as<uint64_t>(), w.big_list.as<uint64_t>() + (m - nlarge)};
+        const uint64_t *lists[3] = {w.small_list.as<uint64_t>(), w.big_list.as<uint64_t>(), w.large_list.as<uint64_t>()};
         const uint64_t counts[3] = {nsmall, nbig, nlarge};
+        const uint64_t *dcounts[3] = {dn_small, dn_big, dn_large};
         for (int li = 0; li < 3; li++)
             if (counts[li])
-                hipLaunchKernelGGL(pgx_tag_compact_kernel, dim3(grid_for(counts[li], 16)), dim3(256), 0, s, lists[li], counts[li], w.ucount.as<uint64_t>(),
-                                   w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.pos_off.as<uint64_t>(), w.positions.as<uint64_t>(),
-                                   (uint64_t)PGX_TAG_COMPACT_SMALL);
-        hipLaunchKernelGGL(pgx_tag_compact_single_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, m, (const uint64_t *)w.run_nums.as<uint64_t>(),
-                           (const uint64_t *)w.single.as<uint64_t>(), (const uint64_t *)w.pos_off.as<uint64_t>(), w.positions.as<uint64_t>());
+                hipLaunchKernelGGL(pgx_tag_compact_kernel, dim3(spec ? fixed_grid(counts[li], 16, 16384) : grid_for(counts[li], 16)), dim3(256), 0, s, lists[li], counts[li],
+                                   dcounts[li], ab, w.ucount.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.pos_off.as<uint64_t>(),
+                                   w.positions.as<uint64_t>(), (uint64_t)PGX_TAG_COMPACT_SMALL);
+        hipLaunchKernelGGL(pgx_tag_compact_single_kernel, dim3(spec ? fixed_grid(m, 256, 16384) : grid_for(m, 256)), dim3(256), 0, s, m, d_m, ab,
+                           (const uint64_t *)w.run_nums.as<uint64_t>(), (const uint64_t *)w.single.as<uint64_t>(), (const uint64_t *)w.pos_off.as<uint64_t>(),
+                           w.positions.as<uint64_t>());
         if (nbig)
-            hipLaunchKernelGGL(pgx_tag_compact_list_kernel, dim3(grid_for(nbig, 1)), dim3(256), 0, s, (const uint64_t *)w.big_list.as<uint64_t>(), nbig,
-                               w.ucount.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.pos_off.as<uint64_t>(),
+            hipLaunchKernelGGL(pgx_tag_compact_list_kernel, dim3(spec ? fixed_grid(nbig, 1, 4096) : grid_for(nbig, 1)), dim3(256), 0, s, (const uint64_t *)w.big_list.as<uint64_t>(), nbig,
+                               dn_big, ab, w.ucount.as<uint64_t>(), w.seg_off.as<uint64_t>(), w.gbuf.as<uint64_t>(), w.pos_off.as<uint64_t>(),
                                w.positions.as<uint64_t>(), (uint64_t)PGX_TAG_COMPACT_SMALL);
         if (nlarge)
-            hipLaunchKernelGGL(pgx_tag_compact_list_kernel, dim3(grid_for(nlarge, 1)), dim3(256), 0, s,
-                               (const uint64_t *)(w.big_list.as<uint64_t>() + (m - nlarge)), nlarge, w.ucount.as<uint64_t>(), w.seg_off.as<uint64_t>(),
+            hipLaunchKernelGGL(pgx_tag_compact_list_kernel, dim3(spec ? fixed_grid(nlarge, 1, 4096) : grid_for(nlarge, 1)), dim3(256), 0, s,
+                               (const uint64_t *)w.large_list.as<uint64_t>(), nlarge, dn_large, ab, w.ucount.as<uint64_t>(), w.seg_off.as<uint64_t>(),
                                w.gbuf.as<uint64_t>(), w.pos_off.as<uint64_t>(), w.positions.as<uint64_t>(), (uint64_t)PGX_TAG_COMPACT_SMALL);
         HIPCHECK(hipGetLastError());
     }
     rec(2);
+    if (!spec) { // what the next run of this batch may assume
+        w.last_G = G; w.last_P = P; w.last_small = nsmall; w.last_big = nbig; w.last_large = nlarge; w.last_largest = largest;
+        w.last_rep = nrep; w.last_dup = ndup;
+        w.have_last = true;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -506,22 +535,23 @@ static void locate_core(pgx_index *h, pgx_device_image *d, const uint64_t *first
             if (!wg_list.empty()) HIPCHECK(hipMemcpy(d_wg, wg_list.data(), wg_list.size() * 8, hipMemcpyHostToDevice));
             if (!wave_list.empty())
                 hipLaunchKernelGGL(pgx_tag_sort_unique_kernel, dim3(grid_for(wave_list.size(), 4)), dim3(256), 0, s, (const uint64_t *)d_wave,
-                                   (uint64_t)wave_list.size(), dcnt.as<uint64_t>(), dvoff.as<uint64_t>(), gbuf.as<uint64_t>(), ducount.as<uint64_t>());
+                                   (uint64_t)wave_list.size(), (const uint64_t *)nullptr, (const uint64_t *)nullptr, dcnt.as<uint64_t>(), dvoff.as<uint64_t>(),
+                                   gbuf.as<uint64_t>(), ducount.as<uint64_t>());
             if (!wg_list.empty()) {
                 uint64_t p2max = 64;
                 while (p2max < max_cnt && p2max < PGX_SORT_WG_LDS_CAP) p2max <<= 1;
                 HIPCHECK(hipFuncSetAttribute((const void *)pgx_tag_sort_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)(PGX_SORT_WG_LDS_CAP * 8)));
                 hipLaunchKernelGGL(pgx_tag_sort_large_kernel, dim3(grid_for(wg_list.size(), 1)), dim3(1024), (size_t)p2max * 8, s,
-                                   (const uint64_t *)d_wg, (uint64_t)wg_list.size(), dcnt.as<uint64_t>(), dvoff.as<uint64_t>(), gbuf.as<uint64_t>(),
-                                   dscratch.as<uint64_t>(), dsoff.as<uint64_t>(), ducount.as<uint64_t>());
+                                   (const uint64_t *)d_wg, (uint64_t)wg_list.size(), (const uint64_t *)nullptr, (const uint64_t *)nullptr, dcnt.as<uint64_t>(),
+                                   dvoff.as<uint64_t>(), gbuf.as<uint64_t>(), dscratch.as<uint64_t>(), dsoff.as<uint64_t>(), ducount.as<uint64_t>());
             }
             HIPCHECK(hipGetLastError());
             scan_excl(1, ducount.p, n, 0, duoff.as<uint64_t>(), scan_tmp, s);
             const uint64_t U = read_u64(duoff.as<uint64_t>() + n, s);
             vals_out.ensure((U ? U : 1) * 8);
-            hipLaunchKernelGGL(pgx_tag_compact_kernel, dim3(grid_for(n, 16)), dim3(256), 0, s, (const uint64_t *)nullptr, n, ducount.as<uint64_t>(), dvoff.as<uint64_t>(),
-                               gbuf.as<uint64_t>(), duoff.as<uint64_t>(), vals_out.as<uint64_t>(), ~0ull);
+            hipLaunchKernelGGL(pgx_tag_compact_kernel, dim3(grid_for(n, 16)), dim3(256), 0, s, (const uint64_t *)nullptr, n, (const uint64_t *)nullptr, (const uint64_t *)nullptr,
+                               ducount.as<uint64_t>(), dvoff.as<uint64_t>(), gbuf.as<uint64_t>(), duoff.as<uint64_t>(), vals_out.as<uint64_t>(), ~0ull);
             HIPCHECK(hipGetLastError());
             h_off.resize(n + 1);
             HIPCHECK(hipMemcpy(h_off.data(), duoff.p, (n + 1) * 8, hipMemcpyDeviceToHost));
@@ -791,6 +821,11 @@ struct pgx_batch {
     TagWork tw;
     uint64_t n_mems = 0, n_positions = 0, n_ext = 0, n_tag_overflow = 0;
     bool ran = false, ran_tags = false;
+    // speculative sizing (pgx_batch_run): what the last run with these parameters produced
+    bool shape_valid = false;
+    uint64_t shape_reads = 0, shape_min_len = 0, shape_min_occ = 0, last_mems = 0;
+    bool shape_tags = false;
+    uint32_t spec_runs = 0, spec_fallbacks = 0;
     // host copies
     HostBuf h_mem_off, h_mems, h_run_nums, h_pos_off, h_positions;
     // timing
@@ -895,7 +930,16 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     b->n_mems = b->n_positions = b->n_ext = b->n_tag_overflow = 0;
     std::memset(&b->timing, 0, sizeof b->timing);
 
-    b->counters.ensure(256); // [0] extensions [1] tag overflows [5] read cursor [3,6,7] stats builds [8] heavy reads [16..20] tag stage
+    // Speculative sizing: a run normally reads a few scalars back in mid-flight (MEM total, tag-stage totals) because they size
+    // the next buffers -- each a host synchronisation with the device idle meanwhile.  When the previous run of this batch had the
+    // same shape (reads, min_len, min_occ, tags), the buffers and grids are sized from ITS totals (+ 25 %), all counts stay on the
+    // device, capacity checks raise an abort flag there, and the host reads everything once at the end; if the flag came up (or the
+    // 32-bit state overflowed) the run is repeated in exact mode.  PGX_SPEC=0 switches it off.
+    for (int pass = 0;; pass++) {
+    b->n_mems = b->n_positions = b->n_ext = b->n_tag_overflow = 0;
+    std::memset(&b->timing, 0, sizeof b->timing);
+    b->counters.ensure(256); // [0] extensions [1] tag overflows [5] read cursor [3,6,7] stats builds [8] heavy reads [9] 32-bit overflow
+                             // [10] MEMs [16..24] tag stage (tag_pipeline) [30] abort flag of a speculative run
     HIPCHECK(hipMemsetAsync(b->counters.p, 0, 256, s));
     unsigned long long *d_next = b->counters.as<unsigned long long>();
     unsigned long long *d_nover = d_next + 1;
@@ -979,6 +1023,12 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         b->heavy_scratch.ensure((size_t)PGX_FM_HEAVY_GRID * PGX_FM_HEAVY_MAXLEN * sizeof(PgxHeavyResult));
     }
     unsigned long long *d_cursor = d_next + 5; // counters layout: see the allocation above
+    const char *spec_env = std::getenv("PGX_SPEC");
+    const bool spec = pass == 0 && chunks.size() == 1 && b->shape_valid && b->shape_reads == n && b->shape_min_len == min_len && b->shape_min_occ == min_occ &&
+                      b->shape_tags == want_tags && (!want_tags || (b->tw.have_last && b->tw.last_largest <= PGX_SORT_WG_LDS_CAP)) &&
+                      !(spec_env && spec_env[0] == '0') && !std::getenv("PGX_FM_NARROW_FORCE_REDO");
+    const uint64_t cm_cap = with_slack(b->last_mems);
+    uint64_t *d_abort = reinterpret_cast<uint64_t *>(d_next + 30);
     for (size_t ci = 0; ci < chunks.size(); ci++) {
         const pgx_chunk &c = chunks[ci];
         const uint64_t cn = c.r1 - c.r0;
@@ -1025,6 +1075,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             b->timing.find_mems_launches++;
             record(b, 2, s);
             scan_excl(0, b->mem_count.as<uint32_t>() + c.r0, cn, 0, local, b->scan_tmp, s, reinterpret_cast<uint64_t *>(d_next + 10));
+            if (spec) { cm = cm_cap; break; } // nothing is read back: the MEM total stays on the device
             unsigned long long cc[11];
             read_scalars(cc, d_next, sizeof cc, s);
             const bool forced = attempt == 0 && kf != kfn_wide && std::getenv("PGX_FM_NARROW_FORCE_REDO") != nullptr; // tests
@@ -1037,7 +1088,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         b->mems.ensure_keep((mem_base + cm ? mem_base + cm : 1) * sizeof(pgx_mem), mem_base * sizeof(pgx_mem));
         hipLaunchKernelGGL(pgx_compact_mems_kernel, dim3(grid_for(cn, 256)), dim3(256), 0, s, c.r0, cn, b->slot_off.as<uint64_t>(),
                            c.slot_base, b->slots.as<pgx_mem>(), b->mem_count.as<uint32_t>(), (const uint64_t *)local, mem_base,
-                           b->mems.as<pgx_mem>());
+                           b->mems.as<pgx_mem>(), spec ? cm_cap : ~0ull, d_abort);
         HIPCHECK(hipGetLastError());
         record(b, 3, s);
         mem_base += cm;
@@ -1061,14 +1112,29 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     if (want_tags) {
         unsigned long long *d_nbig = d_next + 16;
         tag_pipeline(img, b->mems.as<pgx_mem>(), nullptr, nullptr, b->n_mems, b->tw, d_nover, d_nbig, s,
-                     [&](int stage) { record(b, 4 + stage, s); });
+                     [&](int stage) { record(b, 4 + stage, s); }, spec, reinterpret_cast<const uint64_t *>(d_next + 10), d_abort);
         b->n_positions = b->tw.n_positions;
         b->ran_tags = true;
     }
     record(b, 7, s);
-    unsigned long long cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    HIPCHECK(hipMemcpyAsync(cnt, b->counters.p, 72, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
+    unsigned long long cnt[32];
+    read_scalars(cnt, b->counters.p, sizeof cnt, s);
+    if (spec) {
+        b->spec_runs++;
+        if (cnt[30] || cnt[9] || cnt[10] > cm_cap) { b->spec_fallbacks++; b->ran_tags = false; continue; } // a capacity was too small: once more, exactly
+        b->n_mems = cnt[10];
+        n_ext_host = cnt[0];
+        b->timing.heavy_reads = (uint32_t)std::min<unsigned long long>(cnt[8], PGX_FM_HEAVY_CAP);
+        if (want_tags) {
+            TagWork &w = b->tw;
+            w.last_big = cnt[16]; w.last_large = cnt[17]; w.last_largest = cnt[18]; w.last_G = cnt[19]; w.last_small = cnt[21];
+            w.last_rep = cnt[22]; w.last_dup = cnt[23]; w.last_P = cnt[24];
+            w.n_positions = cnt[24];
+            b->n_positions = cnt[24];
+        }
+    }
+    b->last_mems = b->n_mems;
+    b->shape_valid = true; b->shape_reads = n; b->shape_min_len = min_len; b->shape_min_occ = min_occ; b->shape_tags = want_tags;
     if (cnt[6] && std::getenv("PGX_FM_STATS")) // only a -DPGX_FM_STATS build of the kernels fills these (scripts/fm_stats.sh)
         std::fprintf(stderr, "[pgx] find_mems wave trips %llu, live lane-trips %llu (%.1f%% of lanes), longest wave %llu trips, extensions %llu\n", cnt[6], cnt[7],
                      100.0 * (double)cnt[7] / (64.0 * (double)cnt[6]), cnt[3], cnt[0]);
@@ -1086,6 +1152,8 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         }
         b->timing.ms_total = el(0, 7);
     }
+    break;
+    } // (speculative pass, then at most one exact pass)
     b->ran = true;
     return PGX_OK;
     PGX_GUARD_END
@@ -1115,6 +1183,15 @@ extern "C" pgx_status pgx_batch_counts(pgx_batch *b, uint64_t *n_mems, uint64_t 
     if (n_mems) *n_mems = b->n_mems;
     if (n_positions) *n_positions = b->n_positions;
     if (n_extensions) *n_extensions = b->n_ext;
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_batch_spec_stats(pgx_batch *b, uint32_t *speculative_runs, uint32_t *fallbacks) {
+    PGX_GUARD_BEGIN
+    if (!b) throw Error(PGX_ERR_ARG, "pgx_batch_spec_stats: null batch");
+    if (speculative_runs) *speculative_runs = b->spec_runs;
+    if (fallbacks) *fallbacks = b->spec_fallbacks;
     return PGX_OK;
     PGX_GUARD_END
 }
@@ -1398,8 +1475,8 @@ extern "C" pgx_status pgx_tag_query_batch(pgx_index *h, int device, const uint64
     TagWork w;
     try {
         hipStream_t s = nullptr;
-        ds.ensure(n * 8); de.ensure(n * 8); dctr.ensure(64);
-        HIPCHECK(hipMemset(dctr.p, 0, 64));
+        ds.ensure(n * 8); de.ensure(n * 8); dctr.ensure(256);
+        HIPCHECK(hipMemset(dctr.p, 0, 256));
         HIPCHECK(hipMemcpy(ds.p, start, n * 8, hipMemcpyHostToDevice));
         HIPCHECK(hipMemcpy(de.p, end, n * 8, hipMemcpyHostToDevice));
         unsigned long long *ctr = dctr.as<unsigned long long>();

@@ -32,14 +32,27 @@ __device__ __forceinline__ uint64_t pgx_tag_rank(const PgxDevImage &img, uint64_
 
 // per query: run_nums (number_of_runs, :860) and the index of the first item read (:862-874,
 // including the off-by-one when first_bit_index % 10 == 0)
+// Counts that live on the device: every kernel of the tag stage takes its element count as a value (an upper bound: the
+// capacity its buffers were sized for) AND, optionally, a device pointer to the actual count, loops over its elements with a
+// grid stride, and returns at once when the stage's abort flag is set -- so the whole stage can be enqueued without the host
+// knowing any count (pgx_runtime.hip "speculative sizing"); with a NULL pointer and an exact value it is the plain launch.
+#define PGX_DEV_COUNT(n, n_dev) ((n_dev) ? ((*(n_dev)) < (n) ? (*(n_dev)) : (n)) : (n))
+#define PGX_ABORTED(abort) ((abort) && *(abort))
+
 __global__ void __launch_bounds__(PGX_TAG_LOCATE_THREADS)
 pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *__restrict__ mems, const uint64_t *__restrict__ qstart,
-                      const uint64_t *__restrict__ qend, uint64_t n, uint64_t *__restrict__ run_nums,
-                      uint64_t *__restrict__ first_item, uint64_t *__restrict__ need, uint64_t *__restrict__ big_list,
+                      const uint64_t *__restrict__ qend, uint64_t n_cap, const uint64_t *__restrict__ n_dev, const uint64_t *__restrict__ abort,
+                      uint64_t *__restrict__ run_nums,
+                      uint64_t *__restrict__ first_item, uint64_t *__restrict__ need, uint64_t *__restrict__ big_list, uint64_t *__restrict__ large_list,
                       unsigned long long *__restrict__ n_big, unsigned long long *__restrict__ n_large, uint64_t *__restrict__ single,
                       uint64_t *__restrict__ ucount, unsigned long long *__restrict__ n_overflow, uint64_t *__restrict__ small_list,
                       unsigned long long *__restrict__ n_small) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (PGX_ABORTED(abort)) return;
+  const uint64_t n = PGX_DEV_COUNT(n_cap, n_dev);
+  __shared__ uint32_t s_cnt[PGX_TAG_LOCATE_THREADS / 64];
+  __shared__ unsigned long long s_base;
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += (uint64_t)gridDim.x * blockDim.x) { // (uniform per workgroup)
+    const uint64_t i = base + threadIdx.x;
     const bool valid = i < n; // no early return: the small list is appended to by whole waves
     uint64_t cnt = 0;
     if (valid) {
@@ -73,17 +86,14 @@ pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *__restrict__ mems, const u
         uint64_t p2 = 64;
         while (p2 < cnt && p2 < (1ull << 62)) p2 <<= 1;
         need[i] = p2 > PGX_SORT_WG_LDS_CAP ? p2 : 0; // global scratch of the large path
-        // one array, two lists: "big" grows from the front, "large" from the back (they cannot meet)
         if (cnt > PGX_SORT_LDS_CAP) {
-            big_list[n - 1 - atomicAdd(n_large, 1ull)] = i;
+            large_list[atomicAdd(n_large, 1ull)] = i;
             atomicMax(n_large + 1, (unsigned long long)cnt); // sizes the LDS of the large-path launch
         }
         else if (cnt > PGX_TAG_SMALL) big_list[atomicAdd(n_big, 1ull)] = i;
     }
     // queries with 2 .. 16 runs: a list of their own, so that the 16-lane kernels only see those.  One atomic per
     // 1024-thread workgroup: all of them hit one address, and one per wave (23 k for 1.5 M MEMs) cost 0.27 ms.
-    __shared__ uint32_t s_cnt[PGX_TAG_LOCATE_THREADS / 64];
-    __shared__ unsigned long long s_base;
     const bool is_small = valid && cnt >= 2 && cnt <= PGX_TAG_SMALL;
     const unsigned long long m = __ballot(is_small);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -96,15 +106,21 @@ pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *__restrict__ mems, const u
     }
     __syncthreads();
     if (is_small) small_list[s_base + s_cnt[wv] + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = i;
+    __syncthreads(); // s_cnt / s_base are reused by the next round
+  }
 }
 
 // 16 lanes per query, <= 16 runs: gather, sort, unique -> seg, ucount
 __global__ void __launch_bounds__(256)
-pgx_tag_small_kernel(PgxDevImage img, const uint64_t *__restrict__ list, uint64_t n, const uint64_t *__restrict__ run_nums,
+pgx_tag_small_kernel(PgxDevImage img, const uint64_t *__restrict__ list, uint64_t n_cap, const uint64_t *__restrict__ n_dev,
+                     const uint64_t *__restrict__ abort, const uint64_t *__restrict__ run_nums,
                      const uint64_t *__restrict__ first_item, const uint64_t *__restrict__ seg_off, uint64_t *__restrict__ buf,
                      uint64_t *__restrict__ ucount, unsigned long long *__restrict__ n_overflow) {
-    const uint64_t w16 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; // entry of the small list (2 .. 16 runs)
-    const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
+  if (PGX_ABORTED(abort)) return;
+  const uint64_t n = PGX_DEV_COUNT(n_cap, n_dev);
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
+  for (uint64_t wbase = ((uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) >> 4; wbase < n; wbase += ((uint64_t)gridDim.x * blockDim.x) >> 4) { // (uniform per wave)
+    const uint64_t w16 = wbase + (uint64_t)grp; // entry of the small list (2 .. 16 runs)
     const bool valid = w16 < n;
     const uint64_t q = valid ? list[w16] : 0;
     const uint64_t cnt = valid ? run_nums[q] : 0;
@@ -136,16 +152,19 @@ pgx_tag_small_kernel(PgxDevImage img, const uint64_t *__restrict__ list, uint64_
         ucount[q] = (uint64_t)__popc(gm);
         if ((omask >> (16 * grp)) & 0xFFFFull) atomicAdd(n_overflow, 1ull);
     }
+  }
 }
 
 // one wave per listed query: gather run values into its segment of `buf`
 __global__ void __launch_bounds__(256)
-pgx_tag_gather_kernel(PgxDevImage img, const uint64_t *__restrict__ list, uint64_t n_list, const uint64_t *__restrict__ run_nums,
+pgx_tag_gather_kernel(PgxDevImage img, const uint64_t *__restrict__ list, uint64_t n_cap, const uint64_t *__restrict__ n_dev,
+                      const uint64_t *__restrict__ abort, const uint64_t *__restrict__ run_nums,
                       const uint64_t *__restrict__ first_item, const uint64_t *__restrict__ seg_off, uint64_t *__restrict__ buf,
                       unsigned long long *__restrict__ n_overflow) {
-    const uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (w >= n_list) return;
+  if (PGX_ABORTED(abort)) return;
+  const uint64_t n_list = PGX_DEV_COUNT(n_cap, n_dev);
+  const int lane = threadIdx.x & 63;
+  for (uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n_list; w += ((uint64_t)gridDim.x * blockDim.x) >> 6) {
     const uint64_t q = list[w];
     const uint64_t cnt = run_nums[q], src = first_item[q], dst = seg_off[q];
     bool over = false;
@@ -156,6 +175,7 @@ pgx_tag_gather_kernel(PgxDevImage img, const uint64_t *__restrict__ list, uint64
         buf[dst + t] = v;
     }
     if (__any(over) && lane == 0) atomicAdd(n_overflow, 1ull);
+  }
 }
 
 // bitonic sort of cnt values (padded to p2 with ~0) by ONE wave in `arr`, then duplicates dropped
@@ -196,12 +216,14 @@ __device__ __forceinline__ uint64_t pgx_wave_sort_unique(Ptr arr, uint64_t *__re
 
 // one wave per listed query: sort its segment and drop duplicates in place; ucount[q] = #unique
 __global__ void __launch_bounds__(256)
-pgx_tag_sort_unique_kernel(const uint64_t *__restrict__ list, uint64_t n_list, const uint64_t *__restrict__ run_nums,
+pgx_tag_sort_unique_kernel(const uint64_t *__restrict__ list, uint64_t n_cap, const uint64_t *__restrict__ n_dev, const uint64_t *__restrict__ abort,
+                           const uint64_t *__restrict__ run_nums,
                            const uint64_t *__restrict__ seg_off, uint64_t *__restrict__ buf, uint64_t *__restrict__ ucount) {
-    __shared__ uint64_t s_sort[4][PGX_SORT_LDS_CAP];
-    const uint64_t wi = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (wi >= n_list) return;
+  __shared__ uint64_t s_sort[4][PGX_SORT_LDS_CAP];
+  if (PGX_ABORTED(abort)) return;
+  const uint64_t n_list = PGX_DEV_COUNT(n_cap, n_dev);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (uint64_t wi = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; wi < n_list; wi += ((uint64_t)gridDim.x * blockDim.x) >> 6) {
     const uint64_t q = list[wi];
     const uint64_t cnt = run_nums[q];
     uint64_t *seg = buf + seg_off[q];
@@ -223,12 +245,13 @@ pgx_tag_sort_unique_kernel(const uint64_t *__restrict__ list, uint64_t n_list, c
         const int at = __popcll(mask & ((1ull << lane) - 1ull));
         if (keep) seg[at] = v;
         if (lane == 0) ucount[q] = (uint64_t)__popcll(mask);
-        return;
+        continue;
     }
     uint64_t p2 = 64;
     while (p2 < cnt) p2 <<= 1;
     const uint64_t outn = pgx_wave_sort_unique(&s_sort[w][0], seg, cnt, p2, lane); // cnt <= PGX_SORT_LDS_CAP by construction
     if (lane == 0) ucount[q] = outn;
+  }
 }
 
 // bitonic sort of cnt values (padded to p2 with ~0) by ONE workgroup in `arr` (LDS or global
@@ -275,85 +298,130 @@ __device__ __forceinline__ uint64_t pgx_block_sort_unique(Ptr arr, uint64_t *__r
 
 // one 1024-thread workgroup per listed query with more than PGX_SORT_LDS_CAP runs
 __global__ void __launch_bounds__(1024)
-pgx_tag_sort_large_kernel(const uint64_t *__restrict__ list, uint64_t n_list, const uint64_t *__restrict__ run_nums,
+pgx_tag_sort_large_kernel(const uint64_t *__restrict__ list, uint64_t n_cap, const uint64_t *__restrict__ n_dev, const uint64_t *__restrict__ abort,
+                          const uint64_t *__restrict__ run_nums,
                           const uint64_t *__restrict__ seg_off, uint64_t *__restrict__ buf, uint64_t *__restrict__ scratch,
                           const uint64_t *__restrict__ scratch_off, uint64_t *__restrict__ ucount) {
     extern __shared__ __align__(16) uint64_t pgx_sort_lds[]; // PGX_SORT_WG_LDS_CAP values
     __shared__ uint32_t s_wsum[16];
-    if (blockIdx.x >= n_list) return;
-    const uint64_t q = list[blockIdx.x];
-    const uint64_t cnt = run_nums[q];
-    uint64_t *seg = buf + seg_off[q];
-    uint64_t p2 = 64;
-    while (p2 < cnt) p2 <<= 1;
-    uint64_t outn;
-    if (p2 <= PGX_SORT_WG_LDS_CAP) outn = pgx_block_sort_unique(&pgx_sort_lds[0], seg, cnt, p2, s_wsum);
-    else outn = pgx_block_sort_unique(scratch + scratch_off[q], seg, cnt, p2, s_wsum);
-    if (threadIdx.x == 0) ucount[q] = outn;
+    if (PGX_ABORTED(abort)) return;
+    const uint64_t n_list = PGX_DEV_COUNT(n_cap, n_dev);
+    for (uint64_t e = blockIdx.x; e < n_list; e += gridDim.x) {
+        const uint64_t q = list[e];
+        const uint64_t cnt = run_nums[q];
+        uint64_t *seg = buf + seg_off[q];
+        uint64_t p2 = 64;
+        while (p2 < cnt) p2 <<= 1;
+        uint64_t outn;
+        if (p2 <= PGX_SORT_WG_LDS_CAP) outn = pgx_block_sort_unique(&pgx_sort_lds[0], seg, cnt, p2, s_wsum);
+        else outn = pgx_block_sort_unique(scratch + scratch_off[q], seg, cnt, p2, s_wsum);
+        if (threadIdx.x == 0) ucount[q] = outn;
+        __syncthreads();
+    }
 }
 
 // 16 lanes per query: copy the unique prefix of its segment to the dense positions array.  Segments with more than
 // `max_count` values are left to pgx_tag_compact_list_kernel (a few huge segments would otherwise keep 16 lanes busy
 // for thousands of iterations while the rest of the grid has finished).
 __global__ void __launch_bounds__(256)
-pgx_tag_compact_kernel(const uint64_t *__restrict__ list, uint64_t n, const uint64_t *__restrict__ ucount, const uint64_t *__restrict__ seg_off,
+pgx_tag_compact_kernel(const uint64_t *__restrict__ list, uint64_t n_cap, const uint64_t *__restrict__ n_dev, const uint64_t *__restrict__ abort,
+                       const uint64_t *__restrict__ ucount, const uint64_t *__restrict__ seg_off,
                        const uint64_t *__restrict__ buf, const uint64_t *__restrict__ pos_off, uint64_t *__restrict__ positions,
                        uint64_t max_count) {
-    const uint64_t w16 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (PGX_ABORTED(abort)) return;
+    const uint64_t n = PGX_DEV_COUNT(n_cap, n_dev);
     const int l16 = threadIdx.x & 15;
-    if (w16 >= n) return;
-    const uint64_t q = list ? list[w16] : w16; // a list of queries (small / big / large), or all of them
-    const uint64_t c = ucount[q], src = seg_off[q], dst = pos_off[q];
-    if (c > max_count) return;
-    for (uint64_t t = l16; t < c; t += 16) positions[dst + t] = buf[src + t];
+    for (uint64_t w16 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; w16 < n; w16 += ((uint64_t)gridDim.x * blockDim.x) >> 4) {
+        const uint64_t q = list ? list[w16] : w16; // a list of queries (small / big / large), or all of them
+        const uint64_t c = ucount[q], src = seg_off[q], dst = pos_off[q];
+        if (c > max_count) continue;
+        for (uint64_t t = l16; t < c; t += 16) positions[dst + t] = buf[src + t];
+    }
 }
 
 // one thread per query: single-run queries (answered by the locate kernel) go straight to their place
 __global__ void __launch_bounds__(256)
-pgx_tag_compact_single_kernel(uint64_t n, const uint64_t *__restrict__ run_nums, const uint64_t *__restrict__ single,
-                              const uint64_t *__restrict__ pos_off, uint64_t *__restrict__ positions) {
-    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n || run_nums[q] != 1) return;
-    positions[pos_off[q]] = single[q];
+pgx_tag_compact_single_kernel(uint64_t n_cap, const uint64_t *__restrict__ n_dev, const uint64_t *__restrict__ abort, const uint64_t *__restrict__ run_nums,
+                              const uint64_t *__restrict__ single, const uint64_t *__restrict__ pos_off, uint64_t *__restrict__ positions) {
+    if (PGX_ABORTED(abort)) return;
+    const uint64_t n = PGX_DEV_COUNT(n_cap, n_dev);
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (uint64_t)gridDim.x * blockDim.x)
+        if (run_nums[q] == 1) positions[pos_off[q]] = single[q];
 }
 
 // one workgroup per listed query: the segments pgx_tag_compact_kernel skipped (more than `max_count` values)
 __global__ void __launch_bounds__(256)
-pgx_tag_compact_list_kernel(const uint64_t *__restrict__ list, uint64_t n_list, const uint64_t *__restrict__ ucount,
+pgx_tag_compact_list_kernel(const uint64_t *__restrict__ list, uint64_t n_cap, const uint64_t *__restrict__ n_dev, const uint64_t *__restrict__ abort,
+                            const uint64_t *__restrict__ ucount,
                             const uint64_t *__restrict__ seg_off, const uint64_t *__restrict__ buf, const uint64_t *__restrict__ pos_off,
                             uint64_t *__restrict__ positions, uint64_t max_count) {
-    if (blockIdx.x >= n_list) return;
-    const uint64_t q = list[blockIdx.x];
-    const uint64_t c = ucount[q], src = seg_off[q], dst = pos_off[q];
-    if (c <= max_count) return;
-    for (uint64_t t = threadIdx.x; t < c; t += blockDim.x) positions[dst + t] = buf[src + t];
+    if (PGX_ABORTED(abort)) return;
+    const uint64_t n_list = PGX_DEV_COUNT(n_cap, n_dev);
+    for (uint64_t e = blockIdx.x; e < n_list; e += gridDim.x) {
+        const uint64_t q = list[e];
+        const uint64_t c = ucount[q], src = seg_off[q], dst = pos_off[q];
+        if (c <= max_count) continue;
+        for (uint64_t t = threadIdx.x; t < c; t += blockDim.x) positions[dst + t] = buf[src + t];
+    }
 }
 
-// (query id, first item, run count) of every listed query -> host, which groups identical queries
+// Identical large queries are common (every read from the same repeat / N run yields the same SA interval): one representative
+// per distinct (first item, run count) is sorted, the others copy its result.  Grouping on the device: open addressing over
+// `table` (zeroed by the host, a power of two of slots >= 2 x the list), slot = 1 + the query id of the first query that claimed it;
+// whichever duplicate wins the slot becomes the representative -- their results are identical, so the output does not depend on it.
 __global__ void __launch_bounds__(256)
-pgx_tag_list_fetch_kernel(const uint64_t *__restrict__ list, uint64_t n_list, const uint64_t *__restrict__ first_item,
-                          const uint64_t *__restrict__ run_nums, uint64_t *__restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_list) return;
-    const uint64_t q = list[i];
-    out[3 * i] = q;
-    out[3 * i + 1] = first_item[q];
-    out[3 * i + 2] = run_nums[q];
+pgx_tag_dedup_kernel(const uint64_t *__restrict__ list, uint64_t n_cap, const uint64_t *__restrict__ n_dev, const uint64_t *__restrict__ abort,
+                     const uint64_t *__restrict__ first_item, const uint64_t *__restrict__ run_nums, unsigned long long *__restrict__ table,
+                     uint64_t table_mask, uint64_t *__restrict__ reps, unsigned long long *__restrict__ n_rep, uint64_t *__restrict__ pairs,
+                     unsigned long long *__restrict__ n_dup) {
+    if (PGX_ABORTED(abort)) return;
+    const uint64_t n_list = PGX_DEV_COUNT(n_cap, n_dev);
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_list; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t q = list[e], f = first_item[q], c = run_nums[q];
+        uint64_t h = (f * 0x9E3779B97F4A7C15ull ^ c * 0xC2B2AE3D27D4EB4Full) & table_mask;
+        for (;; h = (h + 1) & table_mask) {
+            const unsigned long long prev = atomicCAS(&table[h], 0ull, (unsigned long long)(q + 1));
+            if (prev == 0ull) { reps[atomicAdd(n_rep, 1ull)] = q; break; }
+            const uint64_t r = (uint64_t)prev - 1;
+            if (first_item[r] == f && run_nums[r] == c) {
+                const unsigned long long at = atomicAdd(n_dup, 1ull);
+                pairs[2 * at] = q; pairs[2 * at + 1] = r;
+                break;
+            }
+        }
+    }
 }
 
 // one workgroup per (duplicate, representative) pair: the duplicate query reads exactly the same items, so
 // its sorted unique result is the representative's (and it overflows iff the representative does)
 __global__ void __launch_bounds__(256)
-pgx_tag_copy_dups_kernel(const uint64_t *__restrict__ pairs, uint64_t n_pairs, uint64_t n_tag_items,
+pgx_tag_copy_dups_kernel(const uint64_t *__restrict__ pairs, uint64_t n_cap, const uint64_t *__restrict__ n_dev, const uint64_t *__restrict__ abort,
+                         uint64_t n_tag_items,
                          const uint64_t *__restrict__ first_item, const uint64_t *__restrict__ run_nums,
                          const uint64_t *__restrict__ seg_off, uint64_t *__restrict__ buf, uint64_t *__restrict__ ucount,
                          unsigned long long *__restrict__ n_overflow) {
-    if (blockIdx.x >= n_pairs) return;
-    const uint64_t dup = pairs[2 * blockIdx.x], rep = pairs[2 * blockIdx.x + 1];
-    const uint64_t c = ucount[rep], src = seg_off[rep], dst = seg_off[dup];
-    for (uint64_t t = threadIdx.x; t < c; t += blockDim.x) buf[dst + t] = buf[src + t];
-    if (threadIdx.x == 0) {
-        ucount[dup] = c;
-        if (first_item[dup] + run_nums[dup] > n_tag_items) atomicAdd(n_overflow, 1ull);
+    if (PGX_ABORTED(abort)) return;
+    const uint64_t n_pairs = PGX_DEV_COUNT(n_cap, n_dev);
+    for (uint64_t e = blockIdx.x; e < n_pairs; e += gridDim.x) {
+        const uint64_t dup = pairs[2 * e], rep = pairs[2 * e + 1];
+        const uint64_t c = ucount[rep], src = seg_off[rep], dst = seg_off[dup];
+        for (uint64_t t = threadIdx.x; t < c; t += blockDim.x) buf[dst + t] = buf[src + t];
+        if (threadIdx.x == 0) {
+            ucount[dup] = c;
+            if (first_item[dup] + run_nums[dup] > n_tag_items) atomicAdd(n_overflow, 1ull);
+        }
     }
+}
+
+// capacity check of a speculatively sized stage: raises the abort flag when a count the following kernels rely on exceeds what
+// their buffers were sized for (the host then repeats the run with exact sizes)
+__global__ void pgx_spec_check_kernel(const uint64_t *__restrict__ v0, uint64_t c0, const uint64_t *__restrict__ v1, uint64_t c1,
+                                      const uint64_t *__restrict__ v2, uint64_t c2, const uint64_t *__restrict__ v3, uint64_t c3, uint64_t *__restrict__ abort) {
+    if (threadIdx.x) return;
+    unsigned long long bits = 0;
+    if (v0 && *v0 > c0) bits |= 1ull;
+    if (v1 && *v1 > c1) bits |= 2ull;
+    if (v2 && *v2 > c2) bits |= 4ull;
+    if (v3 && *v3 > c3) bits |= 8ull;
+    if (bits) atomicOr((unsigned long long *)abort, bits);
 }

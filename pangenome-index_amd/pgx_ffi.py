@@ -130,6 +130,7 @@ def lib():
     L.pgx_batch_counts.argtypes = [p, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.pgx_batch_device_result.argtypes = [p, C.POINTER(DeviceResult)]
     L.pgx_batch_timing.argtypes = [p, C.POINTER(Timing)]
+    L.pgx_batch_spec_stats.argtypes = [p, C.POINTER(u32), C.POINTER(u32)]
     L.pgx_batch_free.argtypes = [p]
     L.pgx_batch_free.restype = None
     L.pgx_find_mems_batch.argtypes = [p, C.c_int, p, p, u64, u64, u64, u32, C.POINTER(p), C.POINTER(Result)]
@@ -446,6 +447,12 @@ class Batch:
         a, b_, c = u64(0), u64(0), u64(0)
         _check(self.L.pgx_batch_counts(self.b, C.byref(a), C.byref(b_), C.byref(c)))
         return a.value, b_.value, c.value
+
+    def spec_stats(self):
+        """(runs sized speculatively, of which repeated with exact sizes)"""
+        a, f = u32(0), u32(0)
+        _check(self.L.pgx_batch_spec_stats(self.b, C.byref(a), C.byref(f)))
+        return a.value, f.value
 
     def timing(self):
         t = Timing()

@@ -1,0 +1,108 @@
+"""Speculative sizing of pgx_batch_run (pgx_runtime.hip): a run whose predecessor on the same batch had the same shape takes its
+buffer sizes from that run, keeps every count on the device and synchronises once at the end; when a capacity turns out too
+small the run is repeated with exact sizes.  Either way the results are those of the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import pgx_ffi as P
+import pgx_workload as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(res, ref):
+    assert np.array_equal(res["mem_offsets"], ref["mem_offsets"])
+    assert res["mems"].tobytes() == ref["mems"].tobytes()
+    assert res["n_extensions"] == ref["n_extensions"]
+    assert np.array_equal(res["tag_run_counts"], ref["tag_run_counts"])
+    assert np.array_equal(res["pos_offsets"], ref["pos_offsets"])
+    assert np.array_equal(res["positions"], ref["positions"])
+    assert res["n_tag_overflow"] == ref["n_tag_overflow"]
+
+
+@pytest.fixture(scope="module")
+def pan(workdir):
+    text = os.path.join(workdir, "specpan.txt")
+    W.synth_pangenome_text(text, base_len=150000, n_hap=4, seed=41, n_runs=3, n_run_len=(2000, 6000))  # N runs: huge tag queries, many identical
+    ri_path, tags_path = W.build_index_from_text(text, workdir, "specpan")[:2]
+    return ri_path, tags_path, W.load_sequences(text), O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+
+
+@pytest.mark.parametrize("force", [0, P.MODE_IMAGE_DENSE, P.MODE_IMAGE_RL])
+def test_repeated_runs_are_speculative_and_exact(pan, force):
+    ri_path, tags_path, seqs, ri, tags = pan
+    idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | force)
+    cat, offs = W.sample_reads(seqs, 30000, 150, seed=3)
+    ref = O.find_mems_batch(ri, tags, cat, offs, 20, 1, threads=O.lib().orc_max_threads())
+    assert int(ref["tag_run_counts"].max()) > 2048  # the large path and its device-side grouping of identical queries are exercised
+    b = idx.batch(cat, offs)
+    for k in range(4):
+        b.run(20, 1, P.RUN_TAGS | P.RUN_TIMING)
+        _same(b.result(), ref)
+        assert b.counts() == (len(ref["mems"]), len(ref["positions"]), ref["n_extensions"])
+    assert b.spec_stats() == (3, 0)  # every run after the first: no mid-run read-back, nothing repeated
+    # without tags, and with other parameters: the shape changes, the first such run is exact again
+    b.run(20, 1, 0)
+    b.run(20, 1, 0)
+    assert b.result()["mems"].tobytes() == ref["mems"].tobytes() and b.spec_stats() == (4, 0)
+    ref2 = O.find_mems_batch(ri, tags, cat, offs, 12, 2, threads=O.lib().orc_max_threads())
+    for k in range(2):
+        b.run(12, 2, P.RUN_TAGS)
+        _same(b.result(), ref2)
+    assert b.spec_stats() == (5, 0)
+    b.free()
+    idx.close()
+
+
+def test_capacity_too_small_falls_back(pan):
+    """same number of reads, same parameters, but the new reads produce far more MEMs / positions than the sizes taken from the
+    previous run allow: the speculative run aborts on the device and is repeated exactly"""
+    ri_path, tags_path, seqs, ri, tags = pan
+    idx = P.Index(ri_path, tags_path)
+    n = 20000
+    rng = np.random.default_rng(5)
+    junk = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n * 150)]  # random reads: hardly any MEM of 20
+    offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(150)
+    real, _ = W.sample_reads(seqs, n, 150, seed=9)
+    ref_junk = O.find_mems_batch(ri, tags, junk, offs, 20, 1, threads=O.lib().orc_max_threads())
+    ref_real = O.find_mems_batch(ri, tags, real, offs, 20, 1, threads=O.lib().orc_max_threads())
+    assert len(ref_real["mems"]) > 4 * len(ref_junk["mems"]) + 1000
+    b = idx.batch(junk, offs)
+    b.run(20, 1, P.RUN_TAGS)
+    _same(b.result(), ref_junk)
+    b.upload(real, offs)
+    b.run(20, 1, P.RUN_TAGS)  # speculative with the junk batch's sizes -> abort -> exact
+    _same(b.result(), ref_real)
+    assert b.spec_stats() == (1, 1)
+    b.run(20, 1, P.RUN_TAGS)  # now the sizes fit
+    _same(b.result(), ref_real)
+    b.upload(junk, offs)
+    b.run(20, 1, P.RUN_TAGS)  # fewer than predicted: fits as well
+    _same(b.result(), ref_junk)
+    assert b.spec_stats() == (3, 1)
+    b.free()
+    idx.close()
+
+
+def test_switched_off_and_chunked(pan, monkeypatch):
+    ri_path, tags_path, seqs, ri, tags = pan
+    idx = P.Index(ri_path, tags_path)
+    cat, offs = W.sample_reads(seqs, 12000, 150, seed=4)
+    ref = O.find_mems_batch(ri, tags, cat, offs, 20, 1, threads=O.lib().orc_max_threads())
+    monkeypatch.setenv("PGX_SPEC", "0")
+    b = idx.batch(cat, offs)
+    for k in range(3):
+        b.run(20, 1, P.RUN_TAGS)
+        _same(b.result(), ref)
+    assert b.spec_stats() == (0, 0)
+    monkeypatch.delenv("PGX_SPEC")
+    monkeypatch.setenv("PGX_SLOT_BUDGET_MB", "8")  # several chunks of reads: every chunk is sized exactly
+    for k in range(2):
+        b.run(20, 1, P.RUN_TAGS)
+        _same(b.result(), ref)
+    assert b.spec_stats() == (0, 0)
+    b.free()
+    idx.close()
