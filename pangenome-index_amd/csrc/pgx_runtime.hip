@@ -287,6 +287,7 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
     const uint64_t *dn_small = spec ? u_sc + 5 : nullptr, *dn_big = spec ? u_sc + 0 : nullptr, *dn_large = spec ? u_sc + 1 : nullptr;
     const uint64_t *dn_rep = spec ? u_sc + 6 : nullptr, *dn_dup = spec ? u_sc + 7 : nullptr;
     const uint64_t *ab = spec ? d_abort : nullptr;
+    if (!spec) d_m = nullptr; // exact mode: m is the count
     auto fixed_grid = [](uint64_t n, unsigned per_block, unsigned max_blocks) { return (unsigned)std::min<uint64_t>(std::max<uint64_t>((n + per_block - 1) / per_block, 1), max_blocks); };
     if (m) {
         const unsigned g = spec ? fixed_grid(m, PGX_TAG_LOCATE_THREADS, 8192) : grid_for(m, PGX_TAG_LOCATE_THREADS);
@@ -301,6 +302,8 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
         uint64_t hv[6] = {0, 0, 0, 0, 0, 0};
         read_scalars(hv, sc, 48, s);
         G = hv[3]; nbig = hv[0]; nlarge = hv[1]; nsmall = hv[5]; largest = hv[2];
+        if (std::getenv("PGX_DEBUG_COUNTERS")) std::fprintf(stderr, "[pgx] tag stage: m %llu big %llu large %llu largest %llu G %llu small %llu\n", (unsigned long long)m,
+                                                            (unsigned long long)nbig, (unsigned long long)nlarge, (unsigned long long)largest, (unsigned long long)G, (unsigned long long)nsmall);
     } else { // capacities from the previous run; the device checks what it can before anything is written through them
         G = with_slack(w.last_G); nbig = with_slack(w.last_big); nlarge = with_slack(w.last_large); nsmall = with_slack(w.last_small);
         // the large path sorts in dynamic LDS sized for the largest run count: twice the last one (a power of two), at most the
@@ -363,6 +366,7 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
             uint64_t rd[2] = {0, 0};
             read_scalars(rd, sc + 6, 16, s);
             nrep = rd[0]; ndup = rd[1];
+            if (std::getenv("PGX_DEBUG_COUNTERS")) std::fprintf(stderr, "[pgx] tag stage: representatives %llu duplicates %llu\n", (unsigned long long)nrep, (unsigned long long)ndup);
         } else { nrep = nlarge; ndup = nlarge; } // (capacities: the lists cannot be longer than the large list)
         if (nrep) {
             hipLaunchKernelGGL(pgx_tag_gather_kernel, dim3(spec ? fixed_grid(nrep, 4, 8192) : grid_for(nrep, 4)), dim3(256), 0, s, img, (const uint64_t *)d_reps, nrep,
