@@ -512,7 +512,11 @@ static uint32_t choose_image(const RiFile &ri, uint32_t mode_bits, const PgxCons
     // tiny BWTs: the 64-byte layout, staged in LDS by the kernels (cheapest decode; pgx_runtime.hip: 80 padded bytes per block)
     const uint64_t dense_blocks = (c.n >> 6) + 1;
     if (dense_blocks * 80 + 16 <= 48 * 1024) return PGX_IMAGE_DENSE;
-    // everything else below 2^32 symbols: one 128-byte line per probe, n / 3 bytes (cache resident up to chromosome scale)
+    // the 64-byte layout while it stays resident in the 256 MB memory-side cache (cheapest decode: n = 64 M, 1 M reads: 3.1 ms
+    // against 4.4 ms with dense2); beyond that dense2 up to 2^32 symbols: n / 3 bytes, cache resident up to chromosome scale
+    // (n = 640 M, 10 M reads: 30 ms against 36 ms with the 64-byte layout served from HBM)
+    const uint64_t dense_bytes0 = dense_blocks * PGX_BLOCK_BYTES;
+    if (dense_bytes0 <= (224ull << 20)) return PGX_IMAGE_DENSE;
     if (!(c.n >> 32)) return PGX_IMAGE_DENSE2;
     uint64_t runs = 0;
     for (const auto &b : ri.blocks) runs += b.runs.size();

@@ -78,14 +78,14 @@ static void upload(DevBuf &b, const void *src, size_t bytes) {
 }
 
 // k-mer seed table of a dense image in global memory (pgx_kernels.hip "k-mer seeds"): built level by level on the device,
-// 4^L entries at level L, each one pgx_extend of its parent.  K = log4(n) - 1, at most 13 (1 GiB of table; chr22 scale, 10 M reads:
-// K = 11 / 12 / 13 / 14: 41.2 / 39.1 / 37.2 / 36.4 ms with the 64-byte dense image), PGX_SEED_K overrides (0 = no table, at most 14).
+// 4^L entries at level L, each one pgx_extend of its parent.  K = floor(log4 n), at most 14 (4 GiB of table; chr22 scale, 10 M
+// reads, K = 11 / 12 / 13 / 14: 41.2 / 39.1 / 37.2 / 36.4 ms with the 64-byte dense image; n = 64 M, 1 M reads, K = 0 / 9 / 11 / 12: 3.64 / 3.44 /
+// 3.14 / 3.07 ms), PGX_SEED_K overrides (0 = no table).
 static void build_seed_table(pgx_device_image *d) {
     PgxDevImage &g = d->img;
     int K = 0;
     for (uint64_t v = g.n; v >= 4; v >>= 2) K++;
-    K -= 1;
-    if (K > 13) K = 13;
+    if (K > 14) K = 14;
     if (const char *e = std::getenv("PGX_SEED_K")) K = std::atoi(e);
     if (K > PGX_SEED_MAX_K) K = PGX_SEED_MAX_K;
     if (K < 2) return;

@@ -472,6 +472,13 @@ class Batch:
             out["positions"] = _u64_array(r.positions, int(r.n_positions))
         return out
 
+    def result_counts(self):
+        """pgx_batch_result without copying the arrays into numpy: the download into the batch's pinned host buffers happens,
+        the (n_mems, n_positions) of the result are returned (the PCIe-inclusive timing of bench.py)"""
+        r = Result()
+        _check(self.L.pgx_batch_result(self.b, C.byref(r)))
+        return int(r.n_mems), int(r.n_positions)
+
     def device_result(self):
         """results of the last run as device arrays (valid until the next run / upload / free): mem_offsets int64[n + 1],
         mems int64[n_mems, 4] (start, end, bwt_start, size), and with tags tag_run_counts / pos_offsets / positions"""

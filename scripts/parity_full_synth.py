@@ -20,7 +20,7 @@ r, t = O.RIndex(ri), O.Tags(tags, O.TAGS_COMPACT)
 t0 = time.time()
 ref = O.find_mems_batch(r, t, cat, offs, 20, 1, threads=O.lib().orc_max_threads())
 print("oracle: %.1f s, %d MEMs, %d positions, %d extensions" % (time.time() - t0, len(ref["mems"]), len(ref["positions"]), ref["n_extensions"]), flush=True)
-for name, force in (("automatic (dense2 + seed table)", 0), ("dense", P.MODE_IMAGE_DENSE), ("run-length", P.MODE_IMAGE_RL)):
+for name, force in (("automatic", 0), ("dense2", P.MODE_IMAGE_DENSE2), ("dense", P.MODE_IMAGE_DENSE), ("run-length", P.MODE_IMAGE_RL)):
     idx = P.Index(ri, tags, mode=P.MODE_COMPAT | force)
     res = idx.find_mems(cat, offs, 20, 1, tags=True)
     ok = (np.array_equal(res["mem_offsets"], ref["mem_offsets"]) and res["mems"].tobytes() == ref["mems"].tobytes()

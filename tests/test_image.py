@@ -123,8 +123,8 @@ def test_long_runs_split_and_merge(workdir):
         if exp is not None:
             assert tri[2] == exp, p
         assert emu.count(p) == ri.count(p)
-    # the same index as bit planes: dense2 is the automatic choice at this size (n = 189 k), dense (64-byte blocks) forced
-    for force, kind in ((0, P.IMAGE_DENSE2), (P.MODE_IMAGE_DENSE, P.IMAGE_DENSE)):
+    # the same index as bit planes: dense (64-byte blocks) is the automatic choice while it fits the memory-side cache, dense2 forced
+    for force, kind in ((P.MODE_IMAGE_DENSE2, P.IMAGE_DENSE2), (0, P.IMAGE_DENSE)):
         idx2 = P.Index(ri_path, mode=force)
         assert idx2.info().image_kind == kind and not idx2.info().image_in_lds
         emu2 = ImageEmu(idx2)
@@ -133,7 +133,7 @@ def test_long_runs_split_and_merge(workdir):
         for p in ["A" * 100, "GACGT", "TTTTTG", "N" * 300, "NNNNA"]:
             assert emu2.count(p) == ri.count(p)
     # the N run (40 000 symbols) is a handful of exception runs per 384-symbol block, not one per symbol
-    assert len(idx2.image_view(0)) // 64 > 100 and len(P.Index(ri_path).image_view(15)) < 2 * (n // 384 + 1)
+    assert len(idx2.image_view(0)) // 64 > 100 and len(P.Index(ri_path, mode=P.MODE_IMAGE_DENSE2).image_view(15)) < 2 * (n // 384 + 1)
 
 
 def test_image_layout_choice(workdir, built):
