@@ -220,22 +220,27 @@ def main():
     import torch
     import torch.distributed as dist
 
-    if world > 1:
+    # under a launcher (WORLD_SIZE set) the process group is created even for one rank: the same RCCL barrier / all-reduce code
+    # runs at N = 1 as at N = 8
+    use_dist = "WORLD_SIZE" in os.environ
+    if use_dist and not args.stub_workload and args.dist_backend == "nccl":
+        torch.cuda.set_device(0 if args.one_device else local)
+    if use_dist:
         dist.init_process_group(args.dist_backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=40))
     red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     if args.stub_workload:  # launcher self-test (CPU tier): no GPU, the line still goes through the same reductions
         ones = torch.ones(1, dtype=torch.float64)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(ones)
         if rank == 0:
             print(json.dumps({"metric": "stub", "value": float(world), "unit": "ranks", "n_gpus": world, "n_ranks_seen": int(ones.item()),
                               "steps": args.steps, "warmup": args.warmup}), flush=True)
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -248,7 +253,7 @@ def main():
     torch.cuda.set_device(local)
     # RCCL (or gloo in a rehearsal) sees every rank: sum of ones
     ones = torch.ones(1, dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(ones)
     n_ranks_seen = int(ones.item())
 
@@ -276,12 +281,12 @@ def main():
 
     batch, dt, k_ms, counts = measure(P, idx, cat, offs, local, args.min_len, args.min_occ, flags, args.steps, args.warmup, stream,
                                       torch.cuda.synchronize, barrier)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     tot = torch.tensor([float(c) for c in counts], dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     tot = [float(v) for v in tot.tolist()]
 
@@ -337,7 +342,7 @@ def main():
             line["secondary"] = secondary_x(args, P, wd, local, stream, torch)
         print(json.dumps(line), flush=True)
     barrier()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     if own_tmp and rank == 0:
         import shutil
@@ -466,7 +471,7 @@ def run_chrom(args, rank, world, local, wd, barrier, dist, red_dev):
     for b in batches.values():
         b.free()
     barrier()
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:
         dist.destroy_process_group()
 
 
