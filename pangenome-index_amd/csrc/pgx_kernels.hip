@@ -498,7 +498,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     pgx_stage_tables<LDS_IMAGE>(img, s_ext, s_C, lds_blocks, lds_dir, lds_blow);
 
     static_assert(!NARROW || DENSE, "the 32-bit state exists for the dense image only");
-    static_assert(!SEED || (DENSE && !LDS_IMAGE), "k-mer seeds exist for dense images in global memory");
+    static_assert(!SEED || DENSE, "k-mer seeds exist for the dense images");
     static_assert(DENSE != 2 || !LDS_IMAGE, "the dense2 image is never staged in LDS");
     typedef typename std::conditional<NARROW, uint32_t, uint64_t>::type pos_t;
     const int lane = threadIdx.x & 63;
@@ -788,6 +788,12 @@ template __global__ void pgx_find_mems_kernel<true, 1, false, false>(PgxDevImage
                                                             const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
                                                             uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
 template __global__ void pgx_find_mems_kernel<true, 1, true, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
+                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
+template __global__ void pgx_find_mems_kernel<true, 1, false, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
+                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
+                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
+template __global__ void pgx_find_mems_kernel<true, 1, true, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
                                                             const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
                                                             uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
 template __global__ void pgx_find_mems_kernel<false, 1, true, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,

@@ -77,7 +77,7 @@ static void upload(DevBuf &b, const void *src, size_t bytes) {
     if (bytes) HIPCHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
 }
 
-// k-mer seed table of a dense image in global memory (pgx_kernels.hip "k-mer seeds"): built level by level on the device,
+// k-mer seed table of a dense image (pgx_kernels.hip "k-mer seeds"): built level by level on the device,
 // 4^L entries at level L, each one pgx_extend of its parent.  K = floor(log4 n), at most 14 (4 GiB of table; chr22 scale, 10 M
 // reads, K = 11 / 12 / 13 / 14: 41.2 / 39.1 / 37.2 / 36.4 ms with the 64-byte dense image; n = 64 M, 1 M reads, K = 0 / 9 / 11 / 12: 3.64 / 3.44 /
 // 3.14 / 3.07 ms), PGX_SEED_K overrides (0 = no table).
@@ -86,6 +86,9 @@ static void build_seed_table(pgx_device_image *d) {
     int K = 0;
     for (uint64_t v = g.n; v >= 4; v >>= 2) K++;
     if (K > 14) K = 14;
+    // an image small enough for LDS leaves the loop bound by instruction issue, and every extension a seed replaces is a gain: depth 10
+    // (16 MiB of table, hot in L2) whatever n is (x index, 1 M reads, min_len 10, K = 0 / 4 / 6 / 8 / 10: 1.22 / 1.03 / 0.81 / 0.72 / 0.59 ms)
+    if (d->lds_bytes) K = 10;
     if (const char *e = std::getenv("PGX_SEED_K")) K = std::atoi(e);
     if (K > PGX_SEED_MAX_K) K = PGX_SEED_MAX_K;
     if (K < 2) return;
@@ -151,7 +154,7 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
     d->lds_bytes = (g.dense != 2 && img_bytes <= 48 * 1024) ? ((img_bytes + 15) & ~(size_t)15) : 0; // the dense2 image is never staged in LDS
     g.seed_k = 0;
     g.seed = nullptr;
-    if (g.dense && !d->lds_bytes && h->has_rank) build_seed_table(d.get());
+    if (g.dense && h->has_rank) build_seed_table(d.get());
     h->dev[device] = d.release();
     return h->dev[device];
 }
@@ -998,7 +1001,8 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         // dependency exists, so any grid size is correct; this one avoids a tail of late blocks)
         const bool in_lds = b->dimg->lds_bytes != 0, dense = img.dense != 0, d2 = img.dense == 2;
         const bool seeded = img.seed_k != 0 && min_len >= img.seed_k; // (no stage of a shorter search has room for a seed)
-        kfn_wide = in_lds ? (dense ? (const void *)pgx_find_mems_kernel<true, 1, false, false> : (const void *)pgx_find_mems_kernel<true, 0, false, false>)
+        kfn_wide = in_lds ? (dense ? (seeded ? (const void *)pgx_find_mems_kernel<true, 1, false, true> : (const void *)pgx_find_mems_kernel<true, 1, false, false>)
+                                   : (const void *)pgx_find_mems_kernel<true, 0, false, false>)
                    : d2   ? (seeded ? (const void *)pgx_find_mems_kernel<false, 2, false, true> : (const void *)pgx_find_mems_kernel<false, 2, false, false>)
                           : (dense ? (seeded ? (const void *)pgx_find_mems_kernel<false, 1, false, true> : (const void *)pgx_find_mems_kernel<false, 1, false, false>)
                                    : (const void *)pgx_find_mems_kernel<false, 0, false, false>);
@@ -1008,7 +1012,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         bool c_fits = true; // C[] comes straight from the file: a (corrupt) value beyond 2^32 must not be truncated by the 32-bit state
         for (int i = 0; i < 8; i++) c_fits = c_fits && !(b->h->img.consts.C[i] >> 32);
         if (dense && img.n < (1ull << 30) && c_fits && !(nv && nv[0] == '0'))
-            kfn = in_lds ? (const void *)pgx_find_mems_kernel<true, 1, true, false>
+            kfn = in_lds ? (seeded ? (const void *)pgx_find_mems_kernel<true, 1, true, true> : (const void *)pgx_find_mems_kernel<true, 1, true, false>)
                   : d2   ? (seeded ? (const void *)pgx_find_mems_kernel<false, 2, true, true> : (const void *)pgx_find_mems_kernel<false, 2, true, false>)
                          : (seeded ? (const void *)pgx_find_mems_kernel<false, 1, true, true> : (const void *)pgx_find_mems_kernel<false, 1, true, false>);
         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, PGX_FM_THREADS, b->dimg->lds_bytes));
