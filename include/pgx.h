@@ -42,6 +42,8 @@ typedef enum {
 #define PGX_MODE_IMAGE_RL 0x100u    /* run-length blocks + directory (any size)                     */
 #define PGX_MODE_IMAGE_DENSE 0x200u /* uncompressed bit planes, n bytes of device memory (64 symbols per 64-byte block)       */
 #define PGX_MODE_IMAGE_DENSE2 0x400u /* two bit planes + exception runs, n / 3 bytes (384 symbols per 128-byte block; n < 2^32) */
+#define PGX_MODE_IMAGE_PAIRS 0x800u  /* dense2 + the two-step PAIRS image, n bytes more (n < 2^32, textbook extension tables, few N runs);
+                                      * the default from the size at which dense2 is, when the index qualifies             */
 #define PGX_MODE_MASK 0xFFu
 
 /* tag file formats (SURVEY section 5 "Tag formats") */
@@ -92,7 +94,7 @@ typedef struct {
     uint64_t n_samples;     /* samples.size() = runs in the reference's numbering */
     uint32_t image_kind;    /* 0 = run-length blocks + directory, 1 = dense bit planes (64 symbols per 64-byte block),
                              * 2 = dense2 (384 symbols per 128-byte block, two planes + exception runs) */
-    uint32_t reserved0;
+    uint32_t image_pairs;   /* 1 = a PAIRS image (two extensions per cache line) accompanies the dense2 image */
 } pgx_index_info;
 
 const char *pgx_last_error(void);
@@ -249,6 +251,8 @@ typedef struct {
     float ms_total;       /* first launch -> last launch, device time */
     uint32_t find_mems_launches;
     uint32_t heavy_reads; /* reads whose rest went through the heavy-read kernel (filled by every run, timed or not) */
+    uint32_t pairs_reads; /* 1 = the run used the two-step PAIRS kernel */
+    uint32_t redo_reads;  /* reads the PAIRS kernel handed on to the dense2 kernel (they met \n or N in the BWT) */
 } pgx_timing;
 
 /* Upload reads (read i = reads[offsets[i] .. offsets[i+1]); the `std::getline` lines of

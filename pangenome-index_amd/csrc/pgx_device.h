@@ -33,6 +33,11 @@ struct PgxDevImage {
     // the k bytes of a window, last byte first (pgx_seed_build_kernel); 0 = no table
     uint32_t seed_k;
     const uint4 *seed; // 4^seed_k entries {k lo, k' lo, s lo, k hi | k' hi << 8 | s hi << 16 | depth << 24}
+    // PAIRS image (NULL without one): blocks, ptab (8 dwords per special-run count), first extensions of the full interval
+    const uint4 *pairs;
+    const uint32_t *ptab;
+    const uint4 *first_ext;
+    uint32_t pair_runs;
 };
 #define PGX_SEED_UNUSABLE 255u // depth value of entries the kernels must not use (a coordinate does not fit the entry)
 #define PGX_SEED_MAX_K 14
@@ -61,7 +66,16 @@ template <bool LDS_IMAGE, int DENSE, bool NARROW, bool SEED> // DENSE = image ki
 __global__ void pgx_find_mems_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
                                      uint64_t min_len, uint64_t min_occ, const uint64_t *slot_off, pgx_mem *slots,
                                      uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor, uint64_t first_read,
-                                     uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap, pgx_heavy_item *heavy_list, unsigned long long *heavy_count);
+                                     uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap, pgx_heavy_item *heavy_list, unsigned long long *heavy_count,
+                                     const uint32_t *rid_list, const unsigned long long *rid_count);
+// PAIRS image (pgx_image.h): two extensions per loop trip; reads that meet a special position go to redo_list (then served by the kernel above)
+template <bool SEED>
+__global__ void pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
+                                           uint64_t min_len, uint64_t min_occ, const uint64_t *slot_off, pgx_mem *slots,
+                                           uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor, uint64_t first_read,
+                                           uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap, pgx_heavy_item *heavy_list, unsigned long long *heavy_count,
+                                           uint32_t *redo_list, unsigned long long *redo_count);
+__global__ void pgx_first_ext_kernel(PgxDevImage img, uint4 *out); // out[byte] = {k, k', s, 0} of the full interval extended backward by byte; out[256 + byte]: by 0, then by byte
 __global__ void pgx_rank_kernel(PgxDevImage img, const uint64_t *pos, uint64_t n, int true_codes, uint64_t *out);
 template <bool LDS_IMAGE>
 __global__ void pgx_extend_kernel(PgxDevImage img, const pgx_biint *in, const uint8_t *sym, const uint8_t *forward, uint64_t n,

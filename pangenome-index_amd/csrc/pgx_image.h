@@ -68,6 +68,24 @@
  * exception runs of the block. */
 #define PGX_D2_SYMS 384u
 #define PGX_D2_BLOCK_BYTES 128u
+/* PAIRS image (next to a DENSE2 image; BWTs shorter than 2^32 whose extension tables are the textbook ones): a two-step FM
+ * index.  Position p carries the PAIR (c1, c2) = (BWT[p], BWT[LF(p)]) = the two text symbols before suffix p, so the ranks of
+ * pairs at the two ends of an interval give the interval after TWO extensions -- the positions with c1 = a are mapped by LF,
+ * in order, onto the interval after the first extension, and BWT there is c2 -- from the same cache line that answers one:
+ * find_mems performs half the dependent line fetches.  128 symbols per 128-byte block, n bytes in all:
+ *   dw 4 y + x   (y, x in A C G T = 0..3) number of positions q < 128 b with c1(q) = y, c2(q) = x; except
+ *   dw 15        bit 31: the block holds a SPECIAL position (c1 or c2 is \n or N); bits 0..30: special runs (maximal runs of
+ *                consecutive special positions) that start before the block.  The count of (T, T) is 128 b minus the other
+ *                fifteen minus the special positions before the block (ptab)
+ *   dw 16..19 / 20..23   bit planes of c1 (bit 0, bit 1);  dw 24..27 / 28..31  bit planes of c2
+ *   ptab[8 r ..]  for the r special runs a block has behind it: {special positions, positions with c2 special and c1 = A, C, G, T}
+ *                (what the header counts do not see; 3 unused dwords)
+ * A kernel uses a block only when it is not flagged, and two blocks together only when they have the same run count (nothing
+ * special lies between them): every count that involves \n or N then cancels out of the differences it needs.  Anything else
+ * goes to the DENSE2 image (pgx_find_mems_pairs_kernel hands such reads on). */
+#define PGX_PAIRS_SYMS 128u
+#define PGX_PAIRS_BLOCK_BYTES 128u
+#define PGX_PAIRS_MAX_RUNS 1023u /* ptab lives in LDS (32 bytes per run) */
 
 /* ext_tab entry (one per byte value and direction): how to extend by that byte */
 #define PGX_EXT_CV(e) ((e) & 7u)            /* nuc code whose rank gives the new interval     */
@@ -97,8 +115,11 @@ typedef struct {
     /* unidirectional backward search (FastLocate::count / count_encoded): per read byte the nuc code
      * ranked (bits 0..2), the C slot (bits 3..5) and a "no match" flag (bit 24) */
     uint32_t cnt_tab[256];
-    uint32_t image_kind;  /* PGX_IMAGE_RL / PGX_IMAGE_DENSE */
-    uint32_t reserved0;
+    uint32_t image_kind;  /* PGX_IMAGE_RL / PGX_IMAGE_DENSE / PGX_IMAGE_DENSE2 */
+    uint32_t has_pairs;   /* a PAIRS image accompanies the DENSE2 image */
+    uint32_t pair_t2[32]; /* [8 y + c], y = 2-bit code of a regular symbol, c = nuc code: number of c in BWT[0, first suffix starting with y) */
+    uint32_t pair_runs;   /* special runs (ptab has pair_runs + 1 entries) */
+    uint32_t reserved1;
 } PgxConsts;
 
 /* locate image (FastLocate::locate / locateNext / decompressSA, src/r-index.cpp:1252-1366): three sorted

@@ -7,7 +7,11 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <array>
+#include <cstring>
 #include <memory>
+#include <mutex>
+#include <thread>
 
 #include "pgx_host.hpp"
 
@@ -490,23 +494,173 @@ static void build_dense2_image(const RiFile &ri, HostImage &img) {
     c.image_kind = PGX_IMAGE_DENSE2;
 }
 
+// PAIRS image (pgx_image.h): c2(p) = BWT[LF(p)] for every position whose BWT symbol is A C G T, pair counts per 128 positions.
+// Returns false (and leaves img without one) when the index does not qualify: an extension entry that ranks a regular symbol must
+// place its interval at that symbol's true C value -- the second step of a pair relies on LF mapping the positions with c1 = a
+// onto the interval after the first -- and the special runs must fit ptab.
+static bool build_pairs_image(const RiFile &ri, HostImage &img) {
+    PgxConsts &c = img.consts;
+    img.pairs.clear(); img.ptab.clear();
+    c.has_pairs = 0; c.pair_runs = 0;
+    const uint64_t n = c.n;
+    if (n == 0 || (n >> 32) || c.excl_mask) return false;
+    for (int i = 0; i < 8; i++) if (c.C[i] >> 32) return false;
+    // the BWT as nuc codes, counts, true C
+    std::vector<uint8_t> bw(n);
+    uint64_t tot[6] = {0, 0, 0, 0, 0, 0};
+    {
+        uint64_t pos = 0;
+        for (const auto &blk : ri.blocks)
+            for (const auto &ru : blk.runs) {
+                if (ru.first > 5 || pos + ru.second > n) throw Error(PGX_ERR_FORMAT, "FastLocate: run lengths do not add up to the BWT size");
+                std::memset(bw.data() + pos, (int)ru.first, ru.second);
+                tot[ru.first] += ru.second;
+                pos += ru.second;
+            }
+        if (pos != n) throw Error(PGX_ERR_FORMAT, "FastLocate: run lengths do not add up to the BWT size");
+    }
+    uint64_t trueC[7] = {0};
+    for (int i = 0; i < 6; i++) trueC[i + 1] = trueC[i] + tot[i];
+    static const int two_bit[6] = {-1, 0, 1, 2, -1, 3}; // \n A C G N T
+    static const int code_of_two[4] = {1, 2, 3, 5};
+    for (int e = 0; e < 512; e++) {
+        const uint32_t en = c.ext_tab[e];
+        if (PGX_EXT_KILL(en)) continue;
+        const uint32_t cv = PGX_EXT_CV(en);
+        if (cv > 5) return false;
+        if (two_bit[cv] >= 0 && c.C[PGX_EXT_V(en)] != trueC[cv]) return false;
+    }
+    // chunks of whole blocks; per chunk the counts of the six codes (for LF), later of the sixteen pairs
+    const uint64_t nb = (n >> 7) + 1;
+    struct Special { uint64_t start, len; uint64_t cnt[5]; }; // cnt: {positions, c2 special with c1 = A, C, G, T}
+    std::vector<std::vector<Special>> spec_of;
+    std::vector<std::array<uint64_t, 6>> code_cnt;
+    std::vector<std::array<uint64_t, 16>> pair_cnt;
+    std::vector<std::pair<uint64_t, uint64_t>> range_of;
+    {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const uint64_t want = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(hw ? hw : 1, 32), nb / 4096 + 1));
+        for (uint64_t t = 0; t < want; t++) range_of.push_back({nb * t / want, nb * (t + 1) / want});
+    }
+    const size_t nt = range_of.size();
+    code_cnt.assign(nt, {}); pair_cnt.assign(nt, {}); spec_of.assign(nt, {});
+    auto run_chunks = [&](auto &&fn) {
+        std::vector<std::thread> th;
+        std::exception_ptr err;
+        std::mutex mu;
+        for (size_t t = 0; t < nt; t++)
+            th.emplace_back([&, t]() {
+                try { fn(t, std::min<uint64_t>(range_of[t].first << 7, n), std::min<uint64_t>(range_of[t].second << 7, n)); }
+                catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
+            });
+        for (auto &x : th) x.join();
+        if (err) std::rethrow_exception(err);
+    };
+    run_chunks([&](size_t t, uint64_t p0, uint64_t p1) {
+        std::array<uint64_t, 6> k{};
+        for (uint64_t p = p0; p < p1; p++) k[bw[p]]++;
+        code_cnt[t] = k;
+    });
+    // pr[p]: 0..15 = 4 c1 + c2 (2-bit codes); 0x80 = c1 special; 0x81 + y = c2 special, c1 = y
+    std::vector<uint8_t> pr(n);
+    run_chunks([&](size_t t, uint64_t p0, uint64_t p1) {
+        uint64_t at[6];
+        for (int i = 0; i < 6; i++) { at[i] = trueC[i]; for (size_t u = 0; u < t; u++) at[i] += code_cnt[u][i]; }
+        std::array<uint64_t, 16> pc{};
+        std::vector<Special> &sp = spec_of[t];
+        for (uint64_t p = p0; p < p1; p++) {
+            const int y = two_bit[bw[p]];
+            uint8_t v;
+            if (y < 0) v = 0x80;
+            else {
+                const int x = two_bit[bw[at[bw[p]]++]]; // BWT[LF(p)]
+                v = x < 0 ? (uint8_t)(0x81 + y) : (uint8_t)(4 * y + x);
+            }
+            pr[p] = v;
+            if (v & 0x80) {
+                if (sp.empty() || sp.back().start + sp.back().len != p) sp.push_back({p, 0, {0, 0, 0, 0, 0}});
+                sp.back().len++; sp.back().cnt[0]++;
+                if (v > 0x80) sp.back().cnt[v - 0x80]++;
+            } else pc[v]++;
+        }
+        pair_cnt[t] = pc;
+    });
+    // special runs in order (runs that meet at a chunk border are one)
+    std::vector<Special> runs;
+    for (size_t t = 0; t < nt; t++)
+        for (const Special &sr : spec_of[t]) {
+            if (!runs.empty() && runs.back().start + runs.back().len == sr.start) {
+                runs.back().len += sr.len;
+                for (int i = 0; i < 5; i++) runs.back().cnt[i] += sr.cnt[i];
+            } else runs.push_back(sr);
+        }
+    if (runs.size() > PGX_PAIRS_MAX_RUNS) return false;
+    img.ptab.assign((runs.size() + 1) * 8, 0);
+    for (size_t r = 0; r < runs.size(); r++)
+        for (int i = 0; i < 5; i++) img.ptab[(r + 1) * 8 + i] = img.ptab[r * 8 + i] + (uint32_t)runs[r].cnt[i];
+    // blocks
+    img.pairs.assign(nb * PGX_PAIRS_BLOCK_BYTES, 0);
+    uint32_t *dw = reinterpret_cast<uint32_t *>(img.pairs.data());
+    run_chunks([&](size_t t, uint64_t p0, uint64_t p1) {
+        std::array<uint64_t, 16> pc{};
+        for (size_t u = 0; u < t; u++) for (int i = 0; i < 16; i++) pc[i] += pair_cnt[u][i];
+        const uint64_t b0 = range_of[t].first, b1 = range_of[t].second;
+        size_t r = std::lower_bound(runs.begin(), runs.end(), b0 << 7, [](const Special &a, uint64_t v) { return a.start < v; }) - runs.begin(); // runs starting before the block
+        for (uint64_t b = b0; b < b1; b++) {
+            uint32_t *h = dw + b * 32;
+            const uint64_t s0 = b << 7, s1 = std::min<uint64_t>(s0 + 128, n);
+            while (r < runs.size() && runs[r].start < s0) r++;
+            for (int i = 0; i < 15; i++) h[i] = (uint32_t)pc[i];
+            bool flag = (r > 0 && runs[r - 1].start + runs[r - 1].len > s0) || (r < runs.size() && runs[r].start < s1);
+            h[15] = (uint32_t)r | (flag ? 0x80000000u : 0u);
+            for (uint64_t p = std::min(s0, p1); p < std::min(s1, p1); p++) {
+                const uint8_t v = pr[p];
+                if (v & 0x80) continue;
+                const uint32_t i = (uint32_t)(p - s0), bit = 1u << (i & 31), w = i >> 5;
+                if (v & 4) h[16 + w] |= bit;
+                if (v & 8) h[20 + w] |= bit;
+                if (v & 1) h[24 + w] |= bit;
+                if (v & 2) h[28 + w] |= bit;
+                pc[v]++;
+            }
+        }
+        (void)p0;
+    });
+    // pair_t2[8 y + c]: number of c in BWT[0, true C of y)
+    for (int y = 0; y < 4; y++) {
+        const uint64_t P = trueC[code_of_two[y]];
+        uint64_t cnt[6] = {0, 0, 0, 0, 0, 0};
+        size_t t = 0;
+        for (; t + 1 < nt && std::min<uint64_t>(range_of[t].second << 7, n) <= P; t++)
+            for (int i = 0; i < 6; i++) cnt[i] += code_cnt[t][i];
+        for (uint64_t p = std::min<uint64_t>(range_of[t].first << 7, n); p < P; p++) cnt[bw[p]]++;
+        for (int i = 0; i < 6; i++) c.pair_t2[8 * y + i] = (uint32_t)cnt[i];
+    }
+    c.has_pairs = 1;
+    c.pair_runs = (uint32_t)runs.size();
+    return true;
+}
+
 // layout of the device rank image: dense bit planes when that costs little memory or the run-length image would
 // not stay cache resident either; PGX_MODE_IMAGE_* / the environment variable PGX_IMAGE force one
 // returns PGX_IMAGE_RL / PGX_IMAGE_DENSE / PGX_IMAGE_DENSE2
-static uint32_t choose_image(const RiFile &ri, uint32_t mode_bits, const PgxConsts &c) {
+// pairs: 0 = no PAIRS image, 1 = one if the index qualifies, 2 = required (forced)
+static uint32_t choose_image(const RiFile &ri, uint32_t mode_bits, const PgxConsts &c, int &pairs) {
     const bool can = c.excl_mask == 0;
-    const uint32_t all = PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE | PGX_MODE_IMAGE_DENSE2;
+    const uint32_t all = PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE | PGX_MODE_IMAGE_DENSE2 | PGX_MODE_IMAGE_PAIRS;
     uint32_t force = mode_bits & all;
+    pairs = 0;
     if (!force)
         if (const char *e = std::getenv("PGX_IMAGE")) {
             const std::string v(e);
-            force = v == "dense" ? PGX_MODE_IMAGE_DENSE : v == "dense2" ? PGX_MODE_IMAGE_DENSE2 : v == "rl" ? PGX_MODE_IMAGE_RL : 0u;
+            force = v == "dense" ? PGX_MODE_IMAGE_DENSE : v == "dense2" ? PGX_MODE_IMAGE_DENSE2 : v == "rl" ? PGX_MODE_IMAGE_RL : v == "pairs" ? PGX_MODE_IMAGE_PAIRS : 0u;
         }
     if (force & (force - 1)) throw Error(PGX_ERR_ARG, "pgx_index_open: more than one image layout forced");
-    if (force & (PGX_MODE_IMAGE_DENSE | PGX_MODE_IMAGE_DENSE2)) {
+    if (force & (PGX_MODE_IMAGE_DENSE | PGX_MODE_IMAGE_DENSE2 | PGX_MODE_IMAGE_PAIRS)) {
         if (!can) throw Error(PGX_ERR_UNSUPPORTED, "dense image: not available for a legacy-layout index without N in COMPAT mode");
-        if ((force & PGX_MODE_IMAGE_DENSE2) && (c.n >> 32)) throw Error(PGX_ERR_UNSUPPORTED, "dense2 image: BWT of 2^32 symbols or more");
-        return (force & PGX_MODE_IMAGE_DENSE2) ? PGX_IMAGE_DENSE2 : PGX_IMAGE_DENSE;
+        if ((force & (PGX_MODE_IMAGE_DENSE2 | PGX_MODE_IMAGE_PAIRS)) && (c.n >> 32)) throw Error(PGX_ERR_UNSUPPORTED, "dense2 image: BWT of 2^32 symbols or more");
+        if (force & PGX_MODE_IMAGE_PAIRS) pairs = 2;
+        return (force & PGX_MODE_IMAGE_DENSE) ? PGX_IMAGE_DENSE : PGX_IMAGE_DENSE2;
     }
     if ((force & PGX_MODE_IMAGE_RL) || !can) return PGX_IMAGE_RL;
     // tiny BWTs: the 64-byte layout, staged in LDS by the kernels (cheapest decode; pgx_runtime.hip: 80 padded bytes per block)
@@ -517,7 +671,7 @@ static uint32_t choose_image(const RiFile &ri, uint32_t mode_bits, const PgxCons
     // (n = 640 M, 10 M reads: 30 ms against 36 ms with the 64-byte layout served from HBM)
     const uint64_t dense_bytes0 = dense_blocks * PGX_BLOCK_BYTES;
     if (dense_bytes0 <= (224ull << 20)) return PGX_IMAGE_DENSE;
-    if (!(c.n >> 32)) return PGX_IMAGE_DENSE2;
+    if (!(c.n >> 32)) { pairs = 1; return PGX_IMAGE_DENSE2; } // + the two-step PAIRS image when the index qualifies
     uint64_t runs = 0;
     for (const auto &b : ri.blocks) runs += b.runs.size();
     const uint64_t dense_bytes = dense_blocks * PGX_BLOCK_BYTES, rl_bytes = (runs / PGX_BLOCK_RUNS + 1) * (PGX_BLOCK_BYTES + 4);
@@ -533,9 +687,16 @@ void build_rank_image(const RiFile &ri, uint32_t mode_bits, HostImage &img) {
     c.mode = mode;
     build_ext_tables(ri, mode, c);
     build_count_table(ri, mode, c);
-    const uint32_t kind = choose_image(ri, mode_bits, c);
+    int pairs = 0;
+    const uint32_t kind = choose_image(ri, mode_bits, c, pairs);
+    img.pairs.clear(); img.ptab.clear();
     if (kind == PGX_IMAGE_DENSE) { build_dense_image(ri, img); return; }
-    if (kind == PGX_IMAGE_DENSE2) { build_dense2_image(ri, img); return; }
+    if (kind == PGX_IMAGE_DENSE2) {
+        build_dense2_image(ri, img);
+        if (pairs && !build_pairs_image(ri, img) && pairs == 2)
+            throw Error(PGX_ERR_UNSUPPORTED, "pairs image: the index does not qualify (extension tables of a COMPAT quirk, or too many N / endmarker runs)");
+        return;
+    }
     // Device blocks must refine the reference's blocks only when a header slot carries the
     // reference-block cumulative endmarker count (legacy layout, absent symbol, COMPAT).
     const bool refine = c.excl_mask != 0;
@@ -721,7 +882,7 @@ extern "C" int pgx_abi_version(void) { return PGX_ABI_VERSION; }
 void pgx_release_device_images(pgx_index *h); // pgx_runtime.hip
 
 static pgx_index *open_impl(const uint8_t *ri, uint64_t ri_n, const uint8_t *tags, uint64_t tags_n, uint32_t tags_format, uint32_t mode) {
-    if ((mode & PGX_MODE_MASK) > PGX_MODE_STRICT || (mode & ~(PGX_MODE_MASK | PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE | PGX_MODE_IMAGE_DENSE2)))
+    if ((mode & PGX_MODE_MASK) > PGX_MODE_STRICT || (mode & ~(PGX_MODE_MASK | PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE | PGX_MODE_IMAGE_DENSE2 | PGX_MODE_IMAGE_PAIRS)))
         throw Error(PGX_ERR_ARG, "pgx_index_open: bad mode");
     if (!ri && !tags) throw Error(PGX_ERR_ARG, "pgx_index_open: neither an r-index nor a tag array given");
     std::unique_ptr<pgx_index> h(new pgx_index());
@@ -744,7 +905,7 @@ extern "C" pgx_status pgx_index_open(const char *ri_path, const char *tags_path,
                                      uint32_t mode, pgx_index **out) {
     PGX_GUARD_BEGIN
     if (!ri_path || !out) throw Error(PGX_ERR_ARG, "pgx_index_open: null argument");
-    if ((mode & PGX_MODE_MASK) > PGX_MODE_STRICT || (mode & ~(PGX_MODE_MASK | PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE | PGX_MODE_IMAGE_DENSE2)))
+    if ((mode & PGX_MODE_MASK) > PGX_MODE_STRICT || (mode & ~(PGX_MODE_MASK | PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE | PGX_MODE_IMAGE_DENSE2 | PGX_MODE_IMAGE_PAIRS)))
         throw Error(PGX_ERR_ARG, "pgx_index_open: bad mode");
     *out = nullptr;
     std::vector<uint8_t> f, t;
@@ -803,7 +964,7 @@ extern "C" pgx_status pgx_index_info_get(const pgx_index *h, pgx_index_info *inf
     info->n_tag_runs = c.n_tag_runs;
     info->tag_dir_entries = c.tag_dir_entries;
     info->tag_dir_shift = c.tag_dir_shift;
-    info->image_bytes = h->img.blocks.size() + h->img.dir.size() * 8 + h->img.blow.size() * 2 + h->img.exc.size() * 4;
+    info->image_bytes = h->img.blocks.size() + h->img.dir.size() * 8 + h->img.blow.size() * 2 + h->img.exc.size() * 4 + h->img.pairs.size() + h->img.ptab.size() * 4;
     info->tag_image_bytes = h->img.tstart.size() * 8 + h->img.tvals.size() * 8 + h->img.tdir.size() * 4;
     info->image_in_lds = h->img.consts.image_kind == PGX_IMAGE_DENSE ? (uint64_t)h->img.consts.n_blocks * 80 + 16 <= 48 * 1024
                                                                      : (h->img.consts.image_kind == PGX_IMAGE_RL && info->image_bytes <= 48 * 1024);
@@ -811,6 +972,7 @@ extern "C" pgx_status pgx_index_info_get(const pgx_index *h, pgx_index_info *inf
     info->max_length = h->ri.max_length;
     info->n_samples = h->ri.samples.size();
     info->image_kind = c.image_kind;
+    info->image_pairs = c.has_pairs;
     return PGX_OK;
     PGX_GUARD_END
 }
@@ -844,6 +1006,8 @@ extern "C" pgx_status pgx_index_image_view(const pgx_index *h, int which, const 
     case 6: *ptr = &m.consts; *bytes = sizeof(PgxConsts); break;
     case 7: *ptr = m.blow.data(); *bytes = m.blow.size() * 2; break;
     case 15: *ptr = m.exc.data(); *bytes = m.exc.size() * 4; break;
+    case 20: *ptr = m.pairs.data(); *bytes = m.pairs.size(); break;
+    case 21: *ptr = m.ptab.data(); *bytes = m.ptab.size() * 4; break;
     case 16: case 17: case 18: case 19: {
         if (!(h->ri.encoded && !h->ri.hasN)) throw Error(PGX_ERR_ARG, "pgx_index_image_view: the literal count image exists for encoded indexes without N only");
         pgx::LitHostImage &l = const_cast<pgx_index *>(h)->lit;

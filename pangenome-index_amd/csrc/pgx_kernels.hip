@@ -491,11 +491,14 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                      uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
                      pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
                      unsigned long long *__restrict__ cursor, uint64_t first_read, uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap,
-                     pgx_heavy_item *__restrict__ heavy_list, unsigned long long *__restrict__ heavy_count) {
+                     pgx_heavy_item *__restrict__ heavy_list, unsigned long long *__restrict__ heavy_count,
+                     const uint32_t *__restrict__ rid_list, const unsigned long long *__restrict__ rid_count) {
     __shared__ uint32_t s_ext[512];
     __shared__ uint64_t s_C[8];
     PGX_LDS_CARVE(img);
     pgx_stage_tables<LDS_IMAGE>(img, s_ext, s_C, lds_blocks, lds_dir, lds_blow);
+    // rid_list (may be NULL): the launch serves the reads listed there (handed on by pgx_find_mems_pairs_kernel), *rid_count of them
+    if (rid_list) { first_read = 0; n_reads = *rid_count; }
 
     static_assert(!NARROW || DENSE, "the 32-bit state exists for the dense image only");
     static_assert(!SEED || DENSE, "k-mer seeds exist for the dense images");
@@ -579,7 +582,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
             const uint64_t avail = rend - rnext;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             if (ph == 0 && (uint64_t)rank < avail) {
-                rid = rnext + rank;
+                rid = rid_list ? (uint64_t)rid_list[rnext + rank] : rnext + rank;
                 base = offsets[rid];
                 len = (int32_t)(offsets[rid + 1] - base);
                 slot = slot_off[rid] - slot_base; // slots are reused per chunk of reads (pgx_batch_run)
@@ -775,48 +778,332 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
 #endif
 }
 
-template __global__ void pgx_find_mems_kernel<false, 0, false, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
-                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<false, 1, false, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
-                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<true, 0, false, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
-                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<true, 1, false, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
-                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<true, 1, true, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
-                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<true, 1, false, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
-                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<true, 1, true, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
-                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<false, 1, true, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
-                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<false, 1, false, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
-                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<false, 1, true, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
-                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<false, 2, false, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
-                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<false, 2, true, false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
-                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<false, 2, false, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
-                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
-template __global__ void pgx_find_mems_kernel<false, 2, true, true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,
-                                                            const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t,
-                                                            uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *);
+#define PGX_FM_INSTANTIATE(...)                                                                                                               \
+    template __global__ void pgx_find_mems_kernel<__VA_ARGS__>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,     \
+                                                               const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, \
+                                                               uint64_t, uint64_t, uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *,     \
+                                                               const uint32_t *, const unsigned long long *);
+PGX_FM_INSTANTIATE(false, 0, false, false)
+PGX_FM_INSTANTIATE(false, 1, false, false)
+PGX_FM_INSTANTIATE(true, 0, false, false)
+PGX_FM_INSTANTIATE(true, 1, false, false)
+PGX_FM_INSTANTIATE(true, 1, true, false)
+PGX_FM_INSTANTIATE(true, 1, false, true)
+PGX_FM_INSTANTIATE(true, 1, true, true)
+PGX_FM_INSTANTIATE(false, 1, true, false)
+PGX_FM_INSTANTIATE(false, 1, false, true)
+PGX_FM_INSTANTIATE(false, 1, true, true)
+PGX_FM_INSTANTIATE(false, 2, false, false)
+PGX_FM_INSTANTIATE(false, 2, true, false)
+PGX_FM_INSTANTIATE(false, 2, false, true)
+PGX_FM_INSTANTIATE(false, 2, true, true)
+
+// ------------------------------------------------------------------------------------------
+// find_all_mems over the PAIRS image (pgx_image.h): the loop of pgx_find_mems_kernel, but a trip reads ONE 128-byte block that
+// answers both probes of an extension (p1 within the block of p0; otherwise the second probe takes a second trip) and, where the
+// stage has two more symbols to go, performs BOTH extensions from it:
+//   first by a (code cv1):   s1 = #{c1 = a} in [p0, p1),  k1 = C[a] + #{c1 = a} before p0,  k' += sum of w1[c] #{c1 = c}
+//   then by b (code cv2):    s2 = #{c1 = a, c2 = b},      k2 = C[b] + #b before k1 + #{c1 = a, c2 = b} before p0,
+//                            k' += sum of w2[c] #{c1 = a, c2 = c}          (#b before k1 = pair_t2[a][b] + pairs (a, b) before p0)
+// The first extension's result decides as in the stepwise search: if it is "small" the stage ends there and the second is dropped;
+// otherwise the pair counts as two extensions, and the transitions below see the second one at its own j.  MEMs, restart
+// positions and n_extensions are those of pgx_find_mems_kernel.  Positions, counts and C are below 2^32 (the image exists for
+// such indexes only), so the state is 32-bit.  A stage that starts from the full interval takes its first extension from
+// img.first_ext (or the seed table): the image is never probed with the full interval.
+// A lane that meets a flagged block, or two blocks with special positions between them, gives its read up: the read id goes to
+// redo_list and pgx_find_mems_kernel (dense2 image) searches it from the start.
+struct PgxPairsIn { uint32_t n1, n2, n3, q0, q1, q2, q3; };
+__device__ __forceinline__ PgxPairsIn pgx_pairs_inblock(const uint4 &a0, const uint4 &a1, const uint4 &b0, const uint4 &b1, uint32_t rel, uint32_t inv0,
+                                                        uint32_t inv1) {
+    const uint32_t A0[4] = {a0.x, a0.y, a0.z, a0.w}, A1[4] = {a1.x, a1.y, a1.z, a1.w}, B0[4] = {b0.x, b0.y, b0.z, b0.w}, B1[4] = {b1.x, b1.y, b1.z, b1.w};
+    PgxPairsIn o = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        const int32_t t = (int32_t)rel - 32 * h; // bits of this dword below the position
+        const uint32_t m = t >= 32 ? 0xFFFFFFFFu : (t > 0 ? ((1u << t) - 1u) : 0u);
+        const uint32_t x = A0[h] & m, y = A1[h] & m;
+        o.n1 += __popc(x); o.n2 += __popc(y); o.n3 += __popc(x & y);
+        const uint32_t m1 = (A0[h] ^ inv0) & (A1[h] ^ inv1) & m; // positions whose first symbol is the one extended by
+        const uint32_t u = m1 & B0[h], v = m1 & B1[h];
+        o.q0 += __popc(m1); o.q1 += __popc(u); o.q2 += __popc(v); o.q3 += __popc(u & v);
+    }
+    return o;
+}
+
+template <bool SEED>
+__global__ void __launch_bounds__(PGX_FM_THREADS, PGX_FM_WAVES_PER_SIMD)
+pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
+                           uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
+                           pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
+                           unsigned long long *__restrict__ cursor, uint64_t first_read, uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap,
+                           pgx_heavy_item *__restrict__ heavy_list, unsigned long long *__restrict__ heavy_count,
+                           uint32_t *__restrict__ redo_list, unsigned long long *__restrict__ redo_count) {
+    __shared__ uint32_t s_ext[512];
+    __shared__ uint32_t s_C[8];
+    __shared__ uint32_t s_t2[32];
+    __shared__ uint4 s_fe[512]; // first_ext: [byte] the full interval extended by byte, [256 + byte] extended by 0 and then by byte
+    extern __shared__ __align__(16) unsigned char pgx_dyn_lds[];
+    uint32_t *s_pt = reinterpret_cast<uint32_t *>(pgx_dyn_lds); // 8 dwords per special-run count
+    for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) s_ext[i] = img.consts->ext_tab[i];
+    if (threadIdx.x < 8) s_C[threadIdx.x] = (uint32_t)img.consts->C[threadIdx.x];
+    if (threadIdx.x < 32) s_t2[threadIdx.x] = img.consts->pair_t2[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) s_fe[i] = img.first_ext[i];
+    for (uint32_t i = threadIdx.x; i < (img.pair_runs + 1u) * 8u; i += blockDim.x) s_pt[i] = img.ptab[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = (uint32_t)img.n;
+    const uint32_t mo = min_occ > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)min_occ; // sizes are below 2^32: a larger min_occ makes everything "small" either way
+    const bool mo_huge = min_occ > 0xFFFFFFFFull;
+    uint64_t rid = 0, base = 0, slot = 0;
+    int32_t len = 0, x = 0, j = 0;
+    uint32_t k = 0, kp = 0, s = 0, Jk = 0, Js = 0;
+    uint32_t nm = 0, next = 0, next0 = 0;
+    int ph = 0;
+    uint64_t win = 0, win_hi = 0, win2 = 0, win3 = 0, win_at = ~0ull;
+    uint32_t X0a = 0, X0b = 0, X0c = 0, X0d = 0, ri0 = 0; // first-probe sums of an extension whose second probe is pending
+    uint32_t pend = 0, fresh = 0, restart = 0;
+    uint64_t rnext = 0, rend = 0;
+    bool exhausted = false;
+
+    auto begin = [&]() __attribute__((always_inline)) {
+        if (x >= len || (uint64_t)(len - x) < min_len) { ph = 0; mem_count[rid] = nm; return; }
+        if (heavy_ext && next - next0 >= heavy_ext && len <= (int32_t)PGX_FM_HEAVY_MAXLEN) {
+            const unsigned long long at = atomicAdd(heavy_count, 1ull);
+            if (at < (unsigned long long)heavy_cap) {
+                pgx_heavy_item it;
+                it.rid = rid; it.x = (uint32_t)x; it.nm = nm;
+                heavy_list[at] = it;
+                ph = 0;
+                return;
+            }
+        }
+        k = 0; kp = 0; s = n;
+        if (min_len == 0) { Jk = 0; Js = n; j = x; ph = 2; }
+        else { j = x + (int32_t)min_len - 1; ph = 1; fresh = 1u; }
+    };
+    auto emit = [&]() __attribute__((always_inline)) {
+        pgx_mem m;
+        m.start = (uint64_t)x; m.end = (uint64_t)j; m.bwt_start = (uint64_t)Jk; m.size = (int64_t)(uint64_t)Js;
+        slots[slot + nm] = m;
+        nm++;
+        k = 0; kp = 0; s = n;
+        const bool more = j > x;
+        ph = more ? 3 : ph;
+        fresh = more ? 1u : fresh;
+        x = more ? x : x + 1;
+        restart = more ? restart : 1u;
+    };
+
+    for (;;) {
+        unsigned long long idle = __ballot(ph == 0);
+        while (idle) {
+            if (rnext == rend) {
+                if (exhausted) break;
+                unsigned long long got = 0;
+                if (lane == 0) got = first_read + atomicAdd(cursor, 32ull);
+                got = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(got >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)got);
+                if (got >= n_reads) { exhausted = true; break; }
+                rnext = got;
+                rend = got + 32ull < n_reads ? got + 32ull : n_reads;
+            }
+            const uint64_t avail = rend - rnext;
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (ph == 0 && (uint64_t)rank < avail) {
+                rid = rnext + rank;
+                base = offsets[rid];
+                len = (int32_t)(offsets[rid + 1] - base);
+                slot = slot_off[rid] - slot_base;
+                x = 0; nm = 0;
+                next0 = next;
+                begin();
+                if (ph == 0) ph = -1;
+            }
+            const uint32_t want = (uint32_t)__popcll(idle);
+            rnext += (uint64_t)want < avail ? (uint64_t)want : avail;
+            idle = __ballot(ph == 0);
+        }
+        if (ph == -1) ph = 0;
+        if (!__any(ph > 0)) {
+            if (exhausted && rnext == rend) break;
+            continue;
+        }
+        if (ph > 0) {
+            const bool fr = fresh != 0u; // first extension of a backward stage: from first_ext / the seed table
+            bool seed_lane = false;
+            uint4 se = make_uint4(0u, 0u, 0u, 0u);
+            if (SEED) {
+                const uint4 *sp = img.seed;
+                if (fr) {
+                    const int32_t K = (int32_t)img.seed_k;
+                    const int32_t avail = (ph == 1) ? (j - x + 1) : (j - x);
+                    if (avail >= K && j < len) {
+                        const uint64_t a = base + (uint64_t)(j - K + 1);
+                        const uint32_t sh = (uint32_t)(a & 7ull) * 8u;
+                        const uint64_t *wp = reinterpret_cast<const uint64_t *>(reads + (a & ~7ull));
+                        const uint64_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+                        const uint64_t lo = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0, hi = sh ? (w1 >> sh) | (w2 << (64u - sh)) : w1;
+                        uint32_t sidx;
+                        if (pgx_seed_index(lo, hi, (uint32_t)K, sidx)) { seed_lane = true; sp = img.seed + sidx; }
+                    }
+                }
+                se = *sp;
+            }
+            fresh = 0u;
+            const bool fwd = (ph == 2);
+            const uint64_t at = base + (uint64_t)j;
+            // pattern[len] reads as 0 (quirk 4): step 3 of a MEM that reaches the end of its read starts there, from the full interval;
+            // its first TWO extensions (by 0, then by the last symbol of the read) come from first_ext: the rows of the endmarkers
+            // (block 0 of the image) have the sequences' last symbols before them, often N
+            const bool at_end = j >= len;
+            const uint64_t atw = at_end ? at - 1ull : at; // (a live read has len >= 1)
+            if ((atw & ~31ull) != win_at) {
+                win_at = atw & ~31ull;
+                const ulonglong2 w2 = *reinterpret_cast<const ulonglong2 *>(reads + win_at);
+                const ulonglong2 w3 = *reinterpret_cast<const ulonglong2 *>(reads + win_at + 16);
+                win = w2.x; win_hi = w2.y; win2 = w3.x; win3 = w3.y;
+            }
+            auto window_byte = [&](uint64_t a) __attribute__((always_inline)) {
+                const uint64_t wlo = (a & 8ull) ? win_hi : win, whi = (a & 8ull) ? win3 : win2;
+                return (uint32_t)(((a & 16ull) ? whi : wlo) >> (8u * (uint32_t)(a & 7ull))) & 0xFFu;
+            };
+            const uint32_t byte = at_end ? 0u : window_byte(at);
+            // the symbol after this one in the direction of the stage, when the cached window holds it
+            const uint64_t at2 = (fwd && !at_end) ? at + 1ull : at - 1ull;
+            const bool have2 = (at2 & ~31ull) == win_at;
+            const uint32_t byte2 = window_byte(at2);
+            const uint32_t e1 = s_ext[(fwd ? 256u : 0u) + byte], e2 = s_ext[(fwd ? 256u : 0u) + byte2];
+            const uint32_t cv1 = PGX_EXT_CV(e1), cv2 = PGX_EXT_CV(e2);
+            const bool reg1 = !PGX_EXT_KILL(e1) && ((0x2Eu >> cv1) & 1u), reg2 = !PGX_EXT_KILL(e2) && ((0x2Eu >> cv2) & 1u); // A C G T
+            const uint32_t t1 = reg1 ? cv1 - 1u - (cv1 >> 2) : 0u, t2 = reg2 ? cv2 - 1u - (cv2 >> 2) : 0u;                    // their 2-bit codes
+            const bool rem2 = ph == 1 ? (j - 1 >= x) : (fwd ? (j + 1 < len) : (j - 1 > x)); // the stage has a second extension to make
+            const bool two = !fr && rem2 && have2 && reg1 && reg2;
+            const uint32_t kk = fwd ? kp : k, kq = fwd ? k : kp;
+            const uint32_t p0 = kk, p1 = kk + s;
+            const uint32_t P = pend ? p1 : p0, bs = P & ~127u;
+            const uint4 *bp = img.pairs + (size_t)(P >> 7) * 8;
+            const uint4 h0 = bp[0], h1 = bp[1], h2 = bp[2], h3 = bp[3], a0 = bp[4], a1 = bp[5], b0 = bp[6], b1 = bp[7];
+            const bool flagged = (h3.w >> 31) != 0u;
+            const uint32_t ri = h3.w & 0x7FFFFFFFu;
+            const uint32_t relA = P - bs;
+            const bool same = !pend && (p1 - bs <= 128u);
+            const uint32_t relB = same ? p1 - bs : relA;
+            const uint32_t inv0 = (t1 & 1u) ? 0u : 0xFFFFFFFFu, inv1 = (t1 & 2u) ? 0u : 0xFFFFFFFFu;
+            const PgxPairsIn iA = pgx_pairs_inblock(a0, a1, b0, b1, relA, inv0, inv1), iB = pgx_pairs_inblock(a0, a1, b0, b1, relB, inv0, inv1);
+            // counts before the block: rows of the header (first symbol y: second symbols A C G T), the sixteenth derived
+            const uint32_t pt0 = s_pt[8u * ri], pts = s_pt[8u * ri + 1u + t1];
+            const uint32_t rs0 = h0.x + h0.y + h0.z + h0.w, rs1 = h1.x + h1.y + h1.z + h1.w, rs2 = h2.x + h2.y + h2.z + h2.w;
+            const uint32_t r33 = bs - rs0 - rs1 - rs2 - (h3.x + h3.y + h3.z) - pt0;
+            const uint32_t rs3 = h3.x + h3.y + h3.z + r33;
+            const uint32_t m1 = PGX_EXT_M(e1), m2 = PGX_EXT_M(e2);
+            const uint32_t w1A = (m1 >> 3) & 7u, w1C = (m1 >> 6) & 7u, w1G = (m1 >> 9) & 7u, w1T = (m1 >> 15) & 7u;
+            const uint32_t w2A = (m2 >> 3) & 7u, w2C = (m2 >> 6) & 7u, w2G = (m2 >> 9) & 7u, w2T = (m2 >> 15) & 7u;
+            const uint32_t rx = t1 == 0u ? h0.x : (t1 == 1u ? h1.x : (t1 == 2u ? h2.x : h3.x)), ry = t1 == 0u ? h0.y : (t1 == 1u ? h1.y : (t1 == 2u ? h2.y : h3.y));
+            const uint32_t rz = t1 == 0u ? h0.z : (t1 == 1u ? h1.z : (t1 == 2u ? h2.z : h3.z)), rw = t1 == 0u ? h0.w : (t1 == 1u ? h1.w : (t1 == 2u ? h2.w : r33));
+            const uint32_t abs_one = (t1 == 0u ? rs0 : (t1 == 1u ? rs1 : (t1 == 2u ? rs2 : rs3))) + pts;
+            const uint32_t abs_two = t2 == 0u ? rx : (t2 == 1u ? ry : (t2 == 2u ? rz : rw));
+            const uint32_t abs_w1 = w1A * rs0 + w1C * rs1 + w1G * rs2 + w1T * rs3, abs_w2 = w2A * rx + w2C * ry + w2G * rz + w2T * rw;
+            auto sums = [&](const PgxPairsIn &i, uint32_t rel, uint32_t &one, uint32_t &twov, uint32_t &sw1, uint32_t &sw2) __attribute__((always_inline)) {
+                const uint32_t iT = i.n3, iC = i.n1 - i.n3, iG = i.n2 - i.n3, iAa = rel - i.n1 - i.n2 + i.n3;
+                const uint32_t pT = i.q3, pC = i.q1 - i.q3, pG = i.q2 - i.q3, pA = i.q0 - i.q1 - i.q2 + i.q3;
+                one = abs_one + i.q0;
+                twov = abs_two + (t2 == 0u ? pA : (t2 == 1u ? pC : (t2 == 2u ? pG : pT)));
+                sw1 = abs_w1 + w1A * iAa + w1C * iC + w1G * iG + w1T * iT;
+                sw2 = abs_w2 + w2A * pA + w2C * pC + w2G * pG + w2T * pT;
+            };
+            uint32_t XAa, XAb, XAc, XAd, XBa, XBb, XBc, XBd;
+            sums(iA, relA, XAa, XAb, XAc, XAd);
+            sums(iB, relB, XBa, XBb, XBc, XBd);
+            const bool bail = !fr && (flagged || (pend && ri != ri0));
+            const bool wait = !fr && !pend && !same && !bail; // the second probe lies in another block: next trip
+            if (bail) { // special positions in the way: the dense2 kernel searches this read
+                redo_list[atomicAdd(redo_count, 1ull)] = (uint32_t)rid;
+                ph = 0; next = next0; pend = 0u;
+            } else if (wait) {
+                X0a = XAa; X0b = XAb; X0c = XAc; X0d = XAd; ri0 = ri;
+                pend = 1u;
+            } else {
+                const uint32_t Q0a = pend ? X0a : XAa, Q0b = pend ? X0b : XAb, Q0c = pend ? X0c : XAc, Q0d = pend ? X0d : XAd;
+                const uint32_t Q1a = pend ? XAa : XBa, Q1b = pend ? XAb : XBb, Q1c = pend ? XAc : XBc, Q1d = pend ? XAd : XBd;
+                pend = 0u;
+                // first extension (src/r-index.cpp:713-764); a symbol that is not A C G T has no occurrence in a range free of special positions
+                uint32_t s1 = reg1 ? Q1a - Q0a : 0u;
+                uint32_t k1 = Q0a + s_C[PGX_EXT_V(e1)], q1v = kq + (Q1c - Q0c);
+                if (fr) { const uint4 f = s_fe[byte]; k1 = f.x; q1v = f.y; s1 = f.z; }
+                const bool small1 = s1 == 0u || s1 < mo || mo_huge;
+                const bool do2 = (fr ? (at_end && rem2 && have2) : two) && !small1;
+                uint32_t s2 = Q1b - Q0b, k2 = Q0b + s_C[PGX_EXT_V(e2)] + s_t2[8u * t1 + cv2], q2v = q1v + (Q1d - Q0d);
+                if (fr) { const uint4 f = s_fe[256u + byte2]; k2 = f.x; q2v = f.y; s2 = f.z; }
+                uint32_t ns = do2 ? s2 : s1, nk = do2 ? k2 : k1, nq = do2 ? q2v : q1v;
+                if (ns == 0u) { nk = 0u; nq = 0u; }
+                if (do2) { // the first of the two: what a trip of its own would have left behind
+                    Jk = fwd ? q1v : Jk;
+                    Js = fwd ? s1 : Js;
+                    j = fwd ? j + 1 : j - 1;
+                }
+                next += do2 ? 2u : 1u;
+                s = ns;
+                k = fwd ? nq : nk;
+                kp = fwd ? nk : nq;
+                bool small = ns == 0u || ns < mo || mo_huge;
+                if (SEED && seed_lane) {
+                    const uint32_t depth = se.w >> 24;
+                    const uint32_t ss = se.z;
+                    if (ss != 0u && ss >= mo && !mo_huge) {
+                        k = se.x; kp = se.y; s = ss;
+                        small = false;
+                        j -= (int32_t)img.seed_k - 1;
+                        next += img.seed_k - 1u;
+                    } else if (ss == 0u && depth != PGX_SEED_UNUSABLE && min_occ <= 1) {
+                        k = 0u; kp = 0u; s = 0u;
+                        small = true;
+                        j -= (int32_t)depth - 1;
+                        next += depth - 1u;
+                    }
+                }
+                const bool adv = !small, q1 = ph == 1, q2 = ph == 2, at_x = j == x;
+                const bool to2 = q1 && adv && at_x;
+                const bool keep = adv && (to2 || q2);
+                Jk = keep ? k : Jk;
+                Js = keep ? s : Js;
+                const int32_t jn = adv ? (q1 ? (at_x ? x + (int32_t)min_len : j - 1) : (q2 ? j + 1 : j - 1)) : j;
+                const bool em = (q2 && (small || jn >= len)) || (to2 && jn >= len);
+                const bool rs_small = small && !q2, rs_end = !q1 && !q2 && adv && jn <= x;
+                restart = (rs_small || rs_end) ? 1u : 0u;
+                x = rs_small ? j + 1 : (rs_end ? x + 1 : x);
+                ph = to2 ? 2 : ph;
+                j = jn;
+                if (em) emit();
+                if (restart) begin();
+            }
+        }
+    }
+    unsigned long long tot = next;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
+    if (lane == 0 && tot) atomicAdd(n_ext_total, tot);
+}
+template __global__ void pgx_find_mems_pairs_kernel<false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t, const uint64_t *, pgx_mem *,
+                                                           uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t, uint32_t, uint32_t,
+                                                           pgx_heavy_item *, unsigned long long *, uint32_t *, unsigned long long *);
+template __global__ void pgx_find_mems_pairs_kernel<true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t, const uint64_t *, pgx_mem *,
+                                                          uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t, uint32_t, uint32_t,
+                                                          pgx_heavy_item *, unsigned long long *, uint32_t *, unsigned long long *);
+
+// first extension of every backward stage: the full interval extended by each byte value
+__global__ void __launch_bounds__(256) pgx_first_ext_kernel(PgxDevImage img, uint4 *__restrict__ out) { // out[512]
+    __shared__ uint32_t s_ext[512];
+    __shared__ uint64_t s_C[8];
+    pgx_stage_tables<false>(img, s_ext, s_C, nullptr, nullptr, nullptr);
+    uint64_t k = 0, kp = 0, s = img.n;
+    pgx_extend<false>(img, nullptr, nullptr, nullptr, s_ext, s_C, k, kp, s, threadIdx.x, false);
+    out[threadIdx.x] = make_uint4((uint32_t)k, (uint32_t)kp, (uint32_t)s, 0u);
+    k = 0; kp = 0; s = img.n; // by 0 (what pattern[len] reads as), then by the byte
+    pgx_extend<false>(img, nullptr, nullptr, nullptr, s_ext, s_C, k, kp, s, 0u, false);
+    if (s) pgx_extend<false>(img, nullptr, nullptr, nullptr, s_ext, s_C, k, kp, s, threadIdx.x, false);
+    out[256 + threadIdx.x] = make_uint4((uint32_t)k, (uint32_t)kp, (uint32_t)s, 0u);
+}
 
 // find_mems_function(pattern, min_len, min_occ, x) (algorithm.hpp:653-736) for ONE start position: the MEM it emits (if any), the
 // start position it returns and the extensions it performs.

@@ -48,7 +48,7 @@ static void use_device(int device) {
 struct pgx_device_image {
     int device = -1;
     PgxDevImage img{};
-    DevBuf blocks, dir, blow, consts, tstart, tvals, tdir, seed, exc;
+    DevBuf blocks, dir, blow, consts, tstart, tvals, tdir, seed, exc, pairs, ptab, first_ext;
     DevBuf rstart, rsamp, rdir, lpos, lnext, ldir; // locate image, uploaded on first use
     DevBuf lit_bstart, lit_cum, lit_runs, lit_roff, lit_tabs; // literal count image (quirk 3), uploaded on first use
     PgxLitImage lit{};
@@ -63,7 +63,7 @@ void pgx_release_device_images(pgx_index *h) {
         if (!d) continue;
         if (hipSetDevice(d->device) == hipSuccess) {
             d->blocks.release(); d->dir.release(); d->blow.release(); d->consts.release();
-            d->tstart.release(); d->tvals.release(); d->tdir.release(); d->seed.release(); d->exc.release();
+            d->tstart.release(); d->tvals.release(); d->tdir.release(); d->seed.release(); d->exc.release(); d->pairs.release(); d->ptab.release(); d->first_ext.release();
             d->lit_bstart.release(); d->lit_cum.release(); d->lit_runs.release(); d->lit_roff.release(); d->lit_tabs.release();
             d->rstart.release(); d->rsamp.release(); d->rdir.release(); d->lpos.release(); d->lnext.release(); d->ldir.release();
         }
@@ -154,7 +154,20 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
     d->lds_bytes = (g.dense != 2 && img_bytes <= 48 * 1024) ? ((img_bytes + 15) & ~(size_t)15) : 0; // the dense2 image is never staged in LDS
     g.seed_k = 0;
     g.seed = nullptr;
+    g.pairs = nullptr; g.ptab = nullptr; g.first_ext = nullptr; g.pair_runs = 0;
     if (g.dense && h->has_rank) build_seed_table(d.get());
+    if (m.consts.has_pairs && !m.pairs.empty() && h->has_rank) { // the two-step image next to dense2 (pgx_image.h)
+        upload(d->pairs, m.pairs.data(), m.pairs.size());
+        upload(d->ptab, m.ptab.data(), m.ptab.size() * 4);
+        d->first_ext.ensure(512 * sizeof(uint4));
+        hipLaunchKernelGGL(pgx_first_ext_kernel, dim3(1), dim3(256), 0, nullptr, g, d->first_ext.as<uint4>());
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipDeviceSynchronize());
+        g.pairs = d->pairs.as<uint4>();
+        g.ptab = d->ptab.as<uint32_t>();
+        g.first_ext = d->first_ext.as<uint4>();
+        g.pair_runs = m.consts.pair_runs;
+    }
     h->dev[device] = d.release();
     return h->dev[device];
 }
@@ -824,7 +837,7 @@ struct pgx_batch {
     uint64_t plan_min_len = 0, plan_budget = 0;
     DevBuf reads, offsets;
     // run state
-    DevBuf slot_off, slots, mem_count, mem_off, mems, scan_tmp, counters, heavy_list, heavy_scratch;
+    DevBuf slot_off, slots, mem_count, mem_off, mems, scan_tmp, counters, heavy_list, heavy_scratch, redo_list;
     TagWork tw;
     uint64_t n_mems = 0, n_positions = 0, n_ext = 0, n_tag_overflow = 0;
     bool ran = false, ran_tags = false;
@@ -845,7 +858,7 @@ static void batch_release(pgx_batch *b) {
     if (!b) return;
     if (hipSetDevice(b->device) == hipSuccess) {
         DevBuf *all[] = {&b->reads, &b->offsets, &b->slot_off, &b->slots, &b->mem_count, &b->mem_off, &b->mems, &b->scan_tmp,
-                         &b->counters, &b->heavy_list, &b->heavy_scratch};
+                         &b->counters, &b->heavy_list, &b->heavy_scratch, &b->redo_list};
         for (DevBuf *d : all) d->release();
         b->tw.release();
         HostBuf *hb[] = {&b->h_mem_off, &b->h_mems, &b->h_run_nums, &b->h_pos_off, &b->h_positions};
@@ -994,7 +1007,8 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     float ms_fm = 0, ms_cp = 0;
     uint64_t mem_base = 0;
     int occ = 0, cus = 0;
-    const void *kfn = nullptr, *kfn_wide = nullptr;
+    const void *kfn = nullptr, *kfn_wide = nullptr, *kfn_pairs = nullptr;
+    size_t pairs_lds = 0;
     uint64_t n_ext_host = 0;
     if (n) {
         // persistent grid: as many workgroups as the device keeps resident (no inter-workgroup
@@ -1015,7 +1029,13 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             kfn = in_lds ? (seeded ? (const void *)pgx_find_mems_kernel<true, 1, true, true> : (const void *)pgx_find_mems_kernel<true, 1, true, false>)
                   : d2   ? (seeded ? (const void *)pgx_find_mems_kernel<false, 2, true, true> : (const void *)pgx_find_mems_kernel<false, 2, true, false>)
                          : (seeded ? (const void *)pgx_find_mems_kernel<false, 1, true, true> : (const void *)pgx_find_mems_kernel<false, 1, true, false>);
-        HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, PGX_FM_THREADS, b->dimg->lds_bytes));
+        // two extensions per cache line where the index has a PAIRS image (PGX_FM_PAIRS=0: the dense2 kernel alone); the kernel chosen
+        // above then serves the reads the pairs kernel hands on
+        const char *pv = std::getenv("PGX_FM_PAIRS");
+        // (only behind the seed table: the wide intervals at the start of an unseeded stage always have special positions between their ends)
+        if (img.pairs && seeded && !(pv && pv[0] == '0')) kfn_pairs = (const void *)pgx_find_mems_pairs_kernel<true>;
+        pairs_lds = ((size_t)img.pair_runs + 1) * 32;
+        HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn_pairs ? kfn_pairs : kfn, PGX_FM_THREADS, kfn_pairs ? pairs_lds : b->dimg->lds_bytes));
         HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
         if (occ < 1) occ = 1;
         if (const char *e = std::getenv("PGX_FM_WG_PER_CU")) { // experiments: fewer resident workgroups per CU
@@ -1031,6 +1051,8 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         b->heavy_scratch.ensure((size_t)PGX_FM_HEAVY_GRID * PGX_FM_HEAVY_MAXLEN * sizeof(PgxHeavyResult));
     }
     unsigned long long *d_cursor = d_next + 5; // counters layout: see the allocation above
+    unsigned long long *d_redo_count = d_next + 11, *d_redo_cursor = d_next + 12;
+    if (kfn_pairs) b->redo_list.ensure((n ? n : 1) * sizeof(uint32_t));
     const char *spec_env = std::getenv("PGX_SPEC");
     const bool spec = pass == 0 && chunks.size() == 1 && b->shape_valid && b->shape_reads == n && b->shape_min_len == min_len && b->shape_min_occ == min_occ &&
                       b->shape_tags == want_tags && (!want_tags || (b->tw.have_last && b->tw.last_largest <= PGX_SORT_WG_LDS_CAP)) &&
@@ -1066,9 +1088,19 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             uint32_t a_hext = heavy_ext, a_hcap = PGX_FM_HEAVY_CAP;
             pgx_heavy_item *a_hlist = b->heavy_list.as<pgx_heavy_item>();
             unsigned long long *a_hcount = d_heavy_count;
+            const uint32_t *a_rlist = nullptr;
+            const unsigned long long *a_rcount = nullptr;
+            if (kfn_pairs) { // the pairs kernel first; what it hands on (reads that met \n or N in the BWT) goes through the kernel chosen above
+                uint32_t *a_redo = b->redo_list.as<uint32_t>();
+                unsigned long long *a_redo_n = d_redo_count;
+                void *pargs[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_first, &a_base,
+                                 &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_redo, &a_redo_n};
+                HIPCHECK(hipLaunchKernel(kfn_pairs, dim3(grid), dim3(PGX_FM_THREADS), pargs, pairs_lds, s));
+                a_rlist = a_redo; a_rcount = d_redo_count; a_cur = d_redo_cursor;
+            }
             void *args[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_first, &a_base,
-                            &a_hext, &a_hcap, &a_hlist, &a_hcount};
-            HIPCHECK(hipLaunchKernel(kf, dim3(grid), dim3(PGX_FM_THREADS), args, b->dimg->lds_bytes, s)); // one of the six variants
+                            &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_rlist, &a_rcount};
+            HIPCHECK(hipLaunchKernel(kf, dim3(grid), dim3(PGX_FM_THREADS), args, b->dimg->lds_bytes, s)); // one of the variants
             if (heavy_ext) { // the rest of reads that spent heavy_ext extensions (usually none: the launch then costs a few microseconds)
                 if (b->dimg->lds_bytes)
                     hipLaunchKernelGGL(pgx_find_mems_heavy_kernel<true>, dim3(PGX_FM_HEAVY_GRID), dim3(256), b->dimg->lds_bytes, s, img, a_reads, a_off,
@@ -1084,12 +1116,13 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             record(b, 2, s);
             scan_excl(0, b->mem_count.as<uint32_t>() + c.r0, cn, 0, local, b->scan_tmp, s, reinterpret_cast<uint64_t *>(d_next + 10));
             if (spec) { cm = cm_cap; break; } // nothing is read back: the MEM total stays on the device
-            unsigned long long cc[11];
+            unsigned long long cc[12];
             read_scalars(cc, d_next, sizeof cc, s);
             const bool forced = attempt == 0 && kf != kfn_wide && std::getenv("PGX_FM_NARROW_FORCE_REDO") != nullptr; // tests
             if ((cc[9] || forced) && kf != kfn_wide) { kf = kfn_wide; continue; } // a coordinate left 32 bits: repeat the chunk in 64 bits
             n_ext_host += cc[0];
             b->timing.heavy_reads += (uint32_t)std::min<unsigned long long>(cc[8], PGX_FM_HEAVY_CAP);
+            b->timing.redo_reads += (uint32_t)cc[11];
             cm = cc[10];
             break;
         }
@@ -1109,6 +1142,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         }
     }
     b->n_mems = mem_base;
+    b->timing.pairs_reads = kfn_pairs ? 1u : 0u;
     if (chunks.size() != 1) { // global CSR offsets (a single chunk's local offsets already are global)
         if (chunks.empty()) { record(b, 1, s); record(b, 2, s); }
         scan_excl(0, b->mem_count.p, n, 0, b->mem_off.as<uint64_t>(), b->scan_tmp, s);
@@ -1133,6 +1167,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         b->n_mems = cnt[10];
         n_ext_host = cnt[0];
         b->timing.heavy_reads = (uint32_t)std::min<unsigned long long>(cnt[8], PGX_FM_HEAVY_CAP);
+        b->timing.redo_reads = (uint32_t)cnt[11];
         if (want_tags) {
             TagWork &w = b->tw;
             w.last_big = cnt[16]; w.last_large = cnt[17]; w.last_largest = cnt[18]; w.last_G = cnt[19]; w.last_small = cnt[21];

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PGX_LIB") or os.path.join(PKG_DIR, "libpgx.so")  # PG
 
 OK, ERR_IO, ERR_FORMAT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_ARG, ERR_NOMEM = range(8)
 MODE_COMPAT, MODE_STRICT = 0, 1
-MODE_IMAGE_RL, MODE_IMAGE_DENSE, MODE_IMAGE_DENSE2 = 0x100, 0x200, 0x400  # or-ed into mode: force the layout of the device rank image
+MODE_IMAGE_RL, MODE_IMAGE_DENSE, MODE_IMAGE_DENSE2, MODE_IMAGE_PAIRS = 0x100, 0x200, 0x400, 0x800  # or-ed into mode: force the layout of the device rank image
 IMAGE_RL, IMAGE_DENSE, IMAGE_DENSE2 = 0, 1, 2
 TAGS_AUTO, TAGS_BYTECODE, TAGS_COMPACT = 0, 1, 2
 RUN_TAGS, RUN_TIMING = 1, 2
@@ -32,7 +32,7 @@ class IndexInfo(C.Structure):
         ("n_dev_blocks", u64), ("dir_entries", u64), ("dir_shift", u32), ("is_encoded", u32), ("has_N", u32),
         ("mode", u32), ("has_tags", u32), ("tag_format", u32), ("n_tag_runs", u64), ("tag_dir_entries", u64),
         ("tag_dir_shift", u32), ("image_in_lds", u32), ("image_bytes", u64), ("tag_image_bytes", u64),
-        ("ref_block_mean_bytes", C.c_double), ("max_length", u64), ("n_samples", u64), ("image_kind", u32), ("reserved0", u32),
+        ("ref_block_mean_bytes", C.c_double), ("max_length", u64), ("n_samples", u64), ("image_kind", u32), ("image_pairs", u32),
     ]
 
 
@@ -66,7 +66,7 @@ class Timing(C.Structure):
     _fields_ = [
         ("ms_find_mems", C.c_float), ("ms_compact", C.c_float), ("ms_tag_locate", C.c_float),
         ("ms_tag_gather", C.c_float), ("ms_tag_sort", C.c_float), ("ms_total", C.c_float),
-        ("find_mems_launches", u32), ("heavy_reads", u32),
+        ("find_mems_launches", u32), ("heavy_reads", u32), ("pairs_reads", u32), ("redo_reads", u32),
     ]
 
 
@@ -190,7 +190,7 @@ def convert_tags(in_path, out_path, compact=False):
 
 _VIEW_DTYPES = {0: np.uint8, 1: np.uint64, 2: np.uint64, 3: np.uint64, 4: np.uint64, 5: np.uint32, 6: np.uint8, 7: np.uint16,
                 8: np.uint64, 9: np.uint64, 10: np.uint32, 11: np.uint64, 12: np.uint64, 13: np.uint32, 14: np.uint8, 15: np.uint32,
-                16: np.uint64, 17: np.uint64, 18: np.uint64, 19: np.uint32}
+                16: np.uint64, 17: np.uint64, 18: np.uint64, 19: np.uint32, 20: np.uint32, 21: np.uint32}
 LOCATE_SEQ_IDS, LOCATE_UNIQUE = 1, 2
 NO_POSITION = 0xFFFFFFFFFFFFFFFF
 

@@ -27,7 +27,9 @@ class Consts:
         self.n_tag_runs, self.tag_dir_entries = struct.unpack_from("<2Q", raw, o); o += 16
         self.tag_dir_shift, self.has_tags, self.mode, self.count_supported = struct.unpack_from("<4I", raw, o); o += 16
         self.cnt_tab = struct.unpack_from("<256I", raw, o); o += 1024
-        self.image_kind, _ = struct.unpack_from("<2I", raw, o); o += 8
+        self.image_kind, self.has_pairs = struct.unpack_from("<2I", raw, o); o += 8
+        self.pair_t2 = struct.unpack_from("<32I", raw, o); o += 128
+        self.pair_runs, _ = struct.unpack_from("<2I", raw, o); o += 8
         assert o == len(raw), (o, len(raw))
 
 

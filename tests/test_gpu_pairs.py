@@ -1,0 +1,114 @@
+"""The two-step PAIRS kernel (pgx_find_mems_pairs_kernel: two extensions per cache line; pgx_image.h): MEMs, tag positions and
+the exact extension count equal the oracle's, whatever the seed depth, the mode, min_len (odd, even, below the seed depth) and
+min_occ; reads that meet endmarkers or N in the BWT are handed to the dense2 kernel and come out the same."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import pgx_ffi as P
+import pgx_workload as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(res, ref):
+    assert np.array_equal(res["mem_offsets"], ref["mem_offsets"])
+    assert res["mems"].tobytes() == ref["mems"].tobytes()
+    assert res["n_extensions"] == ref["n_extensions"]
+    assert np.array_equal(res["tag_run_counts"], ref["tag_run_counts"])
+    assert np.array_equal(res["pos_offsets"], ref["pos_offsets"])
+    assert np.array_equal(res["positions"], ref["positions"])
+
+
+def _run(idx, cat, offs, min_len, min_occ):
+    b = idx.batch(cat, offs)
+    b.run(min_len, min_occ, flags=P.RUN_TAGS | P.RUN_TIMING)
+    res, t = b.result(), b.timing()
+    stats = (int(t.pairs_reads), int(t.redo_reads))
+    b.free()
+    return res, stats
+
+
+@pytest.fixture(scope="module")
+def pan(workdir):
+    text = os.path.join(workdir, "pairpan.txt")
+    W.synth_pangenome_text(text, base_len=150000, n_hap=4, seed=33, n_runs=3, n_run_len=(100, 3000))
+    ri_path, tags_path = W.build_index_from_text(text, workdir, "pairpan")[:2]
+    seqs = W.load_sequences(text)
+    cat, offs = W.sample_reads(seqs, 30000, 150, seed=78)
+    rng = np.random.default_rng(4)
+    extra = []
+    for _ in range(600):  # odd bytes, short reads, reads of every length parity
+        s = seqs[int(rng.integers(0, len(seqs)))]
+        ln = int(rng.integers(1, 220))
+        a = int(rng.integers(0, len(s) - ln))
+        r = bytearray(bytes(s[a:a + ln]))
+        for _ in range(int(rng.integers(0, 3))):
+            r[int(rng.integers(0, ln))] = int(rng.choice(np.frombuffer(b"Nacgt\x00$", dtype=np.uint8)))
+        extra.append(bytes(r))
+    for s in seqs[:4]:  # reads that end a sequence (heavy) and reads that start one
+        extra.append(bytes(s[-150:]))
+        extra.append(bytes(s[:150]))
+    ecat, eoffs = O.pack_reads(extra)
+    cat = np.concatenate([cat, ecat])
+    offs = np.concatenate([offs, eoffs[1:] + offs[-1]])
+    return ri_path, tags_path, cat, offs
+
+
+@pytest.mark.parametrize("seed_k", ["0", "7", None])
+def test_pairs_kernel_equals_the_oracle(pan, monkeypatch, seed_k):
+    ri_path, tags_path, cat, offs = pan
+    if seed_k is None:
+        monkeypatch.delenv("PGX_SEED_K", raising=False)
+    else:
+        monkeypatch.setenv("PGX_SEED_K", seed_k)
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    n_reads = len(offs) - 1
+    for mode, omode in ((P.MODE_COMPAT, O.MODE_COMPAT), (P.MODE_STRICT, O.MODE_STRICT)):
+        idx = P.Index(ri_path, tags_path, mode=mode | P.MODE_IMAGE_PAIRS)
+        assert idx.info().image_pairs == 1 and idx.info().image_kind == P.IMAGE_DENSE2
+        idx_seed_k = int(seed_k) if seed_k is not None else 10  # floor(log4 n), n = 1.2 M
+        for min_len, min_occ in [(20, 1), (21, 1), (8, 1), (7, 1), (3, 1), (1, 1), (0, 1), (20, 2), (25, 9), (20, 0), (40, 1), (33, 3)]:
+            ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, mode=omode, threads=O.lib().orc_max_threads())
+            res, (used, redo) = _run(idx, cat, offs, min_len, min_occ)
+            _same(res, ref)
+            seeded = seed_k != "0" and min_len >= idx_seed_k
+            assert used == (1 if seeded else 0)  # the kernel runs behind the seed table only
+            if seeded and seed_k is None and min_occ <= 1:  # (a larger min_occ lets fewer seeds apply: unseeded stages start wide and are handed on)
+                assert redo < n_reads // 3, (min_len, redo)  # the two-step path does the work, not the fallback (a small index: ~0.2 % of its blocks are flagged)
+        idx.close()
+
+
+def test_pairs_kernel_heavy_reads_and_switch(pan, monkeypatch):
+    ri_path, tags_path, cat, offs = pan
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    ref = O.find_mems_batch(ri, tags, cat, offs, 20, 1, threads=O.lib().orc_max_threads())
+    for env in ({"PGX_FM_HEAVY_EXT": "40"}, {"PGX_FM_PAIRS": "0"}, {"PGX_FM_HEAVY_EXT": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | P.MODE_IMAGE_PAIRS)
+        res, (used, _) = _run(idx, cat, offs, 20, 1)
+        _same(res, ref)
+        assert used == (0 if "PGX_FM_PAIRS" in env else 1)
+        idx.close()
+        for k in env:
+            monkeypatch.delenv(k)
+
+
+def test_pairs_kernel_on_an_index_full_of_special_runs(workdir, golden, monkeypatch):
+    """a small multi-sequence index: most blocks hold an endmarker or N neighbour, most reads take the fallback -- same results"""
+    ri_path, tags_path = W.build_index_from_rlbwt(os.path.join(golden, "med_test.rl_bwt"), workdir, "pairs_med")
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    rng = np.random.default_rng(8)
+    reads = ["".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(1, 60)))) for _ in range(3000)]
+    cat, offs = O.pack_reads([r.encode() for r in reads])
+    monkeypatch.setenv("PGX_SEED_K", "6")
+    idx = P.Index(ri_path, tags_path, mode=P.MODE_STRICT | P.MODE_IMAGE_PAIRS)
+    for min_len, min_occ in [(3, 1), (6, 1), (7, 2), (12, 1)]:
+        ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, mode=O.MODE_STRICT, threads=O.lib().orc_max_threads())
+        res, (used, _) = _run(idx, cat, offs, min_len, min_occ)
+        _same(res, ref)
+        assert used == (1 if min_len >= 6 else 0)
+    idx.close()
