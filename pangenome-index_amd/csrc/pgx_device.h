@@ -33,6 +33,10 @@ struct PgxDevImage {
     // the k bytes of a window, last byte first (pgx_seed_build_kernel); 0 = no table
     uint32_t seed_k;
     const uint4 *seed; // 4^seed_k entries {k lo, k' lo, s lo, k hi | k' hi << 8 | s hi << 16 | depth << 24}
+    // end table: the same for a stage that starts at j = len: the full interval extended by 0 (what pattern[len] reads as) and then by the
+    // seed_end_k bytes before the end of the read; depths count the extension by 0
+    uint32_t seed_end_k;
+    const uint4 *seed_end;
     // PAIRS image (NULL without one): blocks, ptab (8 dwords per special-run count), first extensions of the full interval
     const uint4 *pairs;
     const uint32_t *ptab;
@@ -61,7 +65,7 @@ __global__ void pgx_find_mems_heavy_kernel(PgxDevImage img, const uint8_t *reads
                                            unsigned long long *n_ext_total, const pgx_heavy_item *heavy_list,
                                            const unsigned long long *heavy_count, uint32_t heavy_cap, PgxHeavyResult *scratch);
 
-__global__ void pgx_seed_build_kernel(PgxDevImage img, const uint4 *src, uint4 *dst, uint32_t level, uint64_t n_dst, uint64_t limit);
+__global__ void pgx_seed_build_kernel(PgxDevImage img, const uint4 *src, uint4 *dst, uint32_t level, uint64_t n_dst, uint64_t limit, int end_table);
 template <bool LDS_IMAGE, int DENSE, bool NARROW, bool SEED> // DENSE = image kind
 __global__ void pgx_find_mems_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
                                      uint64_t min_len, uint64_t min_occ, const uint64_t *slot_off, pgx_mem *slots,

@@ -435,7 +435,7 @@ __device__ __forceinline__ bool pgx_seed_index(uint64_t lo, uint64_t hi, uint32_
 
 // level `level` (4^level entries, src; level 0 = the full interval) -> level + 1: entry (p << 2 | c) = entry p extended by code c
 __global__ void __launch_bounds__(256)
-pgx_seed_build_kernel(PgxDevImage img, const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t level, uint64_t n_dst, uint64_t limit) {
+pgx_seed_build_kernel(PgxDevImage img, const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t level, uint64_t n_dst, uint64_t limit, int end_table) {
     __shared__ uint32_t s_ext[512];
     __shared__ uint64_t s_C[8];
     pgx_stage_tables<false>(img, s_ext, s_C, nullptr, nullptr, nullptr);
@@ -443,6 +443,11 @@ pgx_seed_build_kernel(PgxDevImage img, const uint4 *__restrict__ src, uint4 *__r
     if (i >= n_dst) return;
     uint64_t k = 0, kp = 0, s = img.n;
     uint32_t depth = 0;
+    const uint32_t base_depth = end_table ? 1u : 0u; // the end table: level 0 is the full interval extended by 0 (pattern[len]), which counts as an extension
+    if (end_table && !level) {
+        pgx_extend<false>(img, nullptr, nullptr, nullptr, s_ext, s_C, k, kp, s, 0u, false);
+        if (s == 0) { k = 0; kp = 0; depth = 1u; }
+    }
     if (level) {
         const uint4 e = src[i >> 2];
         k = (uint64_t)e.x | ((uint64_t)(e.w & 0xFFu) << 32);
@@ -453,7 +458,7 @@ pgx_seed_build_kernel(PgxDevImage img, const uint4 *__restrict__ src, uint4 *__r
     if (s != 0) {
         const uint32_t byte = (0x47544341u >> (8u * (uint32_t)(i & 3))) & 0xFFu; // "ACTG"[code]
         pgx_extend<false>(img, nullptr, nullptr, nullptr, s_ext, s_C, k, kp, s, byte, false);
-        if (s == 0) { k = 0; kp = 0; depth = level + 1; }
+        if (s == 0) { k = 0; kp = 0; depth = level + 1 + base_depth; }
         else if (k >= limit || kp >= limit || k + s >= limit || kp + s >= limit || k + s < k || kp + s < kp) { k = 0; kp = 0; s = 0; depth = PGX_SEED_UNUSABLE; }
     }
     uint4 o;
@@ -611,20 +616,24 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
             // ---- k-mer seed of a backward stage that starts now: the entry is loaded next to the block loads of the ordinary
             //      extension by P[j] (which every lane performs regardless) and replaces its result further down ----
             bool seed_lane = false;
+            uint32_t kuse = 0u; // extensions the seed entry stands for
             uint4 se = make_uint4(0u, 0u, 0u, 0u);
             if (SEED) {
                 const uint4 *sp = img.seed;
                 if (fresh) {
-                    const int32_t K = (int32_t)img.seed_k;
+                    // a stage that starts at j = len (step 3 of a MEM that reaches the end of its read) extends by 0 first, pattern[len]:
+                    // the end table holds that extension followed by the seed_end_k bytes before the end of the read
+                    const bool endw = j >= len;
+                    const int32_t K = endw ? (int32_t)img.seed_end_k : (int32_t)img.seed_k;
                     const int32_t avail = (ph == 1) ? (j - x + 1) : (j - x); // extensions this stage may still perform
-                    if (avail >= K && j < len) {
-                        const uint64_t a = base + (uint64_t)(j - K + 1);
+                    if (K && avail >= K + (endw ? 1 : 0)) {
+                        const uint64_t a = base + (uint64_t)((endw ? len - 1 : j) - K + 1);
                         const uint32_t sh = (uint32_t)(a & 7ull) * 8u;
                         const uint64_t *wp = reinterpret_cast<const uint64_t *>(reads + (a & ~7ull)); // 32 zero bytes follow the last read
                         const uint64_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
                         const uint64_t lo = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0, hi = sh ? (w1 >> sh) | (w2 << (64u - sh)) : w1;
                         uint32_t sidx;
-                        if (pgx_seed_index(lo, hi, (uint32_t)K, sidx)) { seed_lane = true; sp = img.seed + sidx; }
+                        if (pgx_seed_index(lo, hi, (uint32_t)K, sidx)) { seed_lane = true; sp = (endw ? img.seed_end : img.seed) + sidx; kuse = (uint32_t)K + (endw ? 1u : 0u); }
                     }
                 }
                 fresh = 0u;
@@ -735,8 +744,8 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                         kp = NARROW ? (pos_t)se.y : (pos_t)((uint64_t)se.y | ((uint64_t)((se.w >> 8) & 0xFFu) << 32));
                         s = ss;
                         small = false;
-                        j -= (int32_t)img.seed_k - 1;
-                        next += img.seed_k - 1u;
+                        j -= (int32_t)kuse - 1;
+                        next += kuse - 1u;
                     } else if (ss == 0 && depth != PGX_SEED_UNUSABLE && min_occ <= 1) {
                         // the window leaves the index at its depth-th extension (only "empty" is small when min_occ <= 1)
                         k = 0; kp = 0; s = 0;
@@ -812,21 +821,25 @@ PGX_FM_INSTANTIATE(false, 2, true, true)
 // img.first_ext (or the seed table): the image is never probed with the full interval.
 // A lane that meets a flagged block, or two blocks with special positions between them, gives its read up: the read id goes to
 // redo_list and pgx_find_mems_kernel (dense2 image) searches it from the start.
+__device__ __forceinline__ uint32_t pgx_window_byte(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, uint64_t a) { // byte a of the 32-byte window
+    const uint64_t wlo = (a & 8ull) ? w1 : w0, whi = (a & 8ull) ? w3 : w2;
+    return (uint32_t)(((a & 16ull) ? whi : wlo) >> (8u * (uint32_t)(a & 7ull))) & 0xFFu;
+}
 struct PgxPairsIn { uint32_t n1, n2, n3, q0, q1, q2, q3; };
-__device__ __forceinline__ PgxPairsIn pgx_pairs_inblock(const uint4 &a0, const uint4 &a1, const uint4 &b0, const uint4 &b1, uint32_t rel, uint32_t inv0,
-                                                        uint32_t inv1) {
-    const uint32_t A0[4] = {a0.x, a0.y, a0.z, a0.w}, A1[4] = {a1.x, a1.y, a1.z, a1.w}, B0[4] = {b0.x, b0.y, b0.z, b0.w}, B1[4] = {b1.x, b1.y, b1.z, b1.w};
-    PgxPairsIn o = {0, 0, 0, 0, 0, 0, 0};
+// in-block counts below rel: n1 / n2 / n3 = positions with bit 0 / bit 1 / both bits of the first symbol, q0 = positions whose first
+// symbol is the one extended by (inv0, inv1 turn its code into all-ones), q1 / q2 / q3 = those with bit 0 / bit 1 / both of the second
+__device__ __forceinline__ PgxPairsIn pgx_pairs_count(const uint32_t (&x)[4], const uint32_t (&y)[4], const uint32_t (&m1)[4], const uint32_t (&u)[4],
+                                                      const uint32_t (&v)[4], uint32_t rel) {
+    PgxPairsIn o;
+    uint32_t n1 = 0, n2 = 0, n3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
 #pragma unroll
     for (int h = 0; h < 4; h++) {
         const int32_t t = (int32_t)rel - 32 * h; // bits of this dword below the position
         const uint32_t m = t >= 32 ? 0xFFFFFFFFu : (t > 0 ? ((1u << t) - 1u) : 0u);
-        const uint32_t x = A0[h] & m, y = A1[h] & m;
-        o.n1 += __popc(x); o.n2 += __popc(y); o.n3 += __popc(x & y);
-        const uint32_t m1 = (A0[h] ^ inv0) & (A1[h] ^ inv1) & m; // positions whose first symbol is the one extended by
-        const uint32_t u = m1 & B0[h], v = m1 & B1[h];
-        o.q0 += __popc(m1); o.q1 += __popc(u); o.q2 += __popc(v); o.q3 += __popc(u & v);
+        n1 += __popc(x[h] & m); n2 += __popc(y[h] & m); n3 += __popc(x[h] & y[h] & m);
+        q0 += __popc(m1[h] & m); q1 += __popc(u[h] & m); q2 += __popc(v[h] & m); q3 += __popc(u[h] & v[h] & m);
     }
+    o.n1 = n1; o.n2 = n2; o.n3 = n3; o.q0 = q0; o.q1 = q1; o.q2 = q2; o.q3 = q3;
     return o;
 }
 
@@ -855,16 +868,21 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     const uint32_t n = (uint32_t)img.n;
     const uint32_t mo = min_occ > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)min_occ; // sizes are below 2^32: a larger min_occ makes everything "small" either way
     const bool mo_huge = min_occ > 0xFFFFFFFFull;
-    uint64_t rid = 0, base = 0, slot = 0;
+    uint32_t rid = 0; // (the launch serves fewer than 2^32 reads: pgx_batch_run)
+    uint64_t base = 0, slot = 0;
     int32_t len = 0, x = 0, j = 0;
     uint32_t k = 0, kp = 0, s = 0, Jk = 0, Js = 0;
     uint32_t nm = 0, next = 0, next0 = 0;
     int ph = 0;
-    uint64_t win = 0, win_hi = 0, win2 = 0, win3 = 0, win_at = ~0ull;
+    uint64_t win = 0, win_hi = 0, win2 = 0, win3 = 0;
+    uint32_t win_at = ~0u; // the cached 32 bytes of the reads buffer: their offset / 32
     uint32_t X0a = 0, X0b = 0, X0c = 0, X0d = 0, ri0 = 0; // first-probe sums of an extension whose second probe is pending
     uint32_t pend = 0, fresh = 0, restart = 0;
     uint64_t rnext = 0, rend = 0;
     bool exhausted = false;
+#ifdef PGX_FM_STATS
+    unsigned long long st_trips = 0, st_live = 0, st_two = 0, st_wait = 0, st_fresh = 0; // diagnostics build only (scripts/fm_stats.sh)
+#endif
 
     auto begin = [&]() __attribute__((always_inline)) {
         if (x >= len || (uint64_t)(len - x) < min_len) { ph = 0; mem_count[rid] = nm; return; }
@@ -872,7 +890,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             const unsigned long long at = atomicAdd(heavy_count, 1ull);
             if (at < (unsigned long long)heavy_cap) {
                 pgx_heavy_item it;
-                it.rid = rid; it.x = (uint32_t)x; it.nm = nm;
+                it.rid = (uint64_t)rid; it.x = (uint32_t)x; it.nm = nm;
                 heavy_list[at] = it;
                 ph = 0;
                 return;
@@ -911,7 +929,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             const uint64_t avail = rend - rnext;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             if (ph == 0 && (uint64_t)rank < avail) {
-                rid = rnext + rank;
+                rid = (uint32_t)(rnext + rank);
                 base = offsets[rid];
                 len = (int32_t)(offsets[rid + 1] - base);
                 slot = slot_off[rid] - slot_base;
@@ -929,23 +947,30 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             if (exhausted && rnext == rend) break;
             continue;
         }
+#ifdef PGX_FM_STATS
+        st_trips++;
+        st_live += (unsigned long long)__popcll(__ballot(ph > 0));
+        st_fresh += (unsigned long long)__popcll(__ballot(ph > 0 && fresh != 0u));
+#endif
         if (ph > 0) {
             const bool fr = fresh != 0u; // first extension of a backward stage: from first_ext / the seed table
             bool seed_lane = false;
+            uint32_t kuse = 0u; // extensions the seed entry stands for
             uint4 se = make_uint4(0u, 0u, 0u, 0u);
             if (SEED) {
                 const uint4 *sp = img.seed;
                 if (fr) {
-                    const int32_t K = (int32_t)img.seed_k;
+                    const bool endw = j >= len; // (the end table: see pgx_find_mems_kernel)
+                    const int32_t K = endw ? (int32_t)img.seed_end_k : (int32_t)img.seed_k;
                     const int32_t avail = (ph == 1) ? (j - x + 1) : (j - x);
-                    if (avail >= K && j < len) {
-                        const uint64_t a = base + (uint64_t)(j - K + 1);
+                    if (K && avail >= K + (endw ? 1 : 0)) {
+                        const uint64_t a = base + (uint64_t)((endw ? len - 1 : j) - K + 1);
                         const uint32_t sh = (uint32_t)(a & 7ull) * 8u;
                         const uint64_t *wp = reinterpret_cast<const uint64_t *>(reads + (a & ~7ull));
                         const uint64_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
                         const uint64_t lo = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0, hi = sh ? (w1 >> sh) | (w2 << (64u - sh)) : w1;
                         uint32_t sidx;
-                        if (pgx_seed_index(lo, hi, (uint32_t)K, sidx)) { seed_lane = true; sp = img.seed + sidx; }
+                        if (pgx_seed_index(lo, hi, (uint32_t)K, sidx)) { seed_lane = true; sp = (endw ? img.seed_end : img.seed) + sidx; kuse = (uint32_t)K + (endw ? 1u : 0u); }
                     }
                 }
                 se = *sp;
@@ -958,21 +983,19 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             // (block 0 of the image) have the sequences' last symbols before them, often N
             const bool at_end = j >= len;
             const uint64_t atw = at_end ? at - 1ull : at; // (a live read has len >= 1)
-            if ((atw & ~31ull) != win_at) {
-                win_at = atw & ~31ull;
-                const ulonglong2 w2 = *reinterpret_cast<const ulonglong2 *>(reads + win_at);
-                const ulonglong2 w3 = *reinterpret_cast<const ulonglong2 *>(reads + win_at + 16);
+            if ((uint32_t)(atw >> 5) != win_at) {
+                win_at = (uint32_t)(atw >> 5);
+                const ulonglong2 w2 = *reinterpret_cast<const ulonglong2 *>(reads + (atw & ~31ull));
+                const ulonglong2 w3 = *reinterpret_cast<const ulonglong2 *>(reads + (atw & ~31ull) + 16);
                 win = w2.x; win_hi = w2.y; win2 = w3.x; win3 = w3.y;
             }
-            auto window_byte = [&](uint64_t a) __attribute__((always_inline)) {
-                const uint64_t wlo = (a & 8ull) ? win_hi : win, whi = (a & 8ull) ? win3 : win2;
-                return (uint32_t)(((a & 16ull) ? whi : wlo) >> (8u * (uint32_t)(a & 7ull))) & 0xFFu;
-            };
-            const uint32_t byte = at_end ? 0u : window_byte(at);
+            // (a function of values: as a lambda capturing the window by reference it turned into loads through a selected address,
+            //  with the window in scratch memory)
+            const uint32_t byte = at_end ? 0u : pgx_window_byte(win, win_hi, win2, win3, at);
             // the symbol after this one in the direction of the stage, when the cached window holds it
             const uint64_t at2 = (fwd && !at_end) ? at + 1ull : at - 1ull;
-            const bool have2 = (at2 & ~31ull) == win_at;
-            const uint32_t byte2 = window_byte(at2);
+            const bool have2 = (uint32_t)(at2 >> 5) == win_at;
+            const uint32_t byte2 = pgx_window_byte(win, win_hi, win2, win3, at2);
             const uint32_t e1 = s_ext[(fwd ? 256u : 0u) + byte], e2 = s_ext[(fwd ? 256u : 0u) + byte2];
             const uint32_t cv1 = PGX_EXT_CV(e1), cv2 = PGX_EXT_CV(e2);
             const bool reg1 = !PGX_EXT_KILL(e1) && ((0x2Eu >> cv1) & 1u), reg2 = !PGX_EXT_KILL(e2) && ((0x2Eu >> cv2) & 1u); // A C G T
@@ -990,7 +1013,12 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             const bool same = !pend && (p1 - bs <= 128u);
             const uint32_t relB = same ? p1 - bs : relA;
             const uint32_t inv0 = (t1 & 1u) ? 0u : 0xFFFFFFFFu, inv1 = (t1 & 2u) ? 0u : 0xFFFFFFFFu;
-            const PgxPairsIn iA = pgx_pairs_inblock(a0, a1, b0, b1, relA, inv0, inv1), iB = pgx_pairs_inblock(a0, a1, b0, b1, relB, inv0, inv1);
+            // (the masked planes are formed once and both positions counted from them: with the loads inside a per-position helper the
+            //  compiler loaded the block twice)
+            const uint32_t px[4] = {a0.x, a0.y, a0.z, a0.w}, py[4] = {a1.x, a1.y, a1.z, a1.w};
+            const uint32_t pm[4] = {(a0.x ^ inv0) & (a1.x ^ inv1), (a0.y ^ inv0) & (a1.y ^ inv1), (a0.z ^ inv0) & (a1.z ^ inv1), (a0.w ^ inv0) & (a1.w ^ inv1)};
+            const uint32_t pu[4] = {pm[0] & b0.x, pm[1] & b0.y, pm[2] & b0.z, pm[3] & b0.w}, pv[4] = {pm[0] & b1.x, pm[1] & b1.y, pm[2] & b1.z, pm[3] & b1.w};
+            const PgxPairsIn iA = pgx_pairs_count(px, py, pm, pu, pv, relA), iB = pgx_pairs_count(px, py, pm, pu, pv, relB);
             // counts before the block: rows of the header (first symbol y: second symbols A C G T), the sixteenth derived
             const uint32_t pt0 = s_pt[8u * ri], pts = s_pt[8u * ri + 1u + t1];
             const uint32_t rs0 = h0.x + h0.y + h0.z + h0.w, rs1 = h1.x + h1.y + h1.z + h1.w, rs2 = h2.x + h2.y + h2.z + h2.w;
@@ -1017,8 +1045,11 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             sums(iB, relB, XBa, XBb, XBc, XBd);
             const bool bail = !fr && (flagged || (pend && ri != ri0));
             const bool wait = !fr && !pend && !same && !bail; // the second probe lies in another block: next trip
+#ifdef PGX_FM_STATS
+            st_wait += wait ? 1ull : 0ull;
+#endif
             if (bail) { // special positions in the way: the dense2 kernel searches this read
-                redo_list[atomicAdd(redo_count, 1ull)] = (uint32_t)rid;
+                redo_list[atomicAdd(redo_count, 1ull)] = rid;
                 ph = 0; next = next0; pend = 0u;
             } else if (wait) {
                 X0a = XAa; X0b = XAb; X0c = XAc; X0d = XAd; ri0 = ri;
@@ -1032,7 +1063,11 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 uint32_t k1 = Q0a + s_C[PGX_EXT_V(e1)], q1v = kq + (Q1c - Q0c);
                 if (fr) { const uint4 f = s_fe[byte]; k1 = f.x; q1v = f.y; s1 = f.z; }
                 const bool small1 = s1 == 0u || s1 < mo || mo_huge;
-                const bool do2 = (fr ? (at_end && rem2 && have2) : two) && !small1;
+                // a usable seed entry stands for the first extension and the ones after it
+                const uint32_t sdepth = se.w >> 24;
+                const bool seed_alive = SEED && seed_lane && se.z != 0u && se.z >= mo && !mo_huge;
+                const bool seed_dead = SEED && seed_lane && se.z == 0u && sdepth != PGX_SEED_UNUSABLE && min_occ <= 1;
+                const bool do2 = (fr ? (at_end && rem2 && have2 && !seed_alive && !seed_dead) : two) && !small1;
                 uint32_t s2 = Q1b - Q0b, k2 = Q0b + s_C[PGX_EXT_V(e2)] + s_t2[8u * t1 + cv2], q2v = q1v + (Q1d - Q0d);
                 if (fr) { const uint4 f = s_fe[256u + byte2]; k2 = f.x; q2v = f.y; s2 = f.z; }
                 uint32_t ns = do2 ? s2 : s1, nk = do2 ? k2 : k1, nq = do2 ? q2v : q1v;
@@ -1043,24 +1078,23 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                     j = fwd ? j + 1 : j - 1;
                 }
                 next += do2 ? 2u : 1u;
+#ifdef PGX_FM_STATS
+                st_two += do2 ? 1ull : 0ull;
+#endif
                 s = ns;
                 k = fwd ? nq : nk;
                 kp = fwd ? nk : nq;
                 bool small = ns == 0u || ns < mo || mo_huge;
-                if (SEED && seed_lane) {
-                    const uint32_t depth = se.w >> 24;
-                    const uint32_t ss = se.z;
-                    if (ss != 0u && ss >= mo && !mo_huge) {
-                        k = se.x; kp = se.y; s = ss;
-                        small = false;
-                        j -= (int32_t)img.seed_k - 1;
-                        next += img.seed_k - 1u;
-                    } else if (ss == 0u && depth != PGX_SEED_UNUSABLE && min_occ <= 1) {
-                        k = 0u; kp = 0u; s = 0u;
-                        small = true;
-                        j -= (int32_t)depth - 1;
-                        next += depth - 1u;
-                    }
+                if (seed_alive) { // all its extensions at once: sizes only shrink along a stage, so none of the skipped ones was "small"
+                    k = se.x; kp = se.y; s = se.z;
+                    small = false;
+                    j -= (int32_t)kuse - 1;
+                    next += kuse - 1u;
+                } else if (seed_dead) { // the window leaves the index at its depth-th extension
+                    k = 0u; kp = 0u; s = 0u;
+                    small = true;
+                    j -= (int32_t)sdepth - 1;
+                    next += sdepth - 1u;
                 }
                 const bool adv = !small, q1 = ph == 1, q2 = ph == 2, at_x = j == x;
                 const bool to2 = q1 && adv && at_x;
@@ -1083,6 +1117,11 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
     if (lane == 0 && tot) atomicAdd(n_ext_total, tot);
+#ifdef PGX_FM_STATS // slots 2, 4 wave trips / live lane-trips, 13, 14, 15 lane-trips with two extensions / waiting for the second block / fresh
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { st_two += __shfl_down(st_two, off, 64); st_wait += __shfl_down(st_wait, off, 64); }
+    if (lane == 0) { atomicAdd(n_ext_total + 2, st_trips); atomicAdd(n_ext_total + 4, st_live); atomicAdd(n_ext_total + 13, st_two); atomicAdd(n_ext_total + 14, st_wait); atomicAdd(n_ext_total + 15, st_fresh); }
+#endif
 }
 template __global__ void pgx_find_mems_pairs_kernel<false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t, const uint64_t *, pgx_mem *,
                                                            uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t, uint32_t, uint32_t,

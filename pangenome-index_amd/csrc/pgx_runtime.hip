@@ -48,7 +48,7 @@ static void use_device(int device) {
 struct pgx_device_image {
     int device = -1;
     PgxDevImage img{};
-    DevBuf blocks, dir, blow, consts, tstart, tvals, tdir, seed, exc, pairs, ptab, first_ext;
+    DevBuf blocks, dir, blow, consts, tstart, tvals, tdir, seed, seed_end, exc, pairs, ptab, first_ext;
     DevBuf rstart, rsamp, rdir, lpos, lnext, ldir; // locate image, uploaded on first use
     DevBuf lit_bstart, lit_cum, lit_runs, lit_roff, lit_tabs; // literal count image (quirk 3), uploaded on first use
     PgxLitImage lit{};
@@ -63,7 +63,7 @@ void pgx_release_device_images(pgx_index *h) {
         if (!d) continue;
         if (hipSetDevice(d->device) == hipSuccess) {
             d->blocks.release(); d->dir.release(); d->blow.release(); d->consts.release();
-            d->tstart.release(); d->tvals.release(); d->tdir.release(); d->seed.release(); d->exc.release(); d->pairs.release(); d->ptab.release(); d->first_ext.release();
+            d->tstart.release(); d->tvals.release(); d->tdir.release(); d->seed.release(); d->seed_end.release(); d->exc.release(); d->pairs.release(); d->ptab.release(); d->first_ext.release();
             d->lit_bstart.release(); d->lit_cum.release(); d->lit_runs.release(); d->lit_roff.release(); d->lit_tabs.release();
             d->rstart.release(); d->rsamp.release(); d->rdir.release(); d->lpos.release(); d->lnext.release(); d->ldir.release();
         }
@@ -94,19 +94,28 @@ static void build_seed_table(pgx_device_image *d) {
     if (K < 2) return;
     const uint64_t limit = g.n < (1ull << 30) ? (1ull << 32) : (1ull << 40); // what an entry (and the 32-bit kernels) can hold
     DevBuf tmp;
-    try {
-        d->seed.ensure(((size_t)1 << (2 * K)) * sizeof(uint4));
-        tmp.ensure(((size_t)1 << (2 * (K - 1))) * sizeof(uint4));
-        for (int L = 0; L < K; L++) { // level L -> L + 1; level K ends in d->seed
-            uint4 *dst = ((K - (L + 1)) % 2 == 0) ? d->seed.as<uint4>() : tmp.as<uint4>();
-            const uint4 *src = ((K - L) % 2 == 0) ? d->seed.as<uint4>() : tmp.as<uint4>();
+    // end table (stages that start at j = len, i.e. with the extension by 0): depth 8, 1 MiB -- such a stage almost always dies within a few
+    // extensions (a read rarely ends where a sequence ends), which the entry's death depth answers at once
+    int Ke = std::min(K, 8);
+    if (const char *e = std::getenv("PGX_SEED_END_K")) Ke = std::max(0, std::min(std::atoi(e), 12));
+    auto build = [&](DevBuf &out, int depth, int end_table) {
+        out.ensure(((size_t)1 << (2 * depth)) * sizeof(uint4));
+        tmp.ensure(((size_t)1 << (2 * (depth - 1))) * sizeof(uint4));
+        for (int L = 0; L < depth; L++) { // level L -> L + 1; level `depth` ends in out
+            uint4 *dst = ((depth - (L + 1)) % 2 == 0) ? out.as<uint4>() : tmp.as<uint4>();
+            const uint4 *src = ((depth - L) % 2 == 0) ? out.as<uint4>() : tmp.as<uint4>();
             const uint64_t n_dst = 1ull << (2 * (L + 1));
-            hipLaunchKernelGGL(pgx_seed_build_kernel, dim3((unsigned)((n_dst + 255) / 256)), dim3(256), 0, nullptr, g, src, dst, (uint32_t)L, n_dst, limit);
+            hipLaunchKernelGGL(pgx_seed_build_kernel, dim3((unsigned)((n_dst + 255) / 256)), dim3(256), 0, nullptr, g, src, dst, (uint32_t)L, n_dst, limit, end_table);
             HIPCHECK(hipGetLastError());
         }
         HIPCHECK(hipDeviceSynchronize());
-    } catch (...) { tmp.release(); d->seed.release(); throw; }
+    };
+    try {
+        build(d->seed, K, 0);
+        if (Ke >= 2) build(d->seed_end, Ke, 1);
+    } catch (...) { tmp.release(); d->seed.release(); d->seed_end.release(); throw; }
     tmp.release();
+    if (Ke >= 2) { g.seed_end = d->seed_end.as<uint4>(); g.seed_end_k = (uint32_t)Ke; }
     g.seed = d->seed.as<uint4>();
     g.seed_k = (uint32_t)K;
 }
@@ -154,6 +163,8 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
     d->lds_bytes = (g.dense != 2 && img_bytes <= 48 * 1024) ? ((img_bytes + 15) & ~(size_t)15) : 0; // the dense2 image is never staged in LDS
     g.seed_k = 0;
     g.seed = nullptr;
+    g.seed_end_k = 0;
+    g.seed_end = nullptr;
     g.pairs = nullptr; g.ptab = nullptr; g.first_ext = nullptr; g.pair_runs = 0;
     if (g.dense && h->has_rank) build_seed_table(d.get());
     if (m.consts.has_pairs && !m.pairs.empty() && h->has_rank) { // the two-step image next to dense2 (pgx_image.h)
@@ -318,7 +329,7 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
         uint64_t hv[6] = {0, 0, 0, 0, 0, 0};
         read_scalars(hv, sc, 48, s);
         G = hv[3]; nbig = hv[0]; nlarge = hv[1]; nsmall = hv[5]; largest = hv[2];
-        if (std::getenv("PGX_DEBUG_COUNTERS")) std::fprintf(stderr, "[pgx] tag stage: m %llu big %llu large %llu largest %llu G %llu small %llu\n", (unsigned long long)m,
+    if (std::getenv("PGX_DEBUG_COUNTERS")) std::fprintf(stderr, "[pgx] tag stage: m %llu big %llu large %llu largest %llu G %llu small %llu\n", (unsigned long long)m,
                                                             (unsigned long long)nbig, (unsigned long long)nlarge, (unsigned long long)largest, (unsigned long long)G, (unsigned long long)nsmall);
     } else { // capacities from the previous run; the device checks what it can before anything is written through them
         G = with_slack(w.last_G); nbig = with_slack(w.last_big); nlarge = with_slack(w.last_large); nsmall = with_slack(w.last_small);
@@ -382,7 +393,7 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
             uint64_t rd[2] = {0, 0};
             read_scalars(rd, sc + 6, 16, s);
             nrep = rd[0]; ndup = rd[1];
-            if (std::getenv("PGX_DEBUG_COUNTERS")) std::fprintf(stderr, "[pgx] tag stage: representatives %llu duplicates %llu\n", (unsigned long long)nrep, (unsigned long long)ndup);
+    if (std::getenv("PGX_DEBUG_COUNTERS")) std::fprintf(stderr, "[pgx] tag stage: representatives %llu duplicates %llu\n", (unsigned long long)nrep, (unsigned long long)ndup);
         } else { nrep = nlarge; ndup = nlarge; } // (capacities: the lists cannot be longer than the large list)
         if (nrep) {
             hipLaunchKernelGGL(pgx_tag_gather_kernel, dim3(spec ? fixed_grid(nrep, 4, 8192) : grid_for(nrep, 4)), dim3(256), 0, s, img, (const uint64_t *)d_reps, nrep,
@@ -1033,7 +1044,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         // above then serves the reads the pairs kernel hands on
         const char *pv = std::getenv("PGX_FM_PAIRS");
         // (only behind the seed table: the wide intervals at the start of an unseeded stage always have special positions between their ends)
-        if (img.pairs && seeded && !(pv && pv[0] == '0')) kfn_pairs = (const void *)pgx_find_mems_pairs_kernel<true>;
+        if (img.pairs && seeded && !(n >> 32) && b->read_bytes < (1ull << 36) && !(pv && pv[0] == '0')) kfn_pairs = (const void *)pgx_find_mems_pairs_kernel<true>;
         pairs_lds = ((size_t)img.pair_runs + 1) * 32;
         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn_pairs ? kfn_pairs : kfn, PGX_FM_THREADS, kfn_pairs ? pairs_lds : b->dimg->lds_bytes));
         HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
@@ -1181,7 +1192,10 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     if (cnt[6] && std::getenv("PGX_FM_STATS")) // only a -DPGX_FM_STATS build of the kernels fills these (scripts/fm_stats.sh)
         std::fprintf(stderr, "[pgx] find_mems wave trips %llu, live lane-trips %llu (%.1f%% of lanes), longest wave %llu trips, extensions %llu\n", cnt[6], cnt[7],
                      100.0 * (double)cnt[7] / (64.0 * (double)cnt[6]), cnt[3], cnt[0]);
-    if (std::getenv("PGX_DEBUG_COUNTERS")) std::fprintf(stderr, "[pgx] counters %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[6], cnt[7], cnt[8]);
+    if (cnt[2] && std::getenv("PGX_FM_STATS"))
+        std::fprintf(stderr, "[pgx] pairs kernel wave trips %llu, live lane-trips %llu (%.1f%%), with two extensions %llu, waiting for a second block %llu, fresh %llu, reads handed on %llu\n",
+                     cnt[2], cnt[4], 100.0 * (double)cnt[4] / (64.0 * (double)cnt[2]), cnt[13], cnt[14], cnt[15], cnt[11]);
+    if (std::getenv("PGX_DEBUG_COUNTERS")) std::fprintf(stderr, "[pgx] counters %llu %llu %llu %llu %llu %llu %llu %llu %llu redo %llu\n", cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[6], cnt[7], cnt[8], cnt[11]);
     b->n_ext = n_ext_host;
     b->n_tag_overflow = cnt[1];
     if (b->timed) {
