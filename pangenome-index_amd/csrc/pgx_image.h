@@ -72,18 +72,18 @@
  * index.  Position p carries the PAIR (c1, c2) = (BWT[p], BWT[LF(p)]) = the two text symbols before suffix p, so the ranks of
  * pairs at the two ends of an interval give the interval after TWO extensions -- the positions with c1 = a are mapped by LF,
  * in order, onto the interval after the first extension, and BWT there is c2 -- from the same cache line that answers one:
- * find_mems performs half the dependent line fetches.  128 symbols per 128-byte block, n bytes in all:
- *   dw 4 y + x   (y, x in A C G T = 0..3) number of positions q < 128 b with c1(q) = y, c2(q) = x; except
- *   dw 15        bit 31: the block holds a SPECIAL position (c1 or c2 is \n or N); bits 0..30: special runs (maximal runs of
- *                consecutive special positions) that start before the block.  The count of (T, T) is 128 b minus the other
- *                fifteen minus the special positions before the block (ptab)
- *   dw 16..19 / 20..23   bit planes of c1 (bit 0, bit 1);  dw 24..27 / 28..31  bit planes of c2
+ * find_mems performs half the dependent line fetches.  96 symbols per 128-byte block, 4 n / 3 bytes in all:
+ *   dw 4 y + x   (y, x in A C G T = 0..3) number of positions q < 96 b with c1(q) = y, c2(q) = x
+ *   dw 16        bit 31: the block holds a SPECIAL position (c1 or c2 is \n or N); bits 0..30: special runs (maximal runs of
+ *                consecutive special positions) that start before the block;  dw 17..19 unused
+ *   dw 20..22 / 23..25   bit planes of c1 (bit 0, bit 1);  dw 26..28 / 29..31  bit planes of c2
  *   ptab[8 r ..]  for the r special runs a block has behind it: {special positions, positions with c2 special and c1 = A, C, G, T}
- *                (what the header counts do not see; 3 unused dwords)
- * A kernel uses a block only when it is not flagged, and two blocks together only when they have the same run count (nothing
- * special lies between them): every count that involves \n or N then cancels out of the differences it needs.  Anything else
- * goes to the DENSE2 image (pgx_find_mems_pairs_kernel hands such reads on). */
-#define PGX_PAIRS_SYMS 128u
+ *                (what the pair counts do not see; 3 unused dwords)
+ * A kernel probe reads the row of its first symbol (16 bytes), dw 16 and the planes (48 bytes).  A kernel uses a block only when it
+ * is not flagged, and two blocks together only when they are neighbours with the same run count (nothing special in either):
+ * every count that involves \n or N then cancels out of the differences it needs.  Anything else goes to the DENSE2 image
+ * (pgx_find_mems_pairs_kernel hands such reads on). */
+#define PGX_PAIRS_SYMS 96u
 #define PGX_PAIRS_BLOCK_BYTES 128u
 #define PGX_PAIRS_MAX_RUNS 1023u /* ptab lives in LDS (32 bytes per run) */
 

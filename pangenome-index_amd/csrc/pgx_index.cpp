@@ -528,10 +528,15 @@ static bool build_pairs_image(const RiFile &ri, HostImage &img) {
         if (PGX_EXT_KILL(en)) continue;
         const uint32_t cv = PGX_EXT_CV(en);
         if (cv > 5) return false;
-        if (two_bit[cv] >= 0 && c.C[PGX_EXT_V(en)] != trueC[cv]) return false;
+        if (two_bit[cv] < 0) continue;
+        if (c.C[PGX_EXT_V(en)] != trueC[cv]) return false;
+        // the other coordinate moves by the occurrences of the regular symbols that sort after this one (weight 1 each): the kernel counts
+        // "first symbol > a" in one popcount chain instead of weighting four counts
+        for (int y = 0; y < 4; y++)
+            if (((PGX_EXT_M(en) >> (3 * code_of_two[y])) & 7u) != (y > two_bit[cv] ? 1u : 0u)) return false;
     }
     // chunks of whole blocks; per chunk the counts of the six codes (for LF), later of the sixteen pairs
-    const uint64_t nb = (n >> 7) + 1;
+    const uint64_t nb = n / PGX_PAIRS_SYMS + 1;
     struct Special { uint64_t start, len; uint64_t cnt[5]; }; // cnt: {positions, c2 special with c1 = A, C, G, T}
     std::vector<std::vector<Special>> spec_of;
     std::vector<std::array<uint64_t, 6>> code_cnt;
@@ -550,7 +555,7 @@ static bool build_pairs_image(const RiFile &ri, HostImage &img) {
         std::mutex mu;
         for (size_t t = 0; t < nt; t++)
             th.emplace_back([&, t]() {
-                try { fn(t, std::min<uint64_t>(range_of[t].first << 7, n), std::min<uint64_t>(range_of[t].second << 7, n)); }
+                try { fn(t, std::min<uint64_t>(range_of[t].first * PGX_PAIRS_SYMS, n), std::min<uint64_t>(range_of[t].second * PGX_PAIRS_SYMS, n)); }
                 catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
             });
         for (auto &x : th) x.join();
@@ -605,22 +610,22 @@ static bool build_pairs_image(const RiFile &ri, HostImage &img) {
         std::array<uint64_t, 16> pc{};
         for (size_t u = 0; u < t; u++) for (int i = 0; i < 16; i++) pc[i] += pair_cnt[u][i];
         const uint64_t b0 = range_of[t].first, b1 = range_of[t].second;
-        size_t r = std::lower_bound(runs.begin(), runs.end(), b0 << 7, [](const Special &a, uint64_t v) { return a.start < v; }) - runs.begin(); // runs starting before the block
+        size_t r = std::lower_bound(runs.begin(), runs.end(), b0 * PGX_PAIRS_SYMS, [](const Special &a, uint64_t v) { return a.start < v; }) - runs.begin(); // runs starting before the block
         for (uint64_t b = b0; b < b1; b++) {
             uint32_t *h = dw + b * 32;
-            const uint64_t s0 = b << 7, s1 = std::min<uint64_t>(s0 + 128, n);
+            const uint64_t s0 = b * PGX_PAIRS_SYMS, s1 = std::min<uint64_t>(s0 + PGX_PAIRS_SYMS, n);
             while (r < runs.size() && runs[r].start < s0) r++;
-            for (int i = 0; i < 15; i++) h[i] = (uint32_t)pc[i];
+            for (int i = 0; i < 16; i++) h[i] = (uint32_t)pc[i];
             bool flag = (r > 0 && runs[r - 1].start + runs[r - 1].len > s0) || (r < runs.size() && runs[r].start < s1);
-            h[15] = (uint32_t)r | (flag ? 0x80000000u : 0u);
+            h[16] = (uint32_t)r | (flag ? 0x80000000u : 0u);
             for (uint64_t p = std::min(s0, p1); p < std::min(s1, p1); p++) {
                 const uint8_t v = pr[p];
                 if (v & 0x80) continue;
                 const uint32_t i = (uint32_t)(p - s0), bit = 1u << (i & 31), w = i >> 5;
-                if (v & 4) h[16 + w] |= bit;
-                if (v & 8) h[20 + w] |= bit;
-                if (v & 1) h[24 + w] |= bit;
-                if (v & 2) h[28 + w] |= bit;
+                if (v & 4) h[20 + w] |= bit;
+                if (v & 8) h[23 + w] |= bit;
+                if (v & 1) h[26 + w] |= bit;
+                if (v & 2) h[29 + w] |= bit;
                 pc[v]++;
             }
         }
@@ -631,9 +636,9 @@ static bool build_pairs_image(const RiFile &ri, HostImage &img) {
         const uint64_t P = trueC[code_of_two[y]];
         uint64_t cnt[6] = {0, 0, 0, 0, 0, 0};
         size_t t = 0;
-        for (; t + 1 < nt && std::min<uint64_t>(range_of[t].second << 7, n) <= P; t++)
+        for (; t + 1 < nt && std::min<uint64_t>(range_of[t].second * PGX_PAIRS_SYMS, n) <= P; t++)
             for (int i = 0; i < 6; i++) cnt[i] += code_cnt[t][i];
-        for (uint64_t p = std::min<uint64_t>(range_of[t].first << 7, n); p < P; p++) cnt[bw[p]]++;
+        for (uint64_t p = std::min<uint64_t>(range_of[t].first * PGX_PAIRS_SYMS, n); p < P; p++) cnt[bw[p]]++;
         for (int i = 0; i < 6; i++) c.pair_t2[8 * y + i] = (uint32_t)cnt[i];
     }
     c.has_pairs = 1;

@@ -809,42 +809,25 @@ PGX_FM_INSTANTIATE(false, 2, true, true)
 
 // ------------------------------------------------------------------------------------------
 // find_all_mems over the PAIRS image (pgx_image.h): the loop of pgx_find_mems_kernel, but a trip reads ONE 128-byte block that
-// answers both probes of an extension (p1 within the block of p0; otherwise the second probe takes a second trip) and, where the
-// stage has two more symbols to go, performs BOTH extensions from it:
-//   first by a (code cv1):   s1 = #{c1 = a} in [p0, p1),  k1 = C[a] + #{c1 = a} before p0,  k' += sum of w1[c] #{c1 = c}
-//   then by b (code cv2):    s2 = #{c1 = a, c2 = b},      k2 = C[b] + #b before k1 + #{c1 = a, c2 = b} before p0,
-//                            k' += sum of w2[c] #{c1 = a, c2 = c}          (#b before k1 = pair_t2[a][b] + pairs (a, b) before p0)
-// The first extension's result decides as in the stepwise search: if it is "small" the stage ends there and the second is dropped;
-// otherwise the pair counts as two extensions, and the transitions below see the second one at its own j.  MEMs, restart
-// positions and n_extensions are those of pgx_find_mems_kernel.  Positions, counts and C are below 2^32 (the image exists for
-// such indexes only), so the state is 32-bit.  A stage that starts from the full interval takes its first extension from
-// img.first_ext (or the seed table): the image is never probed with the full interval.
-// A lane that meets a flagged block, or two blocks with special positions between them, gives its read up: the read id goes to
-// redo_list and pgx_find_mems_kernel (dense2 image) searches it from the start.
-__device__ __forceinline__ uint32_t pgx_window_byte(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, uint64_t a) { // byte a of the 32-byte window
-    const uint64_t wlo = (a & 8ull) ? w1 : w0, whi = (a & 8ull) ? w3 : w2;
-    return (uint32_t)(((a & 16ull) ? whi : wlo) >> (8u * (uint32_t)(a & 7ull))) & 0xFFu;
+// answers both ends of an interval (p1 within the block of p0; otherwise the interval runs on into the next block, which takes a
+// second trip) and, where the stage has two more symbols to go, performs BOTH extensions from it.  With (c1, c2) the pair at a
+// position, a the first symbol extended by and b the second:
+//   first:   s1 = #{c1 = a} in [p0, p1),          k1 = C[a] + #{c1 = a} before p0,                      k' += #{c1 > a} in [p0, p1)
+//   second:  s2 = #{c1 = a, c2 = b} in [p0, p1),  k2 = C[b] + #b before k1 + #{c1 = a, c2 = b} before p0,  k' += #{c1 = a, c2 > b} in [p0, p1)
+//            (#b before k1 = pair_t2[a][b] + pairs (a, b) before p0: LF maps the positions with c1 = a onto [k1, k1 + s1), and BWT there is c2)
+// ("> a": the regular symbols that sort after a, which is what the extension tables of such an index weight; counts that involve \n or N
+// are zero in the ranges the kernel accepts.)  The first extension's result decides as in the stepwise search: if it is "small" the
+// stage ends there and the second is dropped; otherwise the pair counts as two extensions, and the transitions below see the second
+// one at its own j.  MEMs, restart positions and n_extensions are those of pgx_find_mems_kernel.  Positions, counts and C are below
+// 2^32 (the image exists for such indexes only), so the state is 32-bit.  A stage that starts from the full interval takes its first
+// extension from img.first_ext (or the seed tables): the image is never probed with the full interval.
+// A lane that meets a flagged block, two blocks with different run counts, or an interval wider than two blocks gives its read up:
+// the read id goes to redo_list and pgx_find_mems_kernel (dense2 image) searches it from the start.
+__device__ __forceinline__ uint32_t pgx_window_byte(uint64_t w0, uint64_t w1, uint64_t a) { // byte a of the 16-byte window
+    return (uint32_t)(((a & 8ull) ? w1 : w0) >> (8u * (uint32_t)(a & 7ull))) & 0xFFu;
 }
-struct PgxPairsIn { uint32_t n1, n2, n3, q0, q1, q2, q3; };
-// in-block counts below rel: n1 / n2 / n3 = positions with bit 0 / bit 1 / both bits of the first symbol, q0 = positions whose first
-// symbol is the one extended by (inv0, inv1 turn its code into all-ones), q1 / q2 / q3 = those with bit 0 / bit 1 / both of the second
-__device__ __forceinline__ PgxPairsIn pgx_pairs_count(const uint32_t (&x)[4], const uint32_t (&y)[4], const uint32_t (&m1)[4], const uint32_t (&u)[4],
-                                                      const uint32_t (&v)[4], uint32_t rel) {
-    PgxPairsIn o;
-    uint32_t n1 = 0, n2 = 0, n3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-#pragma unroll
-    for (int h = 0; h < 4; h++) {
-        const int32_t t = (int32_t)rel - 32 * h; // bits of this dword below the position
-        const uint32_t m = t >= 32 ? 0xFFFFFFFFu : (t > 0 ? ((1u << t) - 1u) : 0u);
-        n1 += __popc(x[h] & m); n2 += __popc(y[h] & m); n3 += __popc(x[h] & y[h] & m);
-        q0 += __popc(m1[h] & m); q1 += __popc(u[h] & m); q2 += __popc(v[h] & m); q3 += __popc(u[h] & v[h] & m);
-    }
-    o.n1 = n1; o.n2 = n2; o.n3 = n3; o.q0 = q0; o.q1 = q1; o.q2 = q2; o.q3 = q3;
-    return o;
-}
-
 template <bool SEED>
-__global__ void __launch_bounds__(PGX_FM_THREADS, PGX_FM_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(PGX_FM_THREADS, PGX_FM_WAVES_PER_SIMD) // (five waves per SIMD fit -- 94 VGPRs -- and are slower: 22.4 against 21.1 ms at chr22 scale)
 pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                            uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
                            pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
@@ -874,9 +857,10 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     uint32_t k = 0, kp = 0, s = 0, Jk = 0, Js = 0;
     uint32_t nm = 0, next = 0, next0 = 0;
     int ph = 0;
-    uint64_t win = 0, win_hi = 0, win2 = 0, win3 = 0;
-    uint32_t win_at = ~0u; // the cached 32 bytes of the reads buffer: their offset / 32
-    uint32_t X0a = 0, X0b = 0, X0c = 0, X0d = 0, ri0 = 0; // first-probe sums of an extension whose second probe is pending
+    uint64_t win = 0, win_hi = 0;
+    uint32_t win_at = ~0u; // the cached 16 bytes of the reads buffer: their offset / 16 (16 rather than 32 bytes: four registers less, which is what
+                           // lets five waves share a SIMD)
+    uint32_t X0a = 0, X0b = 0, X0c = 0, X0d = 0, X0e = 0, X0f = 0, ri0 = 0; // sums over the first block of an interval that runs on into the next
     uint32_t pend = 0, fresh = 0, restart = 0;
     uint64_t rnext = 0, rend = 0;
     bool exhausted = false;
@@ -983,19 +967,18 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             // (block 0 of the image) have the sequences' last symbols before them, often N
             const bool at_end = j >= len;
             const uint64_t atw = at_end ? at - 1ull : at; // (a live read has len >= 1)
-            if ((uint32_t)(atw >> 5) != win_at) {
-                win_at = (uint32_t)(atw >> 5);
-                const ulonglong2 w2 = *reinterpret_cast<const ulonglong2 *>(reads + (atw & ~31ull));
-                const ulonglong2 w3 = *reinterpret_cast<const ulonglong2 *>(reads + (atw & ~31ull) + 16);
-                win = w2.x; win_hi = w2.y; win2 = w3.x; win3 = w3.y;
+            if ((uint32_t)(atw >> 4) != win_at) {
+                win_at = (uint32_t)(atw >> 4);
+                const ulonglong2 w2 = *reinterpret_cast<const ulonglong2 *>(reads + (atw & ~15ull));
+                win = w2.x; win_hi = w2.y;
             }
             // (a function of values: as a lambda capturing the window by reference it turned into loads through a selected address,
             //  with the window in scratch memory)
-            const uint32_t byte = at_end ? 0u : pgx_window_byte(win, win_hi, win2, win3, at);
+            const uint32_t byte = at_end ? 0u : pgx_window_byte(win, win_hi, at);
             // the symbol after this one in the direction of the stage, when the cached window holds it
             const uint64_t at2 = (fwd && !at_end) ? at + 1ull : at - 1ull;
-            const bool have2 = (uint32_t)(at2 >> 5) == win_at;
-            const uint32_t byte2 = pgx_window_byte(win, win_hi, win2, win3, at2);
+            const bool have2 = (uint32_t)(at2 >> 4) == win_at;
+            const uint32_t byte2 = pgx_window_byte(win, win_hi, at2);
             const uint32_t e1 = s_ext[(fwd ? 256u : 0u) + byte], e2 = s_ext[(fwd ? 256u : 0u) + byte2];
             const uint32_t cv1 = PGX_EXT_CV(e1), cv2 = PGX_EXT_CV(e2);
             const bool reg1 = !PGX_EXT_KILL(e1) && ((0x2Eu >> cv1) & 1u), reg2 = !PGX_EXT_KILL(e2) && ((0x2Eu >> cv2) & 1u); // A C G T
@@ -1004,63 +987,59 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             const bool two = !fr && rem2 && have2 && reg1 && reg2;
             const uint32_t kk = fwd ? kp : k, kq = fwd ? k : kp;
             const uint32_t p0 = kk, p1 = kk + s;
-            const uint32_t P = pend ? p1 : p0, bs = P & ~127u;
-            const uint4 *bp = img.pairs + (size_t)(P >> 7) * 8;
-            const uint4 h0 = bp[0], h1 = bp[1], h2 = bp[2], h3 = bp[3], a0 = bp[4], a1 = bp[5], b0 = bp[6], b1 = bp[7];
-            const bool flagged = (h3.w >> 31) != 0u;
-            const uint32_t ri = h3.w & 0x7FFFFFFFu;
-            const uint32_t relA = P - bs;
-            const bool same = !pend && (p1 - bs <= 128u);
-            const uint32_t relB = same ? p1 - bs : relA;
-            const uint32_t inv0 = (t1 & 1u) ? 0u : 0xFFFFFFFFu, inv1 = (t1 & 2u) ? 0u : 0xFFFFFFFFu;
-            // (the masked planes are formed once and both positions counted from them: with the loads inside a per-position helper the
-            //  compiler loaded the block twice)
-            const uint32_t px[4] = {a0.x, a0.y, a0.z, a0.w}, py[4] = {a1.x, a1.y, a1.z, a1.w};
-            const uint32_t pm[4] = {(a0.x ^ inv0) & (a1.x ^ inv1), (a0.y ^ inv0) & (a1.y ^ inv1), (a0.z ^ inv0) & (a1.z ^ inv1), (a0.w ^ inv0) & (a1.w ^ inv1)};
-            const uint32_t pu[4] = {pm[0] & b0.x, pm[1] & b0.y, pm[2] & b0.z, pm[3] & b0.w}, pv[4] = {pm[0] & b1.x, pm[1] & b1.y, pm[2] & b1.z, pm[3] & b1.w};
-            const PgxPairsIn iA = pgx_pairs_count(px, py, pm, pu, pv, relA), iB = pgx_pairs_count(px, py, pm, pu, pv, relB);
-            // counts before the block: rows of the header (first symbol y: second symbols A C G T), the sixteenth derived
-            const uint32_t pt0 = s_pt[8u * ri], pts = s_pt[8u * ri + 1u + t1];
-            const uint32_t rs0 = h0.x + h0.y + h0.z + h0.w, rs1 = h1.x + h1.y + h1.z + h1.w, rs2 = h2.x + h2.y + h2.z + h2.w;
-            const uint32_t r33 = bs - rs0 - rs1 - rs2 - (h3.x + h3.y + h3.z) - pt0;
-            const uint32_t rs3 = h3.x + h3.y + h3.z + r33;
-            const uint32_t m1 = PGX_EXT_M(e1), m2 = PGX_EXT_M(e2);
-            const uint32_t w1A = (m1 >> 3) & 7u, w1C = (m1 >> 6) & 7u, w1G = (m1 >> 9) & 7u, w1T = (m1 >> 15) & 7u;
-            const uint32_t w2A = (m2 >> 3) & 7u, w2C = (m2 >> 6) & 7u, w2G = (m2 >> 9) & 7u, w2T = (m2 >> 15) & 7u;
-            const uint32_t rx = t1 == 0u ? h0.x : (t1 == 1u ? h1.x : (t1 == 2u ? h2.x : h3.x)), ry = t1 == 0u ? h0.y : (t1 == 1u ? h1.y : (t1 == 2u ? h2.y : h3.y));
-            const uint32_t rz = t1 == 0u ? h0.z : (t1 == 1u ? h1.z : (t1 == 2u ? h2.z : h3.z)), rw = t1 == 0u ? h0.w : (t1 == 1u ? h1.w : (t1 == 2u ? h2.w : r33));
-            const uint32_t abs_one = (t1 == 0u ? rs0 : (t1 == 1u ? rs1 : (t1 == 2u ? rs2 : rs3))) + pts;
-            const uint32_t abs_two = t2 == 0u ? rx : (t2 == 1u ? ry : (t2 == 2u ? rz : rw));
-            const uint32_t abs_w1 = w1A * rs0 + w1C * rs1 + w1G * rs2 + w1T * rs3, abs_w2 = w2A * rx + w2C * ry + w2G * rz + w2T * rw;
-            auto sums = [&](const PgxPairsIn &i, uint32_t rel, uint32_t &one, uint32_t &twov, uint32_t &sw1, uint32_t &sw2) __attribute__((always_inline)) {
-                const uint32_t iT = i.n3, iC = i.n1 - i.n3, iG = i.n2 - i.n3, iAa = rel - i.n1 - i.n2 + i.n3;
-                const uint32_t pT = i.q3, pC = i.q1 - i.q3, pG = i.q2 - i.q3, pA = i.q0 - i.q1 - i.q2 + i.q3;
-                one = abs_one + i.q0;
-                twov = abs_two + (t2 == 0u ? pA : (t2 == 1u ? pC : (t2 == 2u ? pG : pT)));
-                sw1 = abs_w1 + w1A * iAa + w1C * iC + w1G * iG + w1T * iT;
-                sw2 = abs_w2 + w2A * pA + w2C * pC + w2G * pG + w2T * pT;
-            };
-            uint32_t XAa, XAb, XAc, XAd, XBa, XBb, XBc, XBd;
-            sums(iA, relA, XAa, XAb, XAc, XAd);
-            sums(iB, relB, XBa, XBb, XBc, XBd);
-            const bool bail = !fr && (flagged || (pend && ri != ri0));
-            const bool wait = !fr && !pend && !same && !bail; // the second probe lies in another block: next trip
+            // the block of p0 (96 positions); a second trip (pend) reads the block after it
+            const uint32_t bfirst = (uint32_t)(((uint64_t)(p0 >> 5) * 0xAAAAAAABull) >> 33); // p0 / 96
+            const uint32_t endrel = p1 - bfirst * PGX_PAIRS_SYMS;                             // p1 relative to the first block
+            const uint32_t relA = pend ? 0u : p0 - bfirst * PGX_PAIRS_SYMS;
+            const uint32_t relB = pend ? endrel - PGX_PAIRS_SYMS : (endrel < PGX_PAIRS_SYMS ? endrel : PGX_PAIRS_SYMS);
+            const uint4 *bp = img.pairs + (size_t)(bfirst + pend) * 8;
+            const uint4 row = bp[t1];                                                          // pairs (t1, A C G T) before the block
+            const uint32_t hw = reinterpret_cast<const uint32_t *>(bp)[16];
+            const uint4 d0 = bp[5], d1 = bp[6], d2 = bp[7];                                    // planes: c1 bit 0, c1 bit 1, c2 bit 0, c2 bit 1, three dwords each
+            const bool flagged = (hw >> 31) != 0u;
+            const uint32_t ri = hw & 0x7FFFFFFFu;
+            const uint32_t pts = s_pt[8u * ri + 1u + t1];
+            // masks that turn "code == t" / "code > t" into plane expressions: (x ^ i0) & (y ^ i1) and (y & ua) | (x & (y | va) & wa)
+            const uint32_t i0 = (t1 & 1u) ? 0u : 0xFFFFFFFFu, i1 = (t1 & 2u) ? 0u : 0xFFFFFFFFu, j0 = (t2 & 1u) ? 0u : 0xFFFFFFFFu, j1 = (t2 & 2u) ? 0u : 0xFFFFFFFFu;
+            const uint32_t ua = t1 < 2u ? 0xFFFFFFFFu : 0u, va = t1 == 0u ? 0xFFFFFFFFu : 0u, wa = (t1 & 1u) ? 0u : 0xFFFFFFFFu;
+            const uint32_t ub = t2 < 2u ? 0xFFFFFFFFu : 0u, vb = t2 == 0u ? 0xFFFFFFFFu : 0u, wb = (t2 & 1u) ? 0u : 0xFFFFFFFFu;
+            const uint32_t PX[3] = {d0.x, d0.y, d0.z}, PY[3] = {d0.w, d1.x, d1.y}, PU[3] = {d1.z, d1.w, d2.x}, PV[3] = {d2.y, d2.z, d2.w};
+            // counts below relA (absolute ranks need them) and in [relA, relB) (sizes and the other coordinate are differences)
+            uint32_t e1p = 0, e2p = 0, e1r = 0, g1r = 0, e2r = 0, g2r = 0;
+#pragma unroll
+            for (int h = 0; h < 3; h++) {
+                const int32_t ta = (int32_t)relA - 32 * h, tb = (int32_t)relB - 32 * h;
+                const uint32_t mP = ta >= 32 ? 0xFFFFFFFFu : (ta > 0 ? ((1u << ta) - 1u) : 0u);
+                const uint32_t mR = (tb >= 32 ? 0xFFFFFFFFu : (tb > 0 ? ((1u << tb) - 1u) : 0u)) & ~mP;
+                const uint32_t x = PX[h], y = PY[h], u = PU[h], v = PV[h];
+                const uint32_t m1 = (x ^ i0) & (y ^ i1);             // first symbol == the one extended by
+                const uint32_t g1 = (y & ua) | (x & (y | va) & wa);   // first symbol sorts after it
+                const uint32_t q2 = m1 & (u ^ j0) & (v ^ j1);         // ... and second symbol == the second one extended by
+                const uint32_t g2 = m1 & ((v & ub) | (u & (v | vb) & wb)); // ... and second symbol sorts after it
+                e1p += __popc(m1 & mP); e2p += __popc(q2 & mP);
+                e1r += __popc(m1 & mR); g1r += __popc(g1 & mR); e2r += __popc(q2 & mR); g2r += __popc(g2 & mR);
+            }
+            const uint32_t a01 = row.x + row.y + row.z + row.w + pts + e1p;                       // rank of the first symbol at p0
+            const uint32_t a02 = (t2 == 0u ? row.x : (t2 == 1u ? row.y : (t2 == 2u ? row.z : row.w))) + e2p; // rank of the pair at p0
+            const bool straddle = endrel > PGX_PAIRS_SYMS, far = endrel > 2u * PGX_PAIRS_SYMS;
+            const bool bail = !fr && (flagged || far || (pend && ri != ri0));
+            const bool wait = !fr && !pend && straddle && !bail; // the interval runs on into the next block: next trip
 #ifdef PGX_FM_STATS
             st_wait += wait ? 1ull : 0ull;
 #endif
-            if (bail) { // special positions in the way: the dense2 kernel searches this read
+            if (bail) { // special positions in the way (or an interval wider than two blocks): the dense2 kernel searches this read
                 redo_list[atomicAdd(redo_count, 1ull)] = rid;
                 ph = 0; next = next0; pend = 0u;
             } else if (wait) {
-                X0a = XAa; X0b = XAb; X0c = XAc; X0d = XAd; ri0 = ri;
+                X0a = e1r; X0b = g1r; X0c = e2r; X0d = g2r; X0e = a01; X0f = a02; ri0 = ri;
                 pend = 1u;
             } else {
-                const uint32_t Q0a = pend ? X0a : XAa, Q0b = pend ? X0b : XAb, Q0c = pend ? X0c : XAc, Q0d = pend ? X0d : XAd;
-                const uint32_t Q1a = pend ? XAa : XBa, Q1b = pend ? XAb : XBb, Q1c = pend ? XAc : XBc, Q1d = pend ? XAd : XBd;
+                const uint32_t c1 = pend ? X0a + e1r : e1r, w1 = pend ? X0b + g1r : g1r, c2 = pend ? X0c + e2r : e2r, w2 = pend ? X0d + g2r : g2r;
+                const uint32_t r1 = pend ? X0e : a01, r2 = pend ? X0f : a02;
                 pend = 0u;
                 // first extension (src/r-index.cpp:713-764); a symbol that is not A C G T has no occurrence in a range free of special positions
-                uint32_t s1 = reg1 ? Q1a - Q0a : 0u;
-                uint32_t k1 = Q0a + s_C[PGX_EXT_V(e1)], q1v = kq + (Q1c - Q0c);
+                uint32_t s1 = reg1 ? c1 : 0u;
+                uint32_t k1 = r1 + s_C[PGX_EXT_V(e1)], q1v = kq + w1;
                 if (fr) { const uint4 f = s_fe[byte]; k1 = f.x; q1v = f.y; s1 = f.z; }
                 const bool small1 = s1 == 0u || s1 < mo || mo_huge;
                 // a usable seed entry stands for the first extension and the ones after it
@@ -1068,7 +1047,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 const bool seed_alive = SEED && seed_lane && se.z != 0u && se.z >= mo && !mo_huge;
                 const bool seed_dead = SEED && seed_lane && se.z == 0u && sdepth != PGX_SEED_UNUSABLE && min_occ <= 1;
                 const bool do2 = (fr ? (at_end && rem2 && have2 && !seed_alive && !seed_dead) : two) && !small1;
-                uint32_t s2 = Q1b - Q0b, k2 = Q0b + s_C[PGX_EXT_V(e2)] + s_t2[8u * t1 + cv2], q2v = q1v + (Q1d - Q0d);
+                uint32_t s2 = c2, k2 = r2 + s_C[PGX_EXT_V(e2)] + s_t2[8u * t1 + cv2], q2v = q1v + w2;
                 if (fr) { const uint4 f = s_fe[256u + byte2]; k2 = f.x; q2v = f.y; s2 = f.z; }
                 uint32_t ns = do2 ? s2 : s1, nk = do2 ? k2 : k1, nq = do2 ? q2v : q1v;
                 if (ns == 0u) { nk = 0u; nq = 0u; }

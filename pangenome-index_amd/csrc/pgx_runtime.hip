@@ -1044,7 +1044,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         // above then serves the reads the pairs kernel hands on
         const char *pv = std::getenv("PGX_FM_PAIRS");
         // (only behind the seed table: the wide intervals at the start of an unseeded stage always have special positions between their ends)
-        if (img.pairs && seeded && !(n >> 32) && b->read_bytes < (1ull << 36) && !(pv && pv[0] == '0')) kfn_pairs = (const void *)pgx_find_mems_pairs_kernel<true>;
+        if (img.pairs && seeded && !(n >> 32) && b->read_bytes < (1ull << 35) && !(pv && pv[0] == '0')) kfn_pairs = (const void *)pgx_find_mems_pairs_kernel<true>;
         pairs_lds = ((size_t)img.pair_runs + 1) * 32;
         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn_pairs ? kfn_pairs : kfn, PGX_FM_THREADS, kfn_pairs ? pairs_lds : b->dimg->lds_bytes));
         HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));

@@ -20,13 +20,13 @@ r, t = O.RIndex(ri), O.Tags(tags, O.TAGS_COMPACT)
 t0 = time.time()
 ref = O.find_mems_batch(r, t, cat, offs, 20, 1, threads=O.lib().orc_max_threads())
 print("oracle: %.1f s, %d MEMs, %d positions, %d extensions" % (time.time() - t0, len(ref["mems"]), len(ref["positions"]), ref["n_extensions"]), flush=True)
-for name, force in (("automatic", 0), ("dense2", P.MODE_IMAGE_DENSE2), ("dense", P.MODE_IMAGE_DENSE), ("run-length", P.MODE_IMAGE_RL)):
+for name, force in (("automatic", 0), ("dense2 + pairs", P.MODE_IMAGE_PAIRS), ("dense2", P.MODE_IMAGE_DENSE2), ("dense", P.MODE_IMAGE_DENSE), ("run-length", P.MODE_IMAGE_RL)):
     idx = P.Index(ri, tags, mode=P.MODE_COMPAT | force)
     res = idx.find_mems(cat, offs, 20, 1, tags=True)
     ok = (np.array_equal(res["mem_offsets"], ref["mem_offsets"]) and res["mems"].tobytes() == ref["mems"].tobytes()
           and res["n_extensions"] == ref["n_extensions"] and np.array_equal(res["tag_run_counts"], ref["tag_run_counts"])
           and np.array_equal(res["pos_offsets"], ref["pos_offsets"]) and np.array_equal(res["positions"], ref["positions"])
           and res["n_tag_overflow"] == ref["n_tag_overflow"])
-    print("%s image (kind %d): %s (n = %d, %d reads)" % (name, idx.info().image_kind, "bit-identical to the oracle" if ok else "MISMATCH", idx.info().bwt_size, n_reads), flush=True)
+    print("%s image (kind %d, pairs %d): %s (n = %d, %d reads)" % (name, idx.info().image_kind, idx.info().image_pairs, "bit-identical to the oracle" if ok else "MISMATCH", idx.info().bwt_size, n_reads), flush=True)
     assert ok
     idx.close()

@@ -25,7 +25,10 @@ for wl in wls:
             for r in csv.DictReader(open(f)):
                 agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
         out[C] = {k: sum(v) / len(v) for k, v in agg.items() if k.startswith("pgx_")}
-    fm = [k for k in out["FETCH_SIZE"] if "find_mems_kernel" in k][0]
+    fms = [k for k in out["FETCH_SIZE"] if "find_mems_kernel" in k or "find_mems_pairs_kernel" in k]  # the pairs kernel and the kernel that serves what it hands on
+    fm = " + ".join(sorted(fms))
+    for C in ("FETCH_SIZE", "WRITE_SIZE"):
+        out[C][fm] = sum(out[C].get(k, 0.0) for k in fms)
     bench = json.load(open("%s/%s_FETCH_SIZE.json" % (R, wl)))
     cfg = bench["config"]
     # FETCH_SIZE / WRITE_SIZE are in units of 1024 B (rocprofv3).  FETCH_SIZE = TCC_EA0_RDREQ x 64 B, but every read request of
@@ -33,7 +36,7 @@ for wl in wls:
     # for THIS access pattern by profiles/r01_ubench_random_gather.txt: random 64-B and 128-B records are served at the same
     # record rate), so the read side is doubled.  WRITE_SIZE is exact.
     rec = {"workload": wl, "kernel": fm, "bwt_size": cfg["bwt_size"], "reads": cfg["reads_per_gpu"], "min_len": cfg["min_len"], "tags": cfg["tags"],
-           "image_kind": cfg["image_kind"],
+           "image_kind": cfg["image_kind"], "image_pairs": cfg.get("image_pairs", 0),
            "rank_image": cfg["rank_image"],
            "FETCH_SIZE_KB_per_launch": out["FETCH_SIZE"][fm], "WRITE_SIZE_KB_per_launch": out["WRITE_SIZE"].get(fm, 0.0),
            "find_mems_hbm_bytes_per_launch": (2.0 * out["FETCH_SIZE"][fm] + out["WRITE_SIZE"].get(fm, 0.0)) * 1024.0,

@@ -37,7 +37,7 @@ def _check(idx, bw):
     pair = np.where(special, -1, 4 * y + x)
     blocks = idx.image_view(20).reshape(-1, 32)
     ptab = idx.image_view(21).reshape(-1, 8)
-    nb = (n >> 7) + 1
+    nb = n // 96 + 1
     assert len(blocks) == nb
     # special runs
     starts = np.flatnonzero(special & ~np.concatenate([[False], special[:-1]]))
@@ -53,24 +53,24 @@ def _check(idx, bw):
     assert np.array_equal(ptab.astype(np.int64), exp_pt)
     cum = np.zeros(16, dtype=np.int64)
     for b in range(nb):
-        s0, s1 = b << 7, min((b << 7) + 128, n)
+        s0, s1 = 96 * b, min(96 * b + 96, n)
         h = blocks[b]
-        exp15 = list(cum[:15])
-        assert [int(v) for v in h[:15]] == exp15, b
+        assert [int(v) for v in h[:16]] == list(cum), b
         r = int((starts < s0).sum())
         flag = bool(special[s0:s1].any())
-        assert int(h[15]) == (r | (0x80000000 if flag else 0)), (b, hex(int(h[15])), r, flag)
-        if not flag:  # the derived sixteenth count
-            assert s0 - sum(exp15) - int(ptab[r, 0]) == cum[15]
+        assert int(h[16]) == (r | (0x80000000 if flag else 0)), (b, hex(int(h[16])), r, flag)
+        assert [int(v) for v in h[17:20]] == [0, 0, 0]
+        if not flag:  # every position before an unflagged block is a regular pair or one of the special positions of ptab
+            assert s0 - int(cum.sum()) == int(ptab[r, 0])
         for i in range(s1 - s0):
             pv = int(pair[s0 + i])
-            bits = [(int(h[16 + 4 * pl + (i >> 5)]) >> (i & 31)) & 1 for pl in range(4)]
+            bits = [(int(h[20 + 3 * pl + (i >> 5)]) >> (i & 31)) & 1 for pl in range(4)]
             if pv >= 0:
                 assert bits == [(pv >> 2) & 1, (pv >> 3) & 1, pv & 1, (pv >> 1) & 1], (b, i)
             else:
                 assert bits == [0, 0, 0, 0]
-        for i in range(s1 - s0, 128):
-            assert all(((int(h[16 + 4 * pl + (i >> 5)]) >> (i & 31)) & 1) == 0 for pl in range(4))
+        for i in range(s1 - s0, 96):
+            assert all(((int(h[20 + 3 * pl + (i >> 5)]) >> (i & 31)) & 1) == 0 for pl in range(4))
         cum += np.bincount(pair[s0:s1][pair[s0:s1] >= 0], minlength=16)
     for yy, code in enumerate((1, 2, 3, 5)):
         exp = np.bincount(bw[:trueC[code]], minlength=6)
