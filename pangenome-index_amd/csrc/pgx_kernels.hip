@@ -497,12 +497,13 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                      pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
                      unsigned long long *__restrict__ cursor, uint64_t first_read, uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap,
                      pgx_heavy_item *__restrict__ heavy_list, unsigned long long *__restrict__ heavy_count,
-                     const uint32_t *__restrict__ rid_list, const unsigned long long *__restrict__ rid_count) {
+                     const pgx_heavy_item *__restrict__ rid_list, const unsigned long long *__restrict__ rid_count) {
     __shared__ uint32_t s_ext[512];
     __shared__ uint64_t s_C[8];
     PGX_LDS_CARVE(img);
     pgx_stage_tables<LDS_IMAGE>(img, s_ext, s_C, lds_blocks, lds_dir, lds_blow);
-    // rid_list (may be NULL): the launch serves the reads listed there (handed on by pgx_find_mems_pairs_kernel), *rid_count of them
+    // rid_list (may be NULL): the launch serves the reads listed there (handed on by pgx_find_mems_pairs_kernel), *rid_count of them, each from
+    // the start position it was handed on at, keeping the MEMs written before
     if (rid_list) { first_read = 0; n_reads = *rid_count; }
 
     static_assert(!NARROW || DENSE, "the 32-bit state exists for the dense image only");
@@ -587,11 +588,12 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
             const uint64_t avail = rend - rnext;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             if (ph == 0 && (uint64_t)rank < avail) {
-                rid = rid_list ? (uint64_t)rid_list[rnext + rank] : rnext + rank;
+                x = 0; nm = 0;
+                rid = rnext + rank;
+                if (rid_list) { const pgx_heavy_item it = rid_list[rid]; rid = it.rid; x = (int32_t)it.x; nm = it.nm; }
                 base = offsets[rid];
                 len = (int32_t)(offsets[rid + 1] - base);
                 slot = slot_off[rid] - slot_base; // slots are reused per chunk of reads (pgx_batch_run)
-                x = 0; nm = 0;
                 next0 = next;
                 begin(); // may leave the lane idle again (read shorter than min_len)
                 if (ph == 0) ph = -1; // served in this round; becomes idle again below
@@ -791,7 +793,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     template __global__ void pgx_find_mems_kernel<__VA_ARGS__>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,     \
                                                                const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, \
                                                                uint64_t, uint64_t, uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *,     \
-                                                               const uint32_t *, const unsigned long long *);
+                                                               const pgx_heavy_item *, const unsigned long long *);
 PGX_FM_INSTANTIATE(false, 0, false, false)
 PGX_FM_INSTANTIATE(false, 1, false, false)
 PGX_FM_INSTANTIATE(true, 0, false, false)
@@ -822,7 +824,7 @@ PGX_FM_INSTANTIATE(false, 2, true, true)
 // 2^32 (the image exists for such indexes only), so the state is 32-bit.  A stage that starts from the full interval takes its first
 // extension from img.first_ext (or the seed tables): the image is never probed with the full interval.
 // A lane that meets a flagged block, two blocks with different run counts, or an interval wider than two blocks gives its read up:
-// the read id goes to redo_list and pgx_find_mems_kernel (dense2 image) searches it from the start.
+// the read goes to redo_list with its current start position and pgx_find_mems_kernel (dense2 image) carries on from there.
 __device__ __forceinline__ uint32_t pgx_window_byte(uint64_t w0, uint64_t w1, uint64_t a) { // byte a of the 16-byte window
     return (uint32_t)(((a & 8ull) ? w1 : w0) >> (8u * (uint32_t)(a & 7ull))) & 0xFFu;
 }
@@ -833,7 +835,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                            pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
                            unsigned long long *__restrict__ cursor, uint64_t first_read, uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap,
                            pgx_heavy_item *__restrict__ heavy_list, unsigned long long *__restrict__ heavy_count,
-                           uint32_t *__restrict__ redo_list, unsigned long long *__restrict__ redo_count) {
+                           pgx_heavy_item *__restrict__ redo_list, unsigned long long *__restrict__ redo_count) {
     __shared__ uint32_t s_ext[512];
     __shared__ uint32_t s_C[8];
     __shared__ uint32_t s_t2[32];
@@ -855,7 +857,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     uint64_t base = 0, slot = 0;
     int32_t len = 0, x = 0, j = 0;
     uint32_t k = 0, kp = 0, s = 0, Jk = 0, Js = 0;
-    uint32_t nm = 0, next = 0, next0 = 0;
+    uint32_t nm = 0, next = 0, next0 = 0, nextb = 0; // nextb: value of `next` when the current start position was begun
     int ph = 0;
     uint64_t win = 0, win_hi = 0;
     uint32_t win_at = ~0u; // the cached 16 bytes of the reads buffer: their offset / 16 (16 rather than 32 bytes: four registers less, which is what
@@ -881,6 +883,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             }
         }
         k = 0; kp = 0; s = n;
+        nextb = next;
         if (min_len == 0) { Jk = 0; Js = n; j = x; ph = 2; }
         else { j = x + (int32_t)min_len - 1; ph = 1; fresh = 1u; }
     };
@@ -1028,8 +1031,11 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             st_wait += wait ? 1ull : 0ull;
 #endif
             if (bail) { // special positions in the way (or an interval wider than two blocks): the dense2 kernel searches this read
-                redo_list[atomicAdd(redo_count, 1ull)] = rid;
-                ph = 0; next = next0; pend = 0u;
+                // from this start position on; step 3 means the MEM of this start position has been written: the other kernel writes it again
+                pgx_heavy_item it;
+                it.rid = (uint64_t)rid; it.x = (uint32_t)x; it.nm = nm - (ph == 3 ? 1u : 0u);
+                redo_list[atomicAdd(redo_count, 1ull)] = it;
+                ph = 0; next = nextb; pend = 0u;
             } else if (wait) {
                 X0a = e1r; X0b = g1r; X0c = e2r; X0d = g2r; X0e = a01; X0f = a02; ri0 = ri;
                 pend = 1u;
@@ -1104,10 +1110,10 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
 }
 template __global__ void pgx_find_mems_pairs_kernel<false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t, const uint64_t *, pgx_mem *,
                                                            uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t, uint32_t, uint32_t,
-                                                           pgx_heavy_item *, unsigned long long *, uint32_t *, unsigned long long *);
+                                                           pgx_heavy_item *, unsigned long long *, pgx_heavy_item *, unsigned long long *);
 template __global__ void pgx_find_mems_pairs_kernel<true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t, const uint64_t *, pgx_mem *,
                                                           uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t, uint32_t, uint32_t,
-                                                          pgx_heavy_item *, unsigned long long *, uint32_t *, unsigned long long *);
+                                                          pgx_heavy_item *, unsigned long long *, pgx_heavy_item *, unsigned long long *);
 
 // first extension of every backward stage: the full interval extended by each byte value
 __global__ void __launch_bounds__(256) pgx_first_ext_kernel(PgxDevImage img, uint4 *__restrict__ out) { // out[512]

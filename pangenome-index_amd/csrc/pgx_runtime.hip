@@ -1063,7 +1063,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     }
     unsigned long long *d_cursor = d_next + 5; // counters layout: see the allocation above
     unsigned long long *d_redo_count = d_next + 11, *d_redo_cursor = d_next + 12;
-    if (kfn_pairs) b->redo_list.ensure((n ? n : 1) * sizeof(uint32_t));
+    if (kfn_pairs) b->redo_list.ensure((n ? n : 1) * sizeof(pgx_heavy_item));
     const char *spec_env = std::getenv("PGX_SPEC");
     const bool spec = pass == 0 && chunks.size() == 1 && b->shape_valid && b->shape_reads == n && b->shape_min_len == min_len && b->shape_min_occ == min_occ &&
                       b->shape_tags == want_tags && (!want_tags || (b->tw.have_last && b->tw.last_largest <= PGX_SORT_WG_LDS_CAP)) &&
@@ -1099,10 +1099,10 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             uint32_t a_hext = heavy_ext, a_hcap = PGX_FM_HEAVY_CAP;
             pgx_heavy_item *a_hlist = b->heavy_list.as<pgx_heavy_item>();
             unsigned long long *a_hcount = d_heavy_count;
-            const uint32_t *a_rlist = nullptr;
+            const pgx_heavy_item *a_rlist = nullptr;
             const unsigned long long *a_rcount = nullptr;
             if (kfn_pairs) { // the pairs kernel first; what it hands on (reads that met \n or N in the BWT) goes through the kernel chosen above
-                uint32_t *a_redo = b->redo_list.as<uint32_t>();
+                pgx_heavy_item *a_redo = b->redo_list.as<pgx_heavy_item>();
                 unsigned long long *a_redo_n = d_redo_count;
                 void *pargs[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_first, &a_base,
                                  &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_redo, &a_redo_n};
