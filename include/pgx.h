@@ -42,7 +42,7 @@ typedef enum {
 #define PGX_MODE_IMAGE_RL 0x100u    /* run-length blocks + directory (any size)                     */
 #define PGX_MODE_IMAGE_DENSE 0x200u /* uncompressed bit planes, n bytes of device memory (64 symbols per 64-byte block)       */
 #define PGX_MODE_IMAGE_DENSE2 0x400u /* two bit planes + exception runs, n / 3 bytes (384 symbols per 128-byte block; n < 2^32) */
-#define PGX_MODE_IMAGE_PAIRS 0x800u  /* dense2 + the two-step PAIRS image, n bytes more (n < 2^32, textbook extension tables, few N runs);
+#define PGX_MODE_IMAGE_PAIRS 0x800u  /* dense2 + the two-step PAIRS image, 4 n / 3 bytes more (n < 2^32, textbook extension tables, few N runs);
                                       * the default from the size at which dense2 is, when the index qualifies             */
 #define PGX_MODE_MASK 0xFFu
 
@@ -127,7 +127,8 @@ pgx_status pgx_index_to_device(pgx_index *h, int device);
  * 10 rdir (u32), 11 lpos (u64, ones of `last`), 12 lnext (u64, samples[last_to_run[i] + 1]), 13 ldir (u32),
  * 14 locate constants (PgxLocConsts); 15 exception runs of the dense2 rank image (u32);
  * literal count image of an encoded index without N: 16 block starts (u64), 17 six cumulative counts per
- * block (u64), 18 runs as the reference's late scan sees them (u64: code << 56 | length), 19 first run of every block (u32). */
+ * block (u64), 18 runs as the reference's late scan sees them (u64: code << 56 | length), 19 first run of every block (u32);
+ * two-step PAIRS image (pgx_image.h; empty without one): 20 blocks (32 dwords each), 21 ptab (8 dwords per special-run count). */
 pgx_status pgx_index_image_view(const pgx_index *h, int which, const void **ptr, uint64_t *bytes);
 
 /* ---- index construction (build side; CPU, run once) --------------------------------------- */
