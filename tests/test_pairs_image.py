@@ -121,3 +121,113 @@ def test_pairs_image_refused_where_the_tables_are_not_the_textbook_ones(workdir,
     else:  # the tables happen to be the textbook ones for this index: then the image must be right
         _check(idx, _bwt_codes(os.path.join(G, "x.rl_bwt")))
     assert P.Index(ri).info().image_pairs == 0  # small index: dense image, no pairs
+
+
+class PairsEmu:
+    """one trip of pgx_find_mems_pairs_kernel in Python, from the image views: the two-step arithmetic of pgx_kernels.hip (counts below relA and
+    in [relA, relB) of the 96-position block of p0, the neighbour block when the interval runs on, the bail conditions), TEST INFRASTRUCTURE ONLY"""
+
+    def __init__(self, idx):
+        self.c = Consts(idx.image_view(6))
+        self.blocks = idx.image_view(20).reshape(-1, 32)
+        self.ptab = idx.image_view(21).reshape(-1, 8)
+
+    def _counts(self, b, rel_a, rel_b, t1, t2):
+        h = self.blocks[b]
+        pl = [[int(h[20 + 3 * p + w]) for w in range(3)] for p in range(4)]
+        bits = lambda p, i: (pl[p][i >> 5] >> (i & 31)) & 1
+        c1 = lambda i: bits(0, i) | (bits(1, i) << 1)
+        c2 = lambda i: bits(2, i) | (bits(3, i) << 1)
+        e1p = sum(1 for i in range(rel_a) if c1(i) == t1)
+        e2p = sum(1 for i in range(rel_a) if c1(i) == t1 and c2(i) == t2)
+        rng = range(rel_a, rel_b)
+        e1r = sum(1 for i in rng if c1(i) == t1)
+        g1r = sum(1 for i in rng if c1(i) > t1)
+        e2r = sum(1 for i in rng if c1(i) == t1 and c2(i) == t2)
+        g2r = sum(1 for i in rng if c1(i) == t1 and c2(i) > t2)
+        return e1p, e2p, e1r, g1r, e2r, g2r
+
+    def two_step(self, tri, b1, b2, fwd):
+        """(after the first extension, after both) or None where the kernel hands the read on"""
+        k, kp, s = tri
+        e1, e2 = self.c.ext_tab[(256 if fwd else 0) + b1], self.c.ext_tab[(256 if fwd else 0) + b2]
+        cv1, cv2 = e1 & 7, e2 & 7
+        reg = lambda e: not ((e >> 24) & 1) and (e & 7) in (1, 2, 3, 5)
+        assert reg(e1) and reg(e2)
+        t1, t2 = cv1 - 1 - (cv1 >> 2), cv2 - 1 - (cv2 >> 2)
+        kk, kq = (kp, k) if fwd else (k, kp)
+        p0, p1 = kk, kk + s
+        bf = p0 // 96
+        endrel = p1 - 96 * bf
+        if endrel > 192:
+            return None
+        h = self.blocks[bf]
+        if int(h[16]) >> 31:
+            return None
+        ri = int(h[16]) & 0x7FFFFFFF
+        e1p, e2p, e1r, g1r, e2r, g2r = self._counts(bf, p0 - 96 * bf, min(endrel, 96), t1, t2)
+        a01 = sum(int(h[4 * t1 + x]) for x in range(4)) + int(self.ptab[ri, 1 + t1]) + e1p
+        a02 = int(h[4 * t1 + t2]) + e2p
+        if endrel > 96:
+            h2 = self.blocks[bf + 1]
+            if (int(h2[16]) >> 31) or (int(h2[16]) & 0x7FFFFFFF) != ri:
+                return None
+            _, _, a, b, c, d = self._counts(bf + 1, 0, endrel - 96, t1, t2)
+            e1r, g1r, e2r, g2r = e1r + a, g1r + b, e2r + c, g2r + d
+        s1, k1, q1 = e1r, a01 + self.c.C[(e1 >> 3) & 7], kq + g1r
+        s2, k2, q2 = e2r, a02 + self.c.C[(e2 >> 3) & 7] + self.c.pair_t2[8 * t1 + cv2], q1 + g2r
+        first = (0, 0, 0) if s1 == 0 else ((q1, k1, s1) if fwd else (k1, q1, s1))
+        both = (0, 0, 0) if s2 == 0 else ((q2, k2, s2) if fwd else (k2, q2, s2))
+        return first, both
+
+
+@pytest.mark.parametrize("mode,omode", [(P.MODE_COMPAT, 0), (P.MODE_STRICT, 1)])
+def test_two_step_arithmetic_equals_two_oracle_extensions(workdir, mode, omode):
+    """walks of random reads through the oracle, every interval narrower than two blocks extended by the next two symbols through the PAIRS
+    image: the first result and the result of both equal the oracle's stepwise bi-intervals, backward and forward"""
+    import oracle_ffi as O
+    rng = np.random.default_rng(17)
+    base = "".join("ACGT"[i] for i in rng.integers(0, 4, 6000))
+    seqs = []
+    for h in range(4):
+        s = list(base)
+        for i in rng.integers(0, len(s), 40):
+            s[i] = "ACGT"[rng.integers(0, 4)]
+        if h == 1:
+            s[2000:2040] = "N" * 40
+        seqs.append("".join(s))
+    rc = lambda t: t[::-1].translate(str.maketrans("ACGTN", "TGCAN"))
+    text = os.path.join(workdir, "pairs_walk.txt")
+    with open(text, "w") as f:
+        for s in seqs:
+            f.write(s + "\n" + rc(s) + "\n")
+    ri_path = W.build_index_from_text(text, workdir, "pairs_walk", with_tags=False)[0]
+    idx, ri = P.Index(ri_path, mode=mode | P.MODE_IMAGE_PAIRS), O.RIndex(ri_path)
+    emu = PairsEmu(idx)
+    checked = handed_on = 0
+    for _ in range(300):
+        s = seqs[int(rng.integers(0, len(seqs)))]
+        a = int(rng.integers(0, len(s) - 60))
+        read = s[a:a + 60].replace("N", "A").encode()
+        for fwd in (False, True):
+            tri = ri.full()
+            order = range(len(read)) if fwd else range(len(read) - 1, -1, -1)
+            step = (lambda t, ch: ri.fwd(t, ch, omode)) if fwd else (lambda t, ch: ri.bwd(t, ch, omode))
+            order = list(order)
+            for q in range(len(order) - 1):
+                b1, b2 = read[order[q]], read[order[q + 1]]
+                if tri[2] and tri[2] <= 150:
+                    got = emu.two_step(tri, b1, b2, fwd)
+                    exp1 = step(tri, chr(b1))
+                    exp2 = step(exp1, chr(b2)) if exp1[2] else (0, 0, 0)
+                    if got is None:
+                        handed_on += 1
+                    else:
+                        assert tuple(int(v) for v in got[0]) == tuple(int(v) for v in exp1), (tri, chr(b1), fwd)
+                        if exp1[2]:
+                            assert tuple(int(v) for v in got[1]) == tuple(int(v) for v in exp2), (tri, chr(b1), chr(b2), fwd)
+                        checked += 1
+                tri = step(tri, chr(b1))
+                if tri[2] == 0:
+                    break
+    assert checked > 5000 and handed_on < checked // 5, (checked, handed_on)
