@@ -112,3 +112,37 @@ def test_pairs_kernel_on_an_index_full_of_special_runs(workdir, golden, monkeypa
         _same(res, ref)
         assert used == (1 if min_len >= 6 else 0)
     idx.close()
+
+
+def test_pairs_kernel_in_chunks_and_after_a_forced_repeat(pan, monkeypatch):
+    """batches processed in chunks of the slot budget (the per-chunk counters, cursor and hand-on list are reset per chunk) and the
+    repeat-in-64-bits path of the dense2 kernel that serves the handed-on reads"""
+    ri_path, tags_path, cat, offs = pan
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    ref = O.find_mems_batch(ri, tags, cat, offs, 20, 1, threads=O.lib().orc_max_threads())
+    for env in ({"PGX_SLOT_BUDGET_MB": "8"}, {"PGX_FM_NARROW_FORCE_REDO": "1"}, {"PGX_SLOT_BUDGET_MB": "8", "PGX_FM_NARROW_FORCE_REDO": "1", "PGX_SPEC": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | P.MODE_IMAGE_PAIRS)
+        b = idx.batch(cat, offs)
+        for _ in range(2):  # the second run of the same batch is sized speculatively (unless switched off)
+            b.run(20, 1, flags=P.RUN_TAGS | P.RUN_TIMING)
+            _same(b.result(), ref)
+            assert b.timing().pairs_reads == 1
+        if "PGX_SLOT_BUDGET_MB" in env:
+            assert b.timing().find_mems_launches > 1
+        b.free()
+        idx.close()
+        for k in env:
+            monkeypatch.delenv(k)
+
+
+def test_pairs_kernel_empty_and_tiny_batches(pan):
+    ri_path, tags_path, cat, offs = pan
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | P.MODE_IMAGE_PAIRS)
+    for n in (0, 1, 3, 65):
+        c, o = cat[:int(offs[n])], offs[:n + 1]
+        ref = O.find_mems_batch(ri, tags, c, o, 20, 1)
+        _same(idx.find_mems(c, o, 20, 1, tags=True), ref)
+    idx.close()
