@@ -78,7 +78,10 @@ __global__ void pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *reads
                                            uint64_t min_len, uint64_t min_occ, const uint64_t *slot_off, pgx_mem *slots,
                                            uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor, uint64_t first_read,
                                            uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap, pgx_heavy_item *heavy_list, unsigned long long *heavy_count,
-                                           pgx_heavy_item *redo_list, unsigned long long *redo_count);
+                                           pgx_heavy_item *redo_list, unsigned long long *redo_count, const uint8_t *skip);
+__global__ void pgx_bad_chunks_kernel(const uint8_t *reads, uint64_t n_bytes, uint64_t *chunks, unsigned long long *count, uint64_t cap);
+__global__ void pgx_classify_reads_kernel(const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads, const uint64_t *chunks, const unsigned long long *n_chunks,
+                                          uint64_t cap, uint32_t *flag_words, pgx_heavy_item *list, unsigned long long *count);
 __global__ void pgx_first_ext_kernel(PgxDevImage img, uint4 *out); // out[byte] = {k, k', s, 0} of the full interval extended backward by byte; out[256 + byte]: by 0, then by byte
 __global__ void pgx_rank_kernel(PgxDevImage img, const uint64_t *pos, uint64_t n, int true_codes, uint64_t *out);
 template <bool LDS_IMAGE>

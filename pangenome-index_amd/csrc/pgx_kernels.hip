@@ -810,6 +810,56 @@ PGX_FM_INSTANTIATE(false, 2, false, true)
 PGX_FM_INSTANTIATE(false, 2, true, true)
 
 // ------------------------------------------------------------------------------------------
+// Reads with a byte outside A C G T (upper case): no seed applies to a window that holds one, so the two-step kernel could only hand
+// them on after two trips -- and they are the long chains of the hand-on launch (a read cut from an N run has thousands of extensions).
+// Found once per upload, they go to the dense2 kernel on a second stream WHILE the two-step kernel runs, which skips them.
+// Two passes: a streaming one over the read bytes (16 per lane, coalesced) that lists the 16-byte chunks holding such a byte, and one
+// thread per listed chunk that finds the reads its bad bytes belong to (binary search in the offsets), flags them and lists each once.
+__global__ void __launch_bounds__(256)
+pgx_bad_chunks_kernel(const uint8_t *__restrict__ reads, uint64_t n_bytes, uint64_t *__restrict__ chunks, unsigned long long *__restrict__ count, uint64_t cap) {
+    const uint64_t n_chunks = (n_bytes + 15) >> 4; // (32 zero bytes follow the last read: the last chunk may be read whole)
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * blockDim.x) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(reads + (c << 4));
+        uint64_t b0, b1;
+        (void)pgx_seed_codes(v.x, b0);
+        (void)pgx_seed_codes(v.y, b1);
+        const uint64_t left = n_bytes - (c << 4); // bytes of the chunk that belong to reads
+        if (left < 8) { b0 &= (1ull << (8 * left)) - 1ull; b1 = 0; }
+        else if (left < 16) b1 &= (1ull << (8 * (left - 8))) - 1ull;
+        if (b0 | b1) {
+            const unsigned long long at = atomicAdd(count, 1ull);
+            if (at < cap) chunks[at] = c;
+        }
+    }
+}
+__global__ void __launch_bounds__(256)
+pgx_classify_reads_kernel(const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets, uint64_t n_reads, const uint64_t *__restrict__ chunks,
+                          const unsigned long long *__restrict__ n_chunks, uint64_t cap, uint32_t *__restrict__ flag_words, pgx_heavy_item *__restrict__ list,
+                          unsigned long long *__restrict__ count) {
+    const uint64_t nc = *n_chunks < cap ? *n_chunks : cap;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    const uint64_t p0 = chunks[i] << 4, total = offsets[n_reads];
+    uint64_t rid = ~0ull, rend = 0;
+    for (uint32_t k = 0; k < 16 && p0 + k < total; k++) {
+        const uint64_t p = p0 + k;
+        uint64_t bad;
+        (void)pgx_seed_codes((uint64_t)reads[p] | 0x4141414141414100ull, bad); // the other seven bytes read as 'A'
+        if (!(bad & 0xFFull)) continue;
+        if (rid == ~0ull || p >= rend) { // the read holding byte p: the last one whose offset is <= p (empty reads hold nothing)
+            uint64_t lo = 0, hi = n_reads;
+            while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (offsets[mid + 1] <= p) lo = mid + 1; else hi = mid; }
+            rid = lo; rend = offsets[rid + 1];
+        }
+        const uint32_t bit = 1u << (8u * (uint32_t)(rid & 3));
+        if (!(atomicOr(flag_words + (rid >> 2), bit) & bit)) {
+            pgx_heavy_item it;
+            it.rid = rid; it.x = 0; it.nm = 0;
+            list[atomicAdd(count, 1ull)] = it;
+        }
+    }
+}
+
 // find_all_mems over the PAIRS image (pgx_image.h): the loop of pgx_find_mems_kernel, but a trip reads ONE 128-byte block that
 // answers both ends of an interval (p1 within the block of p0; otherwise the interval runs on into the next block, which takes a
 // second trip) and, where the stage has two more symbols to go, performs BOTH extensions from it.  With (c1, c2) the pair at a
@@ -835,7 +885,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                            pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
                            unsigned long long *__restrict__ cursor, uint64_t first_read, uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap,
                            pgx_heavy_item *__restrict__ heavy_list, unsigned long long *__restrict__ heavy_count,
-                           pgx_heavy_item *__restrict__ redo_list, unsigned long long *__restrict__ redo_count) {
+                           pgx_heavy_item *__restrict__ redo_list, unsigned long long *__restrict__ redo_count, const uint8_t *__restrict__ skip) {
     __shared__ uint32_t s_ext[512];
     __shared__ uint32_t s_C[8];
     __shared__ uint32_t s_t2[32];
@@ -917,13 +967,16 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             if (ph == 0 && (uint64_t)rank < avail) {
                 rid = (uint32_t)(rnext + rank);
-                base = offsets[rid];
-                len = (int32_t)(offsets[rid + 1] - base);
-                slot = slot_off[rid] - slot_base;
-                x = 0; nm = 0;
-                next0 = next;
-                begin();
-                if (ph == 0) ph = -1;
+                if (skip && skip[rid]) ph = -1; // served by the dense2 kernel on the other stream (pgx_classify_reads_kernel)
+                else {
+                    base = offsets[rid];
+                    len = (int32_t)(offsets[rid + 1] - base);
+                    slot = slot_off[rid] - slot_base;
+                    x = 0; nm = 0;
+                    next0 = next;
+                    begin();
+                    if (ph == 0) ph = -1;
+                }
             }
             const uint32_t want = (uint32_t)__popcll(idle);
             rnext += (uint64_t)want < avail ? (uint64_t)want : avail;
@@ -1110,10 +1163,10 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
 }
 template __global__ void pgx_find_mems_pairs_kernel<false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t, const uint64_t *, pgx_mem *,
                                                            uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t, uint32_t, uint32_t,
-                                                           pgx_heavy_item *, unsigned long long *, pgx_heavy_item *, unsigned long long *);
+                                                           pgx_heavy_item *, unsigned long long *, pgx_heavy_item *, unsigned long long *, const uint8_t *);
 template __global__ void pgx_find_mems_pairs_kernel<true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t, const uint64_t *, pgx_mem *,
                                                           uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t, uint32_t, uint32_t,
-                                                          pgx_heavy_item *, unsigned long long *, pgx_heavy_item *, unsigned long long *);
+                                                          pgx_heavy_item *, unsigned long long *, pgx_heavy_item *, unsigned long long *, const uint8_t *);
 
 // first extension of every backward stage: the full interval extended by each byte value
 __global__ void __launch_bounds__(256) pgx_first_ext_kernel(PgxDevImage img, uint4 *__restrict__ out) { // out[512]

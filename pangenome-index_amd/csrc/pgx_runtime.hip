@@ -840,6 +840,10 @@ struct pgx_batch {
     pgx_device_image *dimg = nullptr;
     int device = 0;
     hipStream_t own = nullptr; // non-blocking stream of this batch: its copies, and its kernels when the caller names no stream
+    // second stream: the dense2 kernel over the reads with a byte outside A C G T, while the two-step kernel runs (pgx_classify_reads_kernel)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_side[2] = {nullptr, nullptr};
+    bool class_valid = false, class_ok = false; // read_flags / side_list / side_count describe the uploaded reads (ok: few enough such reads to list)
     uint64_t n_reads = 0, read_bytes = 0;
     std::vector<uint64_t> h_offsets; // rebased host copy (chunk planning)
     std::vector<pgx_chunk> chunks;   // plan of the last run (reused while min_len / budget are unchanged)
@@ -848,7 +852,7 @@ struct pgx_batch {
     uint64_t plan_min_len = 0, plan_budget = 0;
     DevBuf reads, offsets;
     // run state
-    DevBuf slot_off, slots, mem_count, mem_off, mems, scan_tmp, counters, heavy_list, heavy_scratch, redo_list;
+    DevBuf slot_off, slots, mem_count, mem_off, mems, scan_tmp, counters, heavy_list, heavy_scratch, redo_list, read_flags, side_list, side_count;
     TagWork tw;
     uint64_t n_mems = 0, n_positions = 0, n_ext = 0, n_tag_overflow = 0;
     bool ran = false, ran_tags = false;
@@ -869,7 +873,7 @@ static void batch_release(pgx_batch *b) {
     if (!b) return;
     if (hipSetDevice(b->device) == hipSuccess) {
         DevBuf *all[] = {&b->reads, &b->offsets, &b->slot_off, &b->slots, &b->mem_count, &b->mem_off, &b->mems, &b->scan_tmp,
-                         &b->counters, &b->heavy_list, &b->heavy_scratch, &b->redo_list};
+                         &b->counters, &b->heavy_list, &b->heavy_scratch, &b->redo_list, &b->read_flags, &b->side_list, &b->side_count};
         for (DevBuf *d : all) d->release();
         b->tw.release();
         HostBuf *hb[] = {&b->h_mem_off, &b->h_mems, &b->h_run_nums, &b->h_pos_off, &b->h_positions};
@@ -877,6 +881,9 @@ static void batch_release(pgx_batch *b) {
         for (auto &e : b->ev)
             if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (b->own) { (void)hipStreamDestroy(b->own); b->own = nullptr; }
+        if (b->side) { (void)hipStreamDestroy(b->side); b->side = nullptr; }
+        for (auto &e : b->ev_side)
+            if (e) { (void)hipEventDestroy(e); e = nullptr; }
     }
     delete b;
 }
@@ -889,6 +896,7 @@ static void batch_upload(pgx_batch *b, const uint8_t *reads, const uint64_t *off
     b->ran = b->ran_tags = false;
     b->plan_valid = false;
     b->slot_off_valid = false;
+    b->class_valid = false;
     const uint64_t lo = offsets[0], hi = offsets[n_reads];
     b->read_bytes = hi - lo;
     // device offsets are rebased to 0; 16 bytes of zero padding after the last read
@@ -1101,20 +1109,69 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             unsigned long long *a_hcount = d_heavy_count;
             const pgx_heavy_item *a_rlist = nullptr;
             const unsigned long long *a_rcount = nullptr;
+            bool side_running = false;
             if (kfn_pairs) { // the pairs kernel first; what it hands on (reads that met \n or N in the BWT) goes through the kernel chosen above
+                // reads with a byte outside A C G T cannot be seeded: they go to the dense2 kernel at once, on a second stream next to the pairs
+                // kernel, which skips them (a read cut from an N run is a chain of thousands of extensions: behind the pairs kernel it was 1.5 ms of tail)
+                const uint8_t *a_skip = nullptr;
+                if (chunks.size() == 1 && !std::getenv("PGX_FM_NO_SIDE")) {
+                    if (!b->side) {
+                        HIPCHECK(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+                        for (auto &e : b->ev_side) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    }
+                    if (!b->class_valid) { // once per upload: two small passes and one scalar read back
+                        const uint64_t cap = std::max<uint64_t>(cn, 1024); // chunks with such a byte; beyond that (lower-case reads, say) no side launch
+                        b->read_flags.ensure(((cn + 3) & ~3ull) + 4);
+                        b->side_list.ensure((cn ? cn : 1) * sizeof(pgx_heavy_item));
+                        b->side_count.ensure(16);
+                        b->scan_tmp.ensure(cap * 8);
+                        HIPCHECK(hipMemsetAsync(b->side_count.p, 0, 16, s));
+                        HIPCHECK(hipMemsetAsync(b->read_flags.p, 0, ((cn + 3) & ~3ull) + 4, s));
+                        unsigned long long *d_bad = b->side_count.as<unsigned long long>() + 1;
+                        hipLaunchKernelGGL(pgx_bad_chunks_kernel, dim3(std::min<unsigned>(grid_for((b->read_bytes + 15) / 16, 256), (unsigned)cus * 16u)), dim3(256), 0, s,
+                                           a_reads, b->read_bytes, b->scan_tmp.as<uint64_t>(), d_bad, cap);
+                        HIPCHECK(hipGetLastError());
+                        unsigned long long n_bad = 0;
+                        read_scalars(&n_bad, d_bad, sizeof n_bad, s);
+                        b->class_ok = n_bad <= cap;
+                        if (b->class_ok && n_bad) {
+                            hipLaunchKernelGGL(pgx_classify_reads_kernel, dim3(grid_for(n_bad, 256)), dim3(256), 0, s, a_reads, a_off, cn, (const uint64_t *)b->scan_tmp.as<uint64_t>(),
+                                               (const unsigned long long *)d_bad, cap, b->read_flags.as<uint32_t>(), b->side_list.as<pgx_heavy_item>(),
+                                               b->side_count.as<unsigned long long>());
+                            HIPCHECK(hipGetLastError());
+                        }
+                        b->class_valid = true;
+                    }
+                  if (b->class_ok) {
+                    a_skip = b->read_flags.as<uint8_t>();
+                    HIPCHECK(hipEventRecord(b->ev_side[0], s));
+                    HIPCHECK(hipStreamWaitEvent(b->side, b->ev_side[0], 0));
+                    const pgx_heavy_item *s_list = b->side_list.as<pgx_heavy_item>();
+                    const unsigned long long *s_count = b->side_count.as<unsigned long long>();
+                    unsigned long long *s_cur = d_next + 13;
+                    void *sargs[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &s_cur, &a_first, &a_base,
+                                     &a_hext, &a_hcap, &a_hlist, &a_hcount, &s_list, &s_count};
+                    HIPCHECK(hipLaunchKernel(kf, dim3(std::min<unsigned>(grid, (unsigned)cus)), dim3(PGX_FM_THREADS), sargs, b->dimg->lds_bytes, b->side));
+                    HIPCHECK(hipEventRecord(b->ev_side[1], b->side));
+                    side_running = true;
+                  }
+                }
                 pgx_heavy_item *a_redo = b->redo_list.as<pgx_heavy_item>();
                 unsigned long long *a_redo_n = d_redo_count;
                 void *pargs[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_first, &a_base,
-                                 &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_redo, &a_redo_n};
+                                 &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_redo, &a_redo_n, &a_skip};
                 HIPCHECK(hipLaunchKernel(kfn_pairs, dim3(grid), dim3(PGX_FM_THREADS), pargs, pairs_lds, s));
                 a_rlist = a_redo; a_rcount = d_redo_count; a_cur = d_redo_cursor;
                 // the few reads handed on have the device to themselves: the launch lasts as long as its longest read, and a read that ends a
                 // sequence (the usual reason to be here) runs until the heavy-read threshold: a quarter of it (chr22 scale: 21.2 -> 20.7 ms)
-                if (a_hext > 512u) a_hext = 512u;
+                uint32_t redo_hext = 512u;
+                if (const char *e = std::getenv("PGX_FM_REDO_HEAVY_EXT")) redo_hext = (uint32_t)std::strtoul(e, nullptr, 10);
+                if (redo_hext && a_hext > redo_hext) a_hext = redo_hext;
             }
             void *args[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_first, &a_base,
                             &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_rlist, &a_rcount};
             HIPCHECK(hipLaunchKernel(kf, dim3(grid), dim3(PGX_FM_THREADS), args, b->dimg->lds_bytes, s)); // one of the variants
+            if (side_running) HIPCHECK(hipStreamWaitEvent(s, b->ev_side[1], 0)); // the other stream's reads are done (they may have queued heavy reads)
             if (heavy_ext) { // the rest of reads that spent heavy_ext extensions (usually none: the launch then costs a few microseconds)
                 if (b->dimg->lds_bytes)
                     hipLaunchKernelGGL(pgx_find_mems_heavy_kernel<true>, dim3(PGX_FM_HEAVY_GRID), dim3(256), b->dimg->lds_bytes, s, img, a_reads, a_off,
