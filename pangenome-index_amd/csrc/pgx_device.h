@@ -20,6 +20,7 @@ struct PgxDevImage {
     const uint64_t *tstart;   // n_tag_runs
     const uint64_t *tvals;    // n_tag_items
     const uint32_t *tdir;     // tag_dir_entries
+    const ulonglong2 *tpair;  // (tstart[r], tvals[r]) side by side, max(n_tag_runs, n_tag_items) entries (NULL: not built)
     uint64_t n;
     uint64_t dir_entries;
     uint64_t n_tag_runs, n_tag_items, tag_dir_entries;
@@ -100,6 +101,7 @@ __global__ void pgx_scan_apply_kernel(int mode, const void *in, uint64_t n, uint
 __global__ void pgx_compact_mems_kernel(uint64_t first_read, uint64_t n_reads, const uint64_t *slot_off, uint64_t slot_base,
                                         const pgx_mem *slots, const uint32_t *mem_count, const uint64_t *local_off,
                                         uint64_t mem_base, pgx_mem *mems, uint64_t cap_mems, uint64_t *abort);
+__global__ void pgx_tag_pair_kernel(const uint64_t *tstart, const uint64_t *tvals, uint64_t n_runs, uint64_t n_items, ulonglong2 *out);
 #define PGX_TAG_LOCATE_THREADS 1024 // workgroup of pgx_tag_locate_kernel (one list atomic per workgroup)
 #define PGX_SORT_LDS_CAP 2048 // values per wave sorted in an LDS slice (pgx_tag_sort_unique_kernel)
 #define PGX_TAG_SMALL 16      // queries with at most this many runs take the 16-lane path

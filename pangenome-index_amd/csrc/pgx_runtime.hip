@@ -48,7 +48,7 @@ static void use_device(int device) {
 struct pgx_device_image {
     int device = -1;
     PgxDevImage img{};
-    DevBuf blocks, dir, blow, consts, tstart, tvals, tdir, seed, seed_end, exc, pairs, ptab, first_ext;
+    DevBuf blocks, dir, blow, consts, tstart, tvals, tdir, tpair, seed, seed_end, exc, pairs, ptab, first_ext;
     DevBuf rstart, rsamp, rdir, lpos, lnext, ldir; // locate image, uploaded on first use
     DevBuf lit_bstart, lit_cum, lit_runs, lit_roff, lit_tabs; // literal count image (quirk 3), uploaded on first use
     PgxLitImage lit{};
@@ -63,7 +63,7 @@ void pgx_release_device_images(pgx_index *h) {
         if (!d) continue;
         if (hipSetDevice(d->device) == hipSuccess) {
             d->blocks.release(); d->dir.release(); d->blow.release(); d->consts.release();
-            d->tstart.release(); d->tvals.release(); d->tdir.release(); d->seed.release(); d->seed_end.release(); d->exc.release(); d->pairs.release(); d->ptab.release(); d->first_ext.release();
+            d->tstart.release(); d->tvals.release(); d->tdir.release(); d->tpair.release(); d->seed.release(); d->seed_end.release(); d->exc.release(); d->pairs.release(); d->ptab.release(); d->first_ext.release();
             d->lit_bstart.release(); d->lit_cum.release(); d->lit_runs.release(); d->lit_roff.release(); d->lit_tabs.release();
             d->rstart.release(); d->rsamp.release(); d->rdir.release(); d->lpos.release(); d->lnext.release(); d->ldir.release();
         }
@@ -147,6 +147,16 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
     g.tstart = d->tstart.as<uint64_t>();
     g.tvals = d->tvals.as<uint64_t>();
     g.tdir = d->tdir.as<uint32_t>();
+    g.tpair = nullptr;
+    if (!m.tstart.empty() && !m.tvals.empty() && !std::getenv("PGX_NO_TPAIR")) { // tag runs as (start, value) pairs for the locate kernel (built on the device)
+        const uint64_t np = std::max<uint64_t>(m.tstart.size(), m.tvals.size());
+        d->tpair.ensure(np * sizeof(ulonglong2));
+        hipLaunchKernelGGL(pgx_tag_pair_kernel, dim3((unsigned)std::min<uint64_t>((np + 255) / 256, 65536)), dim3(256), 0, nullptr, d->tstart.as<uint64_t>(),
+                           d->tvals.as<uint64_t>(), (uint64_t)m.tstart.size(), (uint64_t)m.tvals.size(), d->tpair.as<ulonglong2>());
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipDeviceSynchronize());
+        g.tpair = d->tpair.as<ulonglong2>();
+    }
     g.n = m.consts.n;
     g.dir_entries = m.consts.dir_entries;
     g.n_tag_runs = m.consts.n_tag_runs;

@@ -17,6 +17,9 @@
 
 #include "pgx_device.h"
 
+// run start r: from the interleaved (start, value) array when the image has one -- the locate kernel then finds the run's value in the
+// cache line its search ended in (three random lines per MEM -> two)
+#define PGX_TSTART(img, r) ((img).tpair ? (img).tpair[(r)].x : (img).tstart[(r)])
 // rank_1(bwt_intervals, x + 1) = number of run starts <= x  (src/tag_arrays.cpp:857-858)
 __device__ __forceinline__ uint64_t pgx_tag_rank(const PgxDevImage &img, uint64_t x) {
     const uint64_t nr = img.n_tag_runs;
@@ -25,7 +28,7 @@ __device__ __forceinline__ uint64_t pgx_tag_rank(const PgxDevImage &img, uint64_
     uint64_t lo = img.tdir[di], hi = img.tdir[di + 1];
     while (lo < hi) {
         const uint64_t mid = (lo + hi) >> 1;
-        if (img.tstart[mid] <= x) lo = mid + 1; else hi = mid;
+        if (PGX_TSTART(img, mid) <= x) lo = mid + 1; else hi = mid;
     }
     return lo;
 }
@@ -65,10 +68,10 @@ pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *__restrict__ mems, const u
         if (en >= st) {
             const uint64_t nr = img.n_tag_runs;
             uint64_t step = 1, lo = f, hi = f;
-            while (hi < nr && img.tstart[hi] <= en) { lo = hi + 1; hi = (hi + step < nr) ? hi + step : nr; step <<= 1; }
+            while (hi < nr && PGX_TSTART(img, hi) <= en) { lo = hi + 1; hi = (hi + step < nr) ? hi + step : nr; step <<= 1; }
             while (lo < hi) {
                 const uint64_t mid = (lo + hi) >> 1;
-                if (img.tstart[mid] <= en) lo = mid + 1; else hi = mid;
+                if (PGX_TSTART(img, mid) <= en) lo = mid + 1; else hi = mid;
             }
             g = lo;
         } else g = pgx_tag_rank(img, en);
@@ -78,7 +81,7 @@ pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *__restrict__ mems, const u
         first_item[i] = fi;
         if (cnt == 1) { // one run = one position: the common case (a MEM inside one node); no segment, no sort
             uint64_t v = 0;
-            if (fi < img.n_tag_items) v = img.tvals[fi];
+            if (fi < img.n_tag_items) v = img.tpair ? img.tpair[fi].y : img.tvals[fi];
             else atomicAdd(n_overflow, 1ull); // the reference reads past the stored runs (UB there): value 0
             single[i] = v;
             ucount[i] = 1;
@@ -424,4 +427,16 @@ __global__ void pgx_spec_check_kernel(const uint64_t *__restrict__ v0, uint64_t 
     if (v2 && *v2 > c2) bits |= 4ull;
     if (v3 && *v3 > c3) bits |= 8ull;
     if (bits) atomicOr((unsigned long long *)abort, bits);
+}
+
+// (start, value) of every tag run side by side (see PGX_TSTART)
+__global__ void __launch_bounds__(256)
+pgx_tag_pair_kernel(const uint64_t *__restrict__ tstart, const uint64_t *__restrict__ tvals, uint64_t n_runs, uint64_t n_items, ulonglong2 *__restrict__ out) {
+    const uint64_t n = n_runs > n_items ? n_runs : n_items;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        ulonglong2 v;
+        v.x = i < n_runs ? tstart[i] : ~0ull;
+        v.y = i < n_items ? tvals[i] : 0ull;
+        out[i] = v;
+    }
 }
