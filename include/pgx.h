@@ -43,7 +43,7 @@ typedef enum {
 #define PGX_MODE_IMAGE_DENSE 0x200u /* uncompressed bit planes, n bytes of device memory (64 symbols per 64-byte block)       */
 #define PGX_MODE_IMAGE_DENSE2 0x400u /* two bit planes + exception runs, n / 3 bytes (384 symbols per 128-byte block; n < 2^32) */
 #define PGX_MODE_IMAGE_PAIRS 0x800u  /* dense2 + the two-step PAIRS image, 4 n / 3 bytes more (n < 2^32, textbook extension tables, few N runs);
-                                      * the default from the size at which dense2 is, when the index qualifies             */
+                                      * by default a PAIRS image accompanies whichever dense layout is chosen, when the index qualifies */
 #define PGX_MODE_MASK 0xFFu
 
 /* tag file formats (SURVEY section 5 "Tag formats") */
@@ -94,7 +94,7 @@ typedef struct {
     uint64_t n_samples;     /* samples.size() = runs in the reference's numbering */
     uint32_t image_kind;    /* 0 = run-length blocks + directory, 1 = dense bit planes (64 symbols per 64-byte block),
                              * 2 = dense2 (384 symbols per 128-byte block, two planes + exception runs) */
-    uint32_t image_pairs;   /* 1 = a PAIRS image (two extensions per cache line) accompanies the dense2 image */
+    uint32_t image_pairs;   /* 1 = a PAIRS image (two extensions per cache line) accompanies the dense / dense2 image */
 } pgx_index_info;
 
 const char *pgx_last_error(void);

@@ -68,7 +68,7 @@
  * exception runs of the block. */
 #define PGX_D2_SYMS 384u
 #define PGX_D2_BLOCK_BYTES 128u
-/* PAIRS image (next to a DENSE2 image; BWTs shorter than 2^32 whose extension tables are the textbook ones): a two-step FM
+/* PAIRS image (next to a DENSE or DENSE2 image; BWTs shorter than 2^32 whose extension tables are the textbook ones): a two-step FM
  * index.  Position p carries the PAIR (c1, c2) = (BWT[p], BWT[LF(p)]) = the two text symbols before suffix p, so the ranks of
  * pairs at the two ends of an interval give the interval after TWO extensions -- the positions with c1 = a are mapped by LF,
  * in order, onto the interval after the first extension, and BWT there is c2 -- from the same cache line that answers one:
@@ -81,7 +81,7 @@
  *                (what the pair counts do not see; 3 unused dwords)
  * A kernel probe reads the row of its first symbol (16 bytes), dw 16 and the planes (48 bytes).  A kernel uses a block only when it
  * is not flagged, and two blocks together only when they are neighbours with the same run count (nothing special in either):
- * every count that involves \n or N then cancels out of the differences it needs.  Anything else goes to the DENSE2 image
+ * every count that involves \n or N then cancels out of the differences it needs.  Anything else goes to the image it accompanies
  * (pgx_find_mems_pairs_kernel hands such reads on). */
 #define PGX_PAIRS_SYMS 96u
 #define PGX_PAIRS_BLOCK_BYTES 128u
@@ -116,7 +116,7 @@ typedef struct {
      * ranked (bits 0..2), the C slot (bits 3..5) and a "no match" flag (bit 24) */
     uint32_t cnt_tab[256];
     uint32_t image_kind;  /* PGX_IMAGE_RL / PGX_IMAGE_DENSE / PGX_IMAGE_DENSE2 */
-    uint32_t has_pairs;   /* a PAIRS image accompanies the DENSE2 image */
+    uint32_t has_pairs;   /* a PAIRS image accompanies the DENSE / DENSE2 image */
     uint32_t pair_t2[32]; /* [8 y + c], y = 2-bit code of a regular symbol, c = nuc code: number of c in BWT[0, first suffix starting with y) */
     uint32_t pair_runs;   /* special runs (ptab has pair_runs + 1 entries) */
     uint32_t reserved1;

@@ -675,7 +675,9 @@ static uint32_t choose_image(const RiFile &ri, uint32_t mode_bits, const PgxCons
     // against 4.4 ms with dense2); beyond that dense2 up to 2^32 symbols: n / 3 bytes, cache resident up to chromosome scale
     // (n = 640 M, 10 M reads: 30 ms against 36 ms with the 64-byte layout served from HBM)
     const uint64_t dense_bytes0 = dense_blocks * PGX_BLOCK_BYTES;
-    if (dense_bytes0 <= (224ull << 20)) return PGX_IMAGE_DENSE;
+    // (with the two-step PAIRS image next to it where the index qualifies: searches behind the seed table run on that -- n = 64 M, 1 M reads:
+    //  2.66 against 3.17 ms --, everything else on the 64-byte image)
+    if (dense_bytes0 <= (224ull << 20)) { pairs = (c.n >> 32) ? 0 : 1; return PGX_IMAGE_DENSE; }
     if (!(c.n >> 32)) { pairs = 1; return PGX_IMAGE_DENSE2; } // + the two-step PAIRS image when the index qualifies
     uint64_t runs = 0;
     for (const auto &b : ri.blocks) runs += b.runs.size();
@@ -695,7 +697,11 @@ void build_rank_image(const RiFile &ri, uint32_t mode_bits, HostImage &img) {
     int pairs = 0;
     const uint32_t kind = choose_image(ri, mode_bits, c, pairs);
     img.pairs.clear(); img.ptab.clear();
-    if (kind == PGX_IMAGE_DENSE) { build_dense_image(ri, img); return; }
+    if (kind == PGX_IMAGE_DENSE) {
+        build_dense_image(ri, img);
+        if (pairs) (void)build_pairs_image(ri, img);
+        return;
+    }
     if (kind == PGX_IMAGE_DENSE2) {
         build_dense2_image(ri, img);
         if (pairs && !build_pairs_image(ri, img) && pairs == 2)

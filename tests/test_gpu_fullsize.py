@@ -25,11 +25,12 @@ def test_synth_pangenome_one_million_reads(workdir):
     assert ri.sigma == 6 and ri.n > 60_000_000
     ref = O.find_mems_batch(ri, tags, cat, offs, 20, 1, threads=O.lib().orc_max_threads())
     assert len(ref["mems"]) > 1_500_000 and len(ref["positions"]) > 10_000_000 and ref["n_extensions"] > 150_000_000
-    # the automatic layout (64-byte dense blocks + seed table), dense2 + the two-step pairs image (the automatic layout of longer BWTs), dense2, run-length blocks
-    for force in (0, P.MODE_IMAGE_PAIRS, P.MODE_IMAGE_DENSE2, P.MODE_IMAGE_RL):
+    # the automatic layout (64-byte dense blocks + the two-step pairs image + seed table), dense2 + pairs (the automatic layout of longer BWTs),
+    # the 64-byte blocks alone, dense2 alone, run-length blocks
+    for force in (0, P.MODE_IMAGE_PAIRS, P.MODE_IMAGE_DENSE, P.MODE_IMAGE_DENSE2, P.MODE_IMAGE_RL):
         idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | force)
         assert force or idx.info().image_kind == P.IMAGE_DENSE
-        assert idx.info().image_pairs == (1 if force == P.MODE_IMAGE_PAIRS else 0)
+        assert idx.info().image_pairs == (1 if force in (0, P.MODE_IMAGE_PAIRS) else 0)
         res = idx.find_mems(cat, offs, 20, 1, tags=True)
         assert np.array_equal(res["mem_offsets"], ref["mem_offsets"])
         assert res["mems"].tobytes() == ref["mems"].tobytes()
