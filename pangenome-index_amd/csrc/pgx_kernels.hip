@@ -874,7 +874,8 @@ pgx_classify_reads_kernel(const uint8_t *__restrict__ reads, const uint64_t *__r
 // 2^32 (the image exists for such indexes only), so the state is 32-bit.  A stage that starts from the full interval takes its first
 // extension from img.first_ext (or the seed tables): the image is never probed with the full interval.
 // A lane that meets a flagged block, two blocks with different run counts, or an interval wider than two blocks gives its read up:
-// the read goes to redo_list with its current start position and pgx_find_mems_kernel (dense2 image) carries on from there.
+// the read goes to redo_list with its current start position and pgx_find_mems_kernel (on the dense / dense2 image the PAIRS image accompanies)
+// carries on from there.
 __device__ __forceinline__ uint32_t pgx_window_byte(uint64_t w0, uint64_t w1, uint64_t a) { // byte a of the 16-byte window
     return (uint32_t)(((a & 8ull) ? w1 : w0) >> (8u * (uint32_t)(a & 7ull))) & 0xFFu;
 }
@@ -910,8 +911,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     uint32_t nm = 0, next = 0, next0 = 0, nextb = 0; // nextb: value of `next` when the current start position was begun
     int ph = 0;
     uint64_t win = 0, win_hi = 0;
-    uint32_t win_at = ~0u; // the cached 16 bytes of the reads buffer: their offset / 16 (16 rather than 32 bytes: four registers less, which is what
-                           // lets five waves share a SIMD)
+    uint32_t win_at = ~0u; // the cached 16 bytes of the reads buffer: their offset / 16 (16 rather than 32 bytes: four registers less, no difference in time)
     uint32_t X0a = 0, X0b = 0, X0c = 0, X0d = 0, X0e = 0, X0f = 0, ri0 = 0; // sums over the first block of an interval that runs on into the next
     uint32_t pend = 0, fresh = 0, restart = 0;
     uint64_t rnext = 0, rend = 0;
