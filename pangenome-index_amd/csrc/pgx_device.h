@@ -64,7 +64,8 @@ template <bool LDS_IMAGE>
 __global__ void pgx_find_mems_heavy_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t min_len, uint64_t min_occ,
                                            const uint64_t *slot_off, uint64_t slot_base, pgx_mem *slots, uint32_t *mem_count,
                                            unsigned long long *n_ext_total, const pgx_heavy_item *heavy_list,
-                                           const unsigned long long *heavy_count, uint32_t heavy_cap, PgxHeavyResult *scratch);
+                                           const unsigned long long *heavy_count, uint32_t heavy_cap, PgxHeavyResult *scratch, uint64_t chunk_first,
+                                           uint64_t chunk_reads);
 
 __global__ void pgx_seed_build_kernel(PgxDevImage img, const uint4 *src, uint4 *dst, uint32_t level, uint64_t n_dst, uint64_t limit, int end_table);
 template <bool LDS_IMAGE, int DENSE, bool NARROW, bool SEED> // DENSE = image kind

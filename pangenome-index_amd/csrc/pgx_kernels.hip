@@ -467,6 +467,15 @@ pgx_seed_build_kernel(PgxDevImage img, const uint4 *__restrict__ src, uint4 *__r
     dst[i] = o;
 }
 
+// MEM slots of one chunk of reads: the first PGX_FAST_SLOTS MEMs of a read live in one 128-byte line of a dense array at the start of the
+// slot buffer (read r of the chunk: entries 4 r .. 4 r + 3) -- a read has 1.9 MEMs on average, so the writes of neighbouring reads fall into
+// neighbouring lines instead of 4 KiB apart, and the compaction reads them as a stream --, further ones at the read's worst-case
+// offset (slot_off) behind that array
+#define PGX_FAST_SLOTS 4u
+__device__ __forceinline__ uint64_t pgx_slot_index(uint64_t read_in_chunk, uint64_t chunk_reads, uint64_t slot, uint32_t nm) {
+    return nm < PGX_FAST_SLOTS ? read_in_chunk * PGX_FAST_SLOTS + nm : chunk_reads * PGX_FAST_SLOTS + slot + nm;
+}
+
 // ------------------------------------------------------------------------------------------
 // find_all_mems for a batch.  State machine of find_mems_function (algorithm.hpp:653-736):
 //   phase 1  backward from j = x+min_len-1 down to x          (:666-676)
@@ -504,6 +513,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     pgx_stage_tables<LDS_IMAGE>(img, s_ext, s_C, lds_blocks, lds_dir, lds_blow);
     // rid_list (may be NULL): the launch serves the reads listed there (handed on by pgx_find_mems_pairs_kernel), *rid_count of them, each from
     // the start position it was handed on at, keeping the MEMs written before
+    const uint64_t chunk_first = first_read, chunk_reads = n_reads - first_read; // (n_reads is the END of the chunk)
     if (rid_list) { first_read = 0; n_reads = *rid_count; }
 
     static_assert(!NARROW || DENSE, "the 32-bit state exists for the dense image only");
@@ -558,7 +568,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     auto emit = [&]() __attribute__((always_inline)) {
         pgx_mem m;
         m.start = (uint64_t)x; m.end = (uint64_t)j; m.bwt_start = (uint64_t)Jk; m.size = (int64_t)(uint64_t)Js; // e == j at every emit
-        slots[slot + nm] = m;
+        slots[pgx_slot_index(rid - chunk_first, chunk_reads, slot, nm)] = m;
         nm++;
         k = 0; kp = 0; s = n;
         // (as selects: an if / else that stores 1 into one of two flags is turned into ONE store through a selected address,
@@ -940,7 +950,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     auto emit = [&]() __attribute__((always_inline)) {
         pgx_mem m;
         m.start = (uint64_t)x; m.end = (uint64_t)j; m.bwt_start = (uint64_t)Jk; m.size = (int64_t)(uint64_t)Js;
-        slots[slot + nm] = m;
+        slots[pgx_slot_index((uint64_t)rid - first_read, n_reads - first_read, slot, nm)] = m;
         nm++;
         k = 0; kp = 0; s = n;
         const bool more = j > x;
@@ -1238,7 +1248,7 @@ pgx_find_mems_heavy_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                            uint64_t min_occ, const uint64_t *__restrict__ slot_off, uint64_t slot_base, pgx_mem *__restrict__ slots,
                            uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
                            const pgx_heavy_item *__restrict__ heavy_list, const unsigned long long *__restrict__ heavy_count,
-                           uint32_t heavy_cap, PgxHeavyResult *__restrict__ scratch) {
+                           uint32_t heavy_cap, PgxHeavyResult *__restrict__ scratch, uint64_t chunk_first, uint64_t chunk_reads) {
     unsigned long long cnt = *heavy_count;
     if (cnt == 0) return; // the usual case: nothing was handed on (uniform exit before any staging)
     if (cnt > heavy_cap) cnt = heavy_cap;
@@ -1266,7 +1276,7 @@ pgx_find_mems_heavy_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             while (x < len && (uint64_t)(len - x) >= min_len) {
                 const PgxHeavyResult r = res[x - x0];
                 ne += r.n_ext;
-                if (r.has_mem) slots[slot + nm++] = r.mem;
+                if (r.has_mem) { slots[pgx_slot_index(it.rid - chunk_first, chunk_reads, slot, nm)] = r.mem; nm++; }
                 x = (int32_t)r.next_x;
             }
             mem_count[it.rid] = nm;
@@ -1277,10 +1287,10 @@ pgx_find_mems_heavy_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
 }
 template __global__ void pgx_find_mems_heavy_kernel<false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, const uint64_t *, uint64_t,
                                                            pgx_mem *, uint32_t *, unsigned long long *, const pgx_heavy_item *,
-                                                           const unsigned long long *, uint32_t, PgxHeavyResult *);
+                                                           const unsigned long long *, uint32_t, PgxHeavyResult *, uint64_t, uint64_t);
 template __global__ void pgx_find_mems_heavy_kernel<true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, const uint64_t *, uint64_t,
                                                           pgx_mem *, uint32_t *, unsigned long long *, const pgx_heavy_item *,
-                                                          const unsigned long long *, uint32_t, PgxHeavyResult *);
+                                                          const unsigned long long *, uint32_t, PgxHeavyResult *, uint64_t, uint64_t);
 
 // ------------------------------------------------------------------------------------------
 // primitives for tests (mirror rank_at_cached_encoded / backward_extend_encoded / forward_...)
@@ -1433,7 +1443,7 @@ pgx_scan_apply_kernel(int mode, const void *in, uint64_t n_cap, uint64_t min_len
 }
 
 // ------------------------------------------------------------------------------------------
-// MEM compaction: slots (worst-case capacity per read) -> dense CSR in read order
+// MEM compaction: slots (pgx_slot_index: four per read in a dense array, the rest at the read's worst-case offset) -> dense CSR in read order
 __global__ void __launch_bounds__(256)
 pgx_compact_mems_kernel(uint64_t first_read, uint64_t n_reads, const uint64_t *__restrict__ slot_off, uint64_t slot_base,
                         const pgx_mem *__restrict__ slots, const uint32_t *__restrict__ mem_count,
@@ -1448,7 +1458,7 @@ pgx_compact_mems_kernel(uint64_t first_read, uint64_t n_reads, const uint64_t *_
         if (c && abort) atomicOr((unsigned long long *)abort, 16ull);
         return;
     }
-    for (uint32_t t = 0; t < c; t++) mems[dst + t] = slots[src + t];
+    for (uint32_t u = 0; u < c; u++) mems[dst + u] = slots[pgx_slot_index(t, n_reads, src, u)];
 }
 
 

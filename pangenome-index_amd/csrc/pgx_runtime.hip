@@ -1031,7 +1031,9 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     const std::vector<pgx_chunk> &chunks = b->chunks;
     uint64_t max_slots = 1;
     for (auto &c : chunks) max_slots = std::max(max_slots, c.slots);
-    b->slots.ensure(max_slots * sizeof(pgx_mem));
+    uint64_t max_chunk_reads = 1;
+    for (auto &c : chunks) max_chunk_reads = std::max(max_chunk_reads, c.r1 - c.r0);
+    b->slots.ensure((max_slots + 4 * max_chunk_reads) * sizeof(pgx_mem)); // 4 = PGX_FAST_SLOTS (pgx_kernels.hip pgx_slot_index): dense array of the first MEMs + worst-case region
     // 2. the hot kernel, 3. CSR offsets + compaction (per chunk)
     float ms_fm = 0, ms_cp = 0;
     uint64_t mem_base = 0;
@@ -1186,11 +1188,11 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                 if (b->dimg->lds_bytes)
                     hipLaunchKernelGGL(pgx_find_mems_heavy_kernel<true>, dim3(PGX_FM_HEAVY_GRID), dim3(256), b->dimg->lds_bytes, s, img, a_reads, a_off,
                                        min_len, min_occ, a_slot_off, c.slot_base, a_slots, a_cnt, d_next, (const pgx_heavy_item *)a_hlist,
-                                       (const unsigned long long *)d_heavy_count, (uint32_t)PGX_FM_HEAVY_CAP, b->heavy_scratch.as<PgxHeavyResult>());
+                                       (const unsigned long long *)d_heavy_count, (uint32_t)PGX_FM_HEAVY_CAP, b->heavy_scratch.as<PgxHeavyResult>(), c.r0, cn);
                 else
                     hipLaunchKernelGGL(pgx_find_mems_heavy_kernel<false>, dim3(PGX_FM_HEAVY_GRID), dim3(256), 0, s, img, a_reads, a_off, min_len, min_occ,
                                        a_slot_off, c.slot_base, a_slots, a_cnt, d_next, (const pgx_heavy_item *)a_hlist,
-                                       (const unsigned long long *)d_heavy_count, (uint32_t)PGX_FM_HEAVY_CAP, b->heavy_scratch.as<PgxHeavyResult>());
+                                       (const unsigned long long *)d_heavy_count, (uint32_t)PGX_FM_HEAVY_CAP, b->heavy_scratch.as<PgxHeavyResult>(), c.r0, cn);
             }
             HIPCHECK(hipGetLastError());
             b->timing.find_mems_launches++;
