@@ -146,3 +146,22 @@ def test_pairs_kernel_empty_and_tiny_batches(pan):
         ref = O.find_mems_batch(ri, tags, c, o, 20, 1)
         _same(idx.find_mems(c, o, 20, 1, tags=True), ref)
     idx.close()
+
+
+def test_pairs_kernel_with_mostly_lower_case_reads(pan):
+    """more 16-byte chunks with a byte outside ACGT than the classification lists: no second-stream launch, the pairs kernel hands
+    such reads on itself (no seed applies to them) -- same results"""
+    ri_path, tags_path, cat, offs = pan
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    n = 3000
+    c = cat[:int(offs[n])].copy()
+    o = offs[:n + 1]
+    lower = np.arange(len(c)) % 3 != 0  # two bytes of three in lower case
+    c[lower] = np.where((c[lower] >= 65) & (c[lower] <= 90), c[lower] + 32, c[lower])
+    idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | P.MODE_IMAGE_PAIRS)
+    for min_len in (20, 12):
+        ref = O.find_mems_batch(ri, tags, c, o, min_len, 1, threads=O.lib().orc_max_threads())
+        res, (used, _) = _run(idx, c, o, min_len, 1)
+        _same(res, ref)
+        assert used == 1
+    idx.close()
