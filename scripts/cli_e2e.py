@@ -1,4 +1,5 @@
-"""End-to-end wall time of the find_mems CLI (text in, text out) on the GPU box: python3 scripts/cli_e2e.py [x|synth] [n_reads]"""
+"""End-to-end wall time of the find_mems CLI (text in, text out) on the GPU box: python3 scripts/cli_e2e.py [x|synth] [n_reads] [check]
+(check: the text written with one worker, with three workers and with two device slots is the same file, byte for byte)"""
 import os, subprocess, sys, time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,3 +39,23 @@ for extra in (["--streams", "1", "--batch", "1048576"], ["--streams", "1"], ["--
         dt = time.time() - t0
         print("%s n=%d %s -> %s: %.2f s wall (%.2f M reads/s end to end), rc=%d" % (wl, n, " ".join(extra), dest, dt, n / dt / 1e6, r.returncode))
         print("   stderr tail:", r.stderr.decode().strip().split("\n")[-2:], flush=True)
+
+if len(sys.argv) > 3 and sys.argv[3] == "check":
+    import hashlib
+    sums = []
+    for i, extra in enumerate((["--streams", "1", "--batch", "1048576"], ["--streams", "3"], ["--devices", "0,0", "--streams", "2", "--batch", "65536"])):
+        dest = os.path.join(wd, "out%d.txt" % i)
+        with open(dest, "wb") as out:
+            r = subprocess.run([exe, ri, tags, path, str(min_len), "1", "--quiet"] + extra, stdout=out, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-400:]
+        h = hashlib.md5()
+        with open(dest, "rb") as f:
+            # the two "Total time" lines at the end differ from run to run
+            body = f.read()
+        cut = body.rfind(b"Total time")
+        cut = body.rfind(b"Total time", 0, cut)
+        h.update(body[:cut])
+        sums.append((h.hexdigest(), len(body)))
+        print("%s %s: %d bytes, md5 of the body %s" % (wl, " ".join(extra), len(body), sums[-1][0]), flush=True)
+    assert len({s for s, _ in sums}) == 1, sums
+    print("check: identical output under every pipeline shape")
