@@ -890,7 +890,7 @@ __device__ __forceinline__ uint32_t pgx_window_byte(uint64_t w0, uint64_t w1, ui
     return (uint32_t)(((a & 8ull) ? w1 : w0) >> (8u * (uint32_t)(a & 7ull))) & 0xFFu;
 }
 template <bool SEED>
-__global__ void __launch_bounds__(PGX_FM_THREADS, PGX_FM_WAVES_PER_SIMD) // (five waves per SIMD fit -- 94 VGPRs -- and are slower: 22.4 against 21.1 ms at chr22 scale)
+__global__ void __launch_bounds__(PGX_FM_THREADS, PGX_FM_WAVES_PER_SIMD) // (96 VGPRs: five waves per SIMD fit and are what the launch uses; four are as fast -- 20.7 against 20.6-21.0 ms at chr22 scale --, three 21.8)
 pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                            uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
                            pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
