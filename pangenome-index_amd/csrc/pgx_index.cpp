@@ -544,7 +544,8 @@ static bool build_pairs_image(const RiFile &ri, HostImage &img) {
     std::vector<std::pair<uint64_t, uint64_t>> range_of;
     {
         const unsigned hw = std::thread::hardware_concurrency();
-        const uint64_t want = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(hw ? hw : 1, 32), nb / 4096 + 1));
+        uint64_t want = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(hw ? hw : 1, 32), nb / 4096 + 1));
+        if (const char *e = std::getenv("PGX_BUILD_THREADS")) want = std::max<uint64_t>(1, std::min<uint64_t>(std::strtoull(e, nullptr, 10), std::min<uint64_t>(nb, 256)));
         for (uint64_t t = 0; t < want; t++) range_of.push_back({nb * t / want, nb * (t + 1) / want});
     }
     const size_t nt = range_of.size();

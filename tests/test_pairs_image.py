@@ -231,3 +231,32 @@ def test_two_step_arithmetic_equals_two_oracle_extensions(workdir, mode, omode):
                 if tri[2] == 0:
                     break
     assert checked > 5000 and handed_on < checked // 5, (checked, handed_on)
+
+
+def test_pairs_image_does_not_depend_on_the_builder_threads(workdir, monkeypatch):
+    """the builder splits the BWT into chunks of blocks, one thread each (LF offsets, pair counts and special runs are stitched at the
+    chunk borders): 1, 3 and 16 threads give the same bytes, and they are the brute-force image"""
+    rng = np.random.default_rng(23)
+    base = "".join("ACGT"[i] for i in rng.integers(0, 4, 40000))
+    seqs = []
+    for h in range(3):
+        s = list(base)
+        for i in rng.integers(0, len(s), 300):
+            s[i] = "ACGT"[rng.integers(0, 4)]
+        if h:
+            a = 5000 * h
+            s[a:a + 700] = "N" * 700
+        seqs.append("".join(s))
+    text = os.path.join(workdir, "pairs_thr.txt")
+    with open(text, "w") as f:
+        for s in seqs:
+            f.write(s + "\n")
+    ri = W.build_index_from_text(text, workdir, "pairs_thr", with_tags=False)[0]
+    images = []
+    for threads in ("1", "3", "16"):
+        monkeypatch.setenv("PGX_BUILD_THREADS", threads)
+        idx = P.Index(ri, mode=P.MODE_STRICT | P.MODE_IMAGE_PAIRS)
+        images.append((idx.image_view(20).tobytes(), idx.image_view(21).tobytes(), bytes(idx.image_view(6))))
+        if threads == "16":
+            _check(idx, _bwt_codes(os.path.join(workdir, "pairs_thr.rl_bwt")))
+    assert images[0] == images[1] == images[2]
