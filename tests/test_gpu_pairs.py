@@ -165,3 +165,54 @@ def test_pairs_kernel_with_mostly_lower_case_reads(pan):
         _same(res, ref)
         assert used == 1
     idx.close()
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_pairs_kernel_on_random_small_indexes(workdir, monkeypatch, seed):
+    """random texts (2-6 sequences, N runs anywhere incl. at sequence starts and ends, some in both strands): so small that a large share of
+    the blocks is flagged -- reads are handed on in the middle of a search and resumed from their current start position all the time"""
+    rng = np.random.default_rng(1000 + seed)
+    seqs = []
+    base = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(800, 6000))))
+    for h in range(int(rng.integers(2, 7))):
+        s = list(base)
+        for i in rng.integers(0, len(s), max(1, len(s) // 60)):
+            s[i] = "ACGT"[rng.integers(0, 4)]
+        for _ in range(int(rng.integers(0, 4))):
+            ln = int(rng.integers(1, 80))
+            a = int(rng.choice([0, len(s) - ln, int(rng.integers(0, len(s) - ln))]))
+            s[a:a + ln] = "N" * ln
+        s = "".join(s)
+        seqs.append(s)
+        if seed % 2:
+            seqs.append(s[::-1].translate(str.maketrans("ACGTN", "TGCAN")))
+    text = os.path.join(workdir, "pairs_rand_%d.txt" % seed)
+    with open(text, "w") as f:
+        for s in seqs:
+            f.write(s + "\n")
+    ri_path, tags_path = W.build_index_from_text(text, workdir, "pairs_rand_%d" % seed)[:2]
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    reads = []
+    for _ in range(1500):
+        s = seqs[int(rng.integers(0, len(seqs)))]
+        ln = int(rng.integers(1, 120))
+        a = int(rng.choice([0, max(0, len(s) - ln), int(rng.integers(0, max(1, len(s) - ln)))]))
+        r = bytearray(s[a:a + ln].encode())
+        for _ in range(int(rng.integers(0, 3))):
+            if r:
+                r[int(rng.integers(0, len(r)))] = int(rng.choice(np.frombuffer(b"ACGTNa", dtype=np.uint8)))
+        reads.append(bytes(r))
+    cat, offs = O.pack_reads(reads)
+    monkeypatch.setenv("PGX_SEED_K", str(int(rng.integers(3, 7))))
+    for mode, omode in ((P.MODE_COMPAT, O.MODE_COMPAT), (P.MODE_STRICT, O.MODE_STRICT)):
+        try:
+            idx = P.Index(ri_path, tags_path, mode=mode | P.MODE_IMAGE_PAIRS)
+        except P.PgxError as e:  # (a text without N in COMPAT: the quirk tables do not qualify)
+            assert e.code == P.ERR_UNSUPPORTED and mode == P.MODE_COMPAT and not ri.has_N
+            continue
+        for min_len, min_occ in [(7, 1), (8, 1), (12, 2), (20, 1)]:
+            ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, mode=omode, threads=O.lib().orc_max_threads())
+            res, (used, _) = _run(idx, cat, offs, min_len, min_occ)
+            _same(res, ref)
+            assert used == 1
+        idx.close()
