@@ -16,7 +16,7 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 wd = "/tmp/pgx_fuzz_pairs"; os.makedirs(wd, exist_ok=True)
 for seed in range(first, first + count):
-    T.test_pairs_kernel_on_random_small_indexes.__wrapped__(wd, Env(), seed) if hasattr(T.test_pairs_kernel_on_random_small_indexes, "__wrapped__") else \
-        T.test_pairs_kernel_on_random_small_indexes(wd, Env(), seed)
+    T._random_index_case(wd, Env(), seed, T.P.MODE_IMAGE_PAIRS)  # dense2 + pairs, forced, shallow seed table
+    T._random_index_case(wd, Env(), seed, 0)                     # the automatic layout (LDS + seed / end tables, or dense + pairs)
     print("seed %d ok" % seed, flush=True)
 print("all %d seeds bit-identical to the oracle" % count)

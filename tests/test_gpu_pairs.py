@@ -167,10 +167,7 @@ def test_pairs_kernel_with_mostly_lower_case_reads(pan):
     idx.close()
 
 
-@pytest.mark.parametrize("seed", list(range(10)))
-def test_pairs_kernel_on_random_small_indexes(workdir, monkeypatch, seed):
-    """random texts (2-6 sequences, N runs anywhere incl. at sequence starts and ends, some in both strands): so small that a large share of
-    the blocks is flagged -- reads are handed on in the middle of a search and resumed from their current start position all the time"""
+def _random_index_case(workdir, monkeypatch, seed, force):
     rng = np.random.default_rng(1000 + seed)
     seqs = []
     base = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(800, 6000))))
@@ -203,16 +200,34 @@ def test_pairs_kernel_on_random_small_indexes(workdir, monkeypatch, seed):
                 r[int(rng.integers(0, len(r)))] = int(rng.choice(np.frombuffer(b"ACGTNa", dtype=np.uint8)))
         reads.append(bytes(r))
     cat, offs = O.pack_reads(reads)
-    monkeypatch.setenv("PGX_SEED_K", str(int(rng.integers(3, 7))))
+    if force:
+        monkeypatch.setenv("PGX_SEED_K", str(int(rng.integers(3, 7))))
+    else:
+        monkeypatch.delenv("PGX_SEED_K", raising=False)
     for mode, omode in ((P.MODE_COMPAT, O.MODE_COMPAT), (P.MODE_STRICT, O.MODE_STRICT)):
         try:
-            idx = P.Index(ri_path, tags_path, mode=mode | P.MODE_IMAGE_PAIRS)
+            idx = P.Index(ri_path, tags_path, mode=mode | force)
         except P.PgxError as e:  # (a text without N in COMPAT: the quirk tables do not qualify)
-            assert e.code == P.ERR_UNSUPPORTED and mode == P.MODE_COMPAT and not ri.has_N
+            assert force and e.code == P.ERR_UNSUPPORTED and mode == P.MODE_COMPAT and not ri.has_N
             continue
-        for min_len, min_occ in [(7, 1), (8, 1), (12, 2), (20, 1)]:
+        for min_len, min_occ in [(7, 1), (8, 1), (12, 2), (20, 1), (10, 1)]:
             ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, mode=omode, threads=O.lib().orc_max_threads())
             res, (used, _) = _run(idx, cat, offs, min_len, min_occ)
             _same(res, ref)
-            assert used == 1
+            if force:
+                assert used == 1
         idx.close()
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_pairs_kernel_on_random_small_indexes(workdir, monkeypatch, seed):
+    """random texts (2-6 sequences, N runs anywhere incl. at sequence starts and ends, some in both strands): so small that a large share of
+    the blocks is flagged -- reads are handed on in the middle of a search and resumed from their current start position all the time"""
+    _random_index_case(workdir, monkeypatch, seed, P.MODE_IMAGE_PAIRS)
+
+
+@pytest.mark.parametrize("seed", list(range(10, 18)))
+def test_automatic_layout_on_random_small_indexes(workdir, monkeypatch, seed):
+    """the same texts under the automatic layout: the image staged in LDS with its seed table of depth 10 and the end table (the smaller
+    ones), the 64-byte image in global memory + the pairs image (the larger ones)"""
+    _random_index_case(workdir, monkeypatch, seed, 0)
