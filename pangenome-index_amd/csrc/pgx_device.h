@@ -38,6 +38,9 @@ struct PgxDevImage {
     // seed_end_k bytes before the end of the read; depths count the extension by 0
     uint32_t seed_end_k;
     const uint4 *seed_end;
+    // host side only (pgx_batch_run puts one of the two tables into seed / seed_k of the copy it launches with): the first table and a shallower one
+    uint32_t seed_k_main, seed_k_small;
+    const uint4 *seed_main, *seed_small;
     // PAIRS image (NULL without one): blocks, ptab (8 dwords per special-run count), first extensions of the full interval
     const uint4 *pairs;
     const uint32_t *ptab;
@@ -45,7 +48,8 @@ struct PgxDevImage {
     uint32_t pair_runs;
 };
 #define PGX_SEED_UNUSABLE 255u // depth value of entries the kernels must not use (a coordinate does not fit the entry)
-#define PGX_SEED_MAX_K 14
+#define PGX_SEED_MAX_K 16
+#define PGX_SEED_SMALL_K 10 // depth of the second table (searches whose min_len is below the depth of the first)
 
 // heavy reads (pgx_kernels.hip): handed from pgx_find_mems_kernel to pgx_find_mems_heavy_kernel
 struct pgx_heavy_item {

@@ -439,8 +439,7 @@ pgx_seed_build_kernel(PgxDevImage img, const uint4 *__restrict__ src, uint4 *__r
     __shared__ uint32_t s_ext[512];
     __shared__ uint64_t s_C[8];
     pgx_stage_tables<false>(img, s_ext, s_C, nullptr, nullptr, nullptr);
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_dst) return;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dst; i += (uint64_t)gridDim.x * blockDim.x) { // (a level can have 2^32 entries)
     uint64_t k = 0, kp = 0, s = img.n;
     uint32_t depth = 0;
     const uint32_t base_depth = end_table ? 1u : 0u; // the end table: level 0 is the full interval extended by 0 (pattern[len]), which counts as an extension
@@ -465,6 +464,7 @@ pgx_seed_build_kernel(PgxDevImage img, const uint4 *__restrict__ src, uint4 *__r
     o.x = (uint32_t)k; o.y = (uint32_t)kp; o.z = (uint32_t)s;
     o.w = (uint32_t)(k >> 32) | ((uint32_t)(kp >> 32) << 8) | ((uint32_t)(s >> 32) << 16) | (depth << 24);
     dst[i] = o;
+  }
 }
 
 // MEM slots of one chunk of reads: the first PGX_FAST_SLOTS MEMs of a read live in one 128-byte line of a dense array at the start of the

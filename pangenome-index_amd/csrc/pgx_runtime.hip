@@ -48,7 +48,7 @@ static void use_device(int device) {
 struct pgx_device_image {
     int device = -1;
     PgxDevImage img{};
-    DevBuf blocks, dir, blow, consts, tstart, tvals, tdir, tpair, seed, seed_end, exc, pairs, ptab, first_ext;
+    DevBuf blocks, dir, blow, consts, tstart, tvals, tdir, tpair, seed, seed_small, seed_end, exc, pairs, ptab, first_ext;
     DevBuf rstart, rsamp, rdir, lpos, lnext, ldir; // locate image, uploaded on first use
     DevBuf lit_bstart, lit_cum, lit_runs, lit_roff, lit_tabs; // literal count image (quirk 3), uploaded on first use
     PgxLitImage lit{};
@@ -63,7 +63,7 @@ void pgx_release_device_images(pgx_index *h) {
         if (!d) continue;
         if (hipSetDevice(d->device) == hipSuccess) {
             d->blocks.release(); d->dir.release(); d->blow.release(); d->consts.release();
-            d->tstart.release(); d->tvals.release(); d->tdir.release(); d->tpair.release(); d->seed.release(); d->seed_end.release(); d->exc.release(); d->pairs.release(); d->ptab.release(); d->first_ext.release();
+            d->tstart.release(); d->tvals.release(); d->tdir.release(); d->tpair.release(); d->seed.release(); d->seed_small.release(); d->seed_end.release(); d->exc.release(); d->pairs.release(); d->ptab.release(); d->first_ext.release();
             d->lit_bstart.release(); d->lit_cum.release(); d->lit_runs.release(); d->lit_roff.release(); d->lit_tabs.release();
             d->rstart.release(); d->rsamp.release(); d->rdir.release(); d->lpos.release(); d->lnext.release(); d->ldir.release();
         }
@@ -83,9 +83,15 @@ static void upload(DevBuf &b, const void *src, size_t bytes) {
 // 3.14 / 3.07 ms), PGX_SEED_K overrides (0 = no table).
 static void build_seed_table(pgx_device_image *d) {
     PgxDevImage &g = d->img;
+    // depth: one more than the first at which a random window is expected in the index less than once (4^K >= n), at most 15 (16 GiB): a seed that dies
+    // inside the table ends a stage without another trip (n = 640 M: K = 14 / 15 / 16: 20.8 / 19.4-20.5 / 20.1 ms; n = 64 M: K = 12 / 13 / 14: 2.47 / 2.43 / 2.37 ms)
     int K = 0;
-    for (uint64_t v = g.n; v >= 4; v >>= 2) K++;
-    if (K > 14) K = 14;
+    while (K < 15 && (K == 0 || (1ull << (2 * (K - 1))) < g.n)) K++;
+    {
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = mem_total = (size_t)16 << 30; }
+        while (K > 2 && (((size_t)1 << (2 * K)) * sizeof(uint4)) * 5 / 4 > std::min(mem_total / 8, mem_free / 2)) K--; // table + the level below it while building
+    }
     // an image small enough for LDS leaves the loop bound by instruction issue, and every extension a seed replaces is a gain: depth 10
     // (16 MiB of table, hot in L2) whatever n is (x index, 1 M reads, min_len 10, K = 0 / 4 / 6 / 8 / 10: 1.22 / 1.03 / 0.81 / 0.72 / 0.59 ms)
     if (d->lds_bytes) K = 10;
@@ -105,19 +111,23 @@ static void build_seed_table(pgx_device_image *d) {
             uint4 *dst = ((depth - (L + 1)) % 2 == 0) ? out.as<uint4>() : tmp.as<uint4>();
             const uint4 *src = ((depth - L) % 2 == 0) ? out.as<uint4>() : tmp.as<uint4>();
             const uint64_t n_dst = 1ull << (2 * (L + 1));
-            hipLaunchKernelGGL(pgx_seed_build_kernel, dim3((unsigned)((n_dst + 255) / 256)), dim3(256), 0, nullptr, g, src, dst, (uint32_t)L, n_dst, limit, end_table);
+            hipLaunchKernelGGL(pgx_seed_build_kernel, dim3((unsigned)std::min<uint64_t>((n_dst + 255) / 256, 1u << 22)), dim3(256), 0, nullptr, g, src, dst, (uint32_t)L, n_dst, limit, end_table);
             HIPCHECK(hipGetLastError());
         }
         HIPCHECK(hipDeviceSynchronize());
     };
+    const int Ks = K > PGX_SEED_SMALL_K ? PGX_SEED_SMALL_K : 0; // second, shallower table for searches with min_len < K
     try {
         build(d->seed, K, 0);
+        if (Ks) build(d->seed_small, Ks, 0);
         if (Ke >= 2) build(d->seed_end, Ke, 1);
-    } catch (...) { tmp.release(); d->seed.release(); d->seed_end.release(); throw; }
+    } catch (...) { tmp.release(); d->seed.release(); d->seed_small.release(); d->seed_end.release(); throw; }
     tmp.release();
     if (Ke >= 2) { g.seed_end = d->seed_end.as<uint4>(); g.seed_end_k = (uint32_t)Ke; }
     g.seed = d->seed.as<uint4>();
     g.seed_k = (uint32_t)K;
+    g.seed_main = g.seed; g.seed_k_main = g.seed_k;
+    if (Ks) { g.seed_small = d->seed_small.as<uint4>(); g.seed_k_small = (uint32_t)Ks; }
 }
 
 // one device image per (index, device), created on first use; concurrent first calls from several host threads are serialised
@@ -175,6 +185,8 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
     g.seed = nullptr;
     g.seed_end_k = 0;
     g.seed_end = nullptr;
+    g.seed_k_main = g.seed_k_small = 0;
+    g.seed_main = g.seed_small = nullptr;
     g.pairs = nullptr; g.ptab = nullptr; g.first_ext = nullptr; g.pair_runs = 0;
     if (g.dense && h->has_rank) build_seed_table(d.get());
     if (m.consts.has_pairs && !m.pairs.empty() && h->has_rank) { // the two-step image next to dense2 (pgx_image.h)
@@ -969,7 +981,9 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     if (!b) throw Error(PGX_ERR_ARG, "pgx_batch_run: null batch");
     use_device(b->device);
     hipStream_t s = stream ? (hipStream_t)stream : b->own;
-    const PgxDevImage &img = b->dimg->img;
+    PgxDevImage img = b->dimg->img; // (a copy: the seed table is chosen per run)
+    // seeds need min_len >= their depth (no stage of a shorter search has room for one): the shallower table serves searches below the depth of the first
+    if (img.seed_k_main && min_len < img.seed_k_main && img.seed_k_small && min_len >= img.seed_k_small) { img.seed = img.seed_small; img.seed_k = img.seed_k_small; }
     const uint64_t n = b->n_reads;
     const bool want_tags = (flags & PGX_RUN_TAGS) != 0;
     if (want_tags && !b->h->has_tags) throw Error(PGX_ERR_ARG, "pgx_batch_run: PGX_RUN_TAGS without a tag array");

@@ -69,7 +69,7 @@ def test_pairs_kernel_equals_the_oracle(pan, monkeypatch, seed_k):
     for mode, omode in ((P.MODE_COMPAT, O.MODE_COMPAT), (P.MODE_STRICT, O.MODE_STRICT)):
         idx = P.Index(ri_path, tags_path, mode=mode | P.MODE_IMAGE_PAIRS)
         assert idx.info().image_pairs == 1 and idx.info().image_kind == P.IMAGE_DENSE2
-        idx_seed_k = int(seed_k) if seed_k is not None else 10  # floor(log4 n), n = 1.2 M
+        idx_seed_k = int(seed_k) if seed_k is not None else 10  # automatic: depth 12 for n = 1.2 M and the second table of depth 10
         for min_len, min_occ in [(20, 1), (21, 1), (8, 1), (7, 1), (3, 1), (1, 1), (0, 1), (20, 2), (25, 9), (20, 0), (40, 1), (33, 3)]:
             ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, mode=omode, threads=O.lib().orc_max_threads())
             res, (used, redo) = _run(idx, cat, offs, min_len, min_occ)
