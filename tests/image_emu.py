@@ -234,9 +234,13 @@ class ImageEmu:
 
     def find_all_mems(self, read, min_len, min_occ):
         """state machine of pgx_find_mems_kernel, one read"""
+        return self.find_all_mems_from(read, min_len, min_occ, 0)
+
+    def find_all_mems_from(self, read, min_len, min_occ, x0):
+        """... from start position x0 on (a read the pairs kernel hands on resumes like this)"""
         b = read.encode() if isinstance(read, str) else bytes(read)
         ln, n = len(b), self.c.n
-        out, x, next_ = [], 0, 0
+        out, x, next_ = [], x0, 0
         while True:
             if x >= ln or (ln - x) < min_len:
                 break

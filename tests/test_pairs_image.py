@@ -260,3 +260,172 @@ def test_pairs_image_does_not_depend_on_the_builder_threads(workdir, monkeypatch
         if threads == "16":
             _check(idx, _bwt_codes(os.path.join(workdir, "pairs_thr.rl_bwt")))
     assert images[0] == images[1] == images[2]
+
+
+class PairsKernelEmu(PairsEmu):
+    """pgx_find_mems_pairs_kernel for one read, from the image views: the stage machine with seeds of depth K (computed here by K stepwise
+    extensions of the dense2 image, which is what the table holds), the first-extension table, two-step trips with the "first result decides"
+    rule, and the hand-on with resume at the current start position (the rest of the read then goes through ImageEmu = the stepwise kernel).
+    TEST INFRASTRUCTURE ONLY."""
+
+    def __init__(self, idx, K):
+        super().__init__(idx)
+        from image_emu import ImageEmu
+        self.base = ImageEmu(idx)
+        self.K = K
+        self.two_step_trips = self.single_trips = self.hand_ons = 0
+
+    def _reg(self, byte, fwd):
+        e = self.c.ext_tab[(256 if fwd else 0) + byte]
+        return not ((e >> 24) & 1) and (e & 7) in (1, 2, 3, 5)
+
+    def _seed(self, b, j, K):
+        """(alive tri | None, depth): the K extensions from the full interval over b[j-K+1..j], last byte first"""
+        tri = (0, 0, self.c.n)
+        for d in range(K):
+            tri = self.base.extend(tri, b[j - d], False)
+            if tri[2] == 0:
+                return None, d + 1
+        return tri, K
+
+    def find_all_mems(self, read, min_len, min_occ):
+        b = read.encode() if isinstance(read, str) else bytes(read)
+        ln, n, K = len(b), self.c.n, self.K
+        assert min_len >= K
+        out, x, next_ = [], 0, 0
+        acgt = lambda lo, hi: all(ch in b"ACGT" for ch in b[lo:hi + 1])
+
+        def stage(tri, j, x, ph, fresh):
+            """runs one stage; returns (tri, j, small, extensions) or None when the kernel hands the read on"""
+            ne = 0
+            while True:
+                fwd = ph == 2
+                if fresh:
+                    fresh = False
+                    avail = (j - x + 1) if ph == 1 else (j - x)
+                    byte = b[j] if j < ln else 0
+                    if j < ln and avail >= K and acgt(j - K + 1, j):  # seed table
+                        t, depth = self._seed(b, j, K)
+                        if t is not None and t[2] >= min_occ:
+                            tri, j, ne, small = t, j - (K - 1), ne + K, False
+                        elif t is None and min_occ <= 1:
+                            tri, j, ne, small = (0, 0, 0), j - (depth - 1), ne + depth, True
+                        else:  # the ordinary first extension stands (first_ext)
+                            tri = self.base.extend((0, 0, n), byte, False); ne += 1
+                            small = tri[2] < min_occ or tri[2] == 0
+                    else:
+                        tri = self.base.extend((0, 0, n), byte, False); ne += 1
+                        small = tri[2] < min_occ or tri[2] == 0
+                        # (the end table and first_ext[256 + byte] only replace further stepwise extensions by their results)
+                else:
+                    byte = b[j]
+                    j2 = j + 1 if fwd else j - 1
+                    rem2 = (j - 1 >= x) if ph == 1 else ((j + 1 < ln) if fwd else (j - 1 > x))
+                    if not self._reg(byte, fwd):
+                        # a symbol outside A C G T has no occurrence in a range free of special positions; the probe itself may still hand on
+                        got = self.two_step(tri, ord("A"), ord("A"), fwd)
+                        if got is None:
+                            return None
+                        tri, small = (0, 0, 0), True; ne += 1
+                    else:
+                        two = rem2 and self._reg(b[j2], fwd)
+                        got = self.two_step(tri, byte, b[j2] if two else ord("A"), fwd)
+                        if got is None:
+                            return None
+                        first, both = got
+                        small1 = first[2] < min_occ or first[2] == 0
+                        if two and not small1:
+                            self.two_step_trips += 1
+                            if fwd:
+                                self.J = first
+                            tri, j, ne = both, j2, ne + 2
+                        else:
+                            self.single_trips += 1
+                            tri, ne = first, ne + 1
+                        small = tri[2] < min_occ or tri[2] == 0
+                if small:
+                    return tri, j, True, ne
+                if ph == 1:
+                    if j == x:
+                        return tri, j, False, ne
+                    j -= 1
+                elif ph == 2:
+                    self.J = tri
+                    j += 1
+                    if j >= ln:
+                        return tri, j, False, ne
+                else:
+                    j -= 1
+                    if j <= x:
+                        return tri, j, False, ne
+
+        while True:
+            if x >= ln or (ln - x) < min_len:
+                break
+            start_next = next_
+            r = stage((0, 0, n), x + min_len - 1, x, 1, True)
+            if r is None:
+                break
+            tri, j, small, ne = r; next_ += ne
+            if small:
+                x = j + 1; continue
+            self.J = tri
+            j = x + min_len
+            if j < ln:
+                r = stage(tri, j, x, 2, False)
+                if r is None:
+                    next_ = start_next; break
+                tri, j, small, ne = r; next_ += ne
+            e = j
+            out.append((x, e, self.J[0], self.J[2]))
+            nxt = x + 1
+            if e > x:
+                r = stage((0, 0, n), e, x, 3, True)
+                if r is None:
+                    out.pop(); next_ = start_next; break
+                tri, j, small, ne = r; next_ += ne
+                if small:
+                    nxt = j + 1
+            x = nxt
+        else:
+            return out, next_
+        if x >= ln or (ln - x) < min_len:
+            return out, next_
+        # handed on: the stepwise kernel carries on from start position x
+        self.hand_ons += 1
+        rest, ne = self.base.find_all_mems_from(b, min_len, min_occ, x)
+        return out + rest, next_ + ne
+
+
+@pytest.mark.parametrize("mode,omode", [(P.MODE_COMPAT, 0), (P.MODE_STRICT, 1)])
+def test_pairs_kernel_state_machine_emulated(workdir, mode, omode):
+    """the whole two-step search of reads, emulated from the image views, against the oracle's find_all_mems: MEMs and extension counts"""
+    import oracle_ffi as O
+    rng = np.random.default_rng(29)
+    base = "".join("ACGT"[i] for i in rng.integers(0, 4, 20000))
+    seqs = []
+    for h in range(3):
+        s = list(base)
+        for i in rng.integers(0, len(s), 150):
+            s[i] = "ACGT"[rng.integers(0, 4)]
+        if h == 2:
+            s[7000:7050] = "N" * 50
+        seqs.append("".join(s))
+    text = os.path.join(workdir, "pairs_sm.txt")
+    with open(text, "w") as f:
+        for s in seqs:
+            f.write(s + "\n")
+    ri_path = W.build_index_from_text(text, workdir, "pairs_sm", with_tags=False)[0]
+    idx, ri = P.Index(ri_path, mode=mode | P.MODE_IMAGE_PAIRS), O.RIndex(ri_path)
+    emu = PairsKernelEmu(idx, K=6)
+    for i in range(120):
+        s = seqs[int(rng.integers(0, len(seqs)))]
+        ln = int(rng.integers(12, 90))
+        a = int(rng.choice([0, len(s) - ln, int(rng.integers(0, len(s) - ln))]))
+        r = bytearray(s[a:a + ln].encode())
+        for _ in range(int(rng.integers(0, 3))):
+            r[int(rng.integers(0, ln))] = int(rng.choice(np.frombuffer(b"ACGTNa", dtype=np.uint8)))
+        for min_len, min_occ in ((8, 1), (11, 2)):
+            exp = ri.find_all_mems(bytes(r), min_len, min_occ, omode, with_ext=True)
+            assert emu.find_all_mems(bytes(r), min_len, min_occ) == exp, (bytes(r), min_len, min_occ)
+    assert emu.two_step_trips > 2000 and emu.two_step_trips > emu.single_trips
