@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PGX_ABI_VERSION 1
+#define PGX_ABI_VERSION 2 /* 2: pgx_timing grew (pairs_reads, redo_reads), pgx_index_info.image_pairs, PGX_MODE_IMAGE_PAIRS */
 
 typedef enum {
     PGX_OK = 0,

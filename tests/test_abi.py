@@ -26,7 +26,7 @@ def test_header_symbols_exported(built):
     L = ctypes.CDLL(P.LIB_PATH)
     for n in names:
         assert hasattr(L, n), "missing export: " + n
-    assert L.pgx_abi_version() == 1
+    assert L.pgx_abi_version() == 2
 
 
 def test_kernels_are_gfx950_code_objects(built):
