@@ -26,7 +26,17 @@ def test_header_symbols_exported(built):
     L = ctypes.CDLL(P.LIB_PATH)
     for n in names:
         assert hasattr(L, n), "missing export: " + n
-    assert L.pgx_abi_version() == 2
+    import __graft_entry__ as G
+
+    assert L.pgx_abi_version() == G.header_abi_version()
+
+
+def test_driver_entry_build(built):
+    """__graft_entry__.build() is what the driver runs on the CPU box every round: it must
+    succeed at HEAD (a header bump once left a stale literal in it)."""
+    import __graft_entry__ as G
+
+    G.build()
 
 
 def test_kernels_are_gfx950_code_objects(built):
