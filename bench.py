@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pangenome-index_amd"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+GATHER_CEILING_LINES_PER_S = 51.7e9  # dependent random 128-byte lines from a table beyond the memory-side cache (profiles/r01_ubench_random_gather.txt)
 
 DEFAULTS = {  # workload -> (reads per GPU, min_len, base_len)
     "chr22": (10_000_000, 20, 40_000_000),
@@ -60,6 +61,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="chr22: skip the nested x (configs[1]) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target core-seconds of the CPU sample")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the measured batch (parity_sample)")
+    ap.add_argument("--parity-reads", type=int, default=100_000, help="reads of the measured batch the oracle re-computes (parity_sample)")
     ap.add_argument("--workdir", default=None)
     ap.add_argument("--pcie", action="store_true",
                     help="also time the host-buffer API (upload + run + download per call); reported separately, never as value")
@@ -157,7 +160,7 @@ def measure(P, idx, cat, offs, local, min_len, min_occ, flags, steps, warmup, st
     sync()
     barrier()
     t0 = time.perf_counter()
-    k_ms = dict(find_mems=0.0, compact=0.0, tag_locate=0.0, tag_gather=0.0, tag_sort=0.0, total=0.0)
+    k_ms = dict(find_mems=0.0, find_mems_main=0.0, compact=0.0, tag_locate=0.0, tag_gather=0.0, tag_sort=0.0, total=0.0)
     for _ in range(steps):
         batch.run(min_len, min_occ, flags, stream)
         t = batch.timing()  # HIP events recorded on the launch stream inside pgx_batch_run
@@ -170,30 +173,47 @@ def measure(P, idx, cat, offs, local, min_len, min_occ, flags, steps, warmup, st
     return batch, dt, {k: v / steps for k, v in k_ms.items()}, (n_mems, n_pos, n_ext)
 
 
-def roofline_record(info, cat_len, n_reads, counts, fm_ms, workload_key, min_len, tags):
-    """roofline of the dominant kernel (pgx_find_mems_kernel), SURVEY 8d "Algorithmic bytes": per extension 2 rank probes x
-    (B_blk + 16 B directory) in the reference's layout, per read L+1 input bytes, per MEM 32 output bytes; extensions and MEMs are
-    the kernel's own exact counters (equal to the oracle's, asserted in the parity tests)."""
+def roofline_record(info, cat_len, n_reads, counts, k_ms, timing, workload_key, min_len, tags):
+    """Roofline of the dominant kernel = the first launch of the find_mems stage (pgx_find_mems_pairs_kernel where the index has a PAIRS
+    image, else pgx_find_mems_kernel), timed on its own by HIP events on the launch stream (pgx_timing.ms_find_mems_main).
+
+    frac       bytes the kernel actually moves / its time / the HBM peak.  The bytes are counted by the kernel itself (pgx_timing.main_lines,
+               main_seed_loads: lane trips that fetch a 128-byte line of the rank image, seed / end table entries read) x 128 B, plus what
+               it streams: the read bytes and offsets once, 32 B per MEM written, 4 B per read of MEM counts.  Always <= 1.
+    algorithmic_ratio   the SURVEY 8d figure: bytes the REFERENCE layout would move for the same extensions (2 rank probes x (B_blk + 16 B)
+               per extension, L+1 input bytes per read, 32 B per MEM) over the time of the whole find_mems stage, relative to the HBM
+               peak.  Seeds and two-step trips answer extensions without the probes this charges for, so it may exceed 1: a speed-up
+               over the reference layout at the roofline, not a bandwidth."""
     n_mems, _, n_ext = counts
     b_blk = float(info.ref_block_mean_bytes)
     algo_bytes = n_ext * 2.0 * (b_blk + 16.0) + float(cat_len + n_reads) + 32.0 * n_mems
-    achieved = algo_bytes / (fm_ms * 1e-3) / 1e9 if fm_ms > 0 else 0.0
+    fm_ms, main_ms = k_ms["find_mems"], k_ms["find_mems_main"]
     in_lds = bool(info.image_in_lds)
+    pairs = bool(getattr(info, "image_pairs", 0)) and bool(timing.pairs_reads)
+    lines, seeds = int(timing.main_lines), int(timing.main_seed_loads)
+    all_lines = lines + int(timing.other_lines)
+    moved = 128.0 * (lines + seeds) + float(cat_len) + 8.0 * (n_reads + 1) + 32.0 * n_mems + 4.0 * n_reads
+    achieved = moved / (main_ms * 1e-3) / 1e9 if main_ms > 0 else 0.0
     rec = {
-        # what bounds the kernel: with the rank image staged in LDS nothing of it comes from HBM (issue slots / LDS bound it);
-        # otherwise random 128-byte line fetches from HBM (or the Infinity Cache when the image fits it)
-        "bound": "lds/valu" if in_lds else "hbm",
-        "kernel": "pgx_find_mems_pairs_kernel (+ pgx_find_mems_kernel for the reads it hands on)" if getattr(info, "image_pairs", 0) else "pgx_find_mems_kernel",
-        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS,
-        "frac_note": ("algorithmic bytes of the reference layout over kernel time, relative to the HBM peak; the image is in LDS, so this is "
-                      "a nominal ratio, not an achieved HBM fraction") if in_lds else
-                     ("algorithmic bytes of the reference layout (SURVEY 8d) over kernel time, relative to the HBM peak; the two-step PAIRS image "
-                      "answers two extensions from one cache line, so the bytes actually moved (traffic) are about half of these and the "
-                      "ratio can exceed 1" if getattr(info, "image_pairs", 0) else
-                      "algorithmic bytes of the reference layout (SURVEY 8d) over kernel time, relative to the HBM peak"),
-        "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": fm_ms,
-        "bytes_per_extension": 2.0 * (b_blk + 16.0), "extensions_per_launch": n_ext,
+        # with the rank image staged in LDS nothing of it comes from HBM: issue slots / LDS bound the kernel and frac only says how little
+        # of the HBM roofline it needs; otherwise the bound is random 128-byte line fetches from HBM (or the memory-side cache)
+        "bound": "hbm",
+        "kernel": "pgx_find_mems_pairs_kernel" if pairs else "pgx_find_mems_kernel",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "frac_note": ("bytes moved per launch (kernel-counted image lines and seed entries x 128 B + streamed reads, offsets, MEM slots) / kernel time / HBM peak"
+                      + ("; the rank image is staged in LDS, so the kernel is bound by LDS / issue slots, not by HBM" if in_lds else "")),
+        "kernel_ms": main_ms, "bytes_moved_per_launch": moved,
+        "probes_issued": lines, "seed_loads": seeds, "lines_per_s": (lines + seeds) / (main_ms * 1e-3) if main_ms > 0 else 0.0,
+        "frac_of_gather_ceiling": ((lines + seeds) / (main_ms * 1e-3) / GATHER_CEILING_LINES_PER_S) if (main_ms > 0 and not in_lds) else None,
+        "gather_ceiling_note": "dependent random 128-byte lines/s of scripts/ubench_gather.hip on a 2 GB table (profiles/r01_ubench_random_gather.txt)",
+        "extensions_per_line": (n_ext / all_lines) if all_lines else None,
+        "two_step_trips": int(timing.two_step_trips),
+        "other_launches": {"lines": int(timing.other_lines), "seed_loads": int(timing.other_seed_loads), "ms": max(fm_ms - main_ms, 0.0),
+                           "what": "pgx_find_mems_kernel over the reads handed on / on the second stream, heavy-read kernel"},
+        "traffic": None,
+        "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_ratio": (algo_bytes / (fm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fm_ms > 0 else None,
+        "algorithmic_ratio_note": "SURVEY 8d bytes of the reference layout for the same extensions / time of the find_mems stage / HBM peak; may exceed 1 (work avoided, not bandwidth)",
+        "stage_ms": fm_ms, "bytes_per_extension": 2.0 * (b_blk + 16.0), "extensions_per_launch": n_ext,
     }
     # counter traffic only from a PMC record of THIS workload (scripts/profile_round.sh writes what it measured)
     tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload_key)
@@ -205,10 +225,63 @@ def roofline_record(info, cat_len, n_reads, counts, fm_ms, workload_key, min_len
                     and int(t.get("image_pairs", 0)) == int(info.image_pairs) and bool(t.get("tags", True)) == bool(tags))
             if same:
                 rec["traffic"] = t.get("find_mems_hbm_bytes_per_launch")
-                rec["traffic_source"] = "profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % workload_key
+                rec["traffic_source"] = ("profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, recorded %s; all find_mems launches of a step)"
+                                         % (workload_key, t.get("recorded", "in round 2")))
+                if rec["traffic"]:
+                    total_model = moved + 128.0 * (int(timing.other_lines) + int(timing.other_seed_loads))
+                    rec["traffic_over_model"] = rec["traffic"] / total_model
         except Exception:
             pass
     return rec
+
+
+_ORACLE = {}
+
+
+def oracle_objects(ri, tags):
+    """the oracle's view of the index files (loaded once per bench run; used by the cpu_baseline and parity_sample legs only)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi as O
+
+    key = (ri, tags)
+    if key not in _ORACLE:
+        _ORACLE.clear()  # one index at a time (the chr22-scale oracle structures take gigabytes)
+        _ORACLE[key] = (O.RIndex(ri), None if tags is None else O.Tags(tags, O.TAGS_COMPACT))
+    return _ORACLE[key]
+
+
+def parity_sample(args, ri, tags, cat, offs, min_len, res, sample, idx=None, local=0):
+    """The oracle on the first `sample` reads of the batch against the prefix of the device result of the SAME batch run (one chunk of
+    n reads, the measured configuration): MEM offsets, MEM bytes, tag run counts, positions.  The oracle is the checker here, nothing else."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+
+    import oracle_ffi as O
+
+    L = args.read_len
+    r, t = oracle_objects(ri, tags)
+    mode = O.MODE_COMPAT if args.mode == "compat" else O.MODE_STRICT
+    cores = host_cores(O.lib().orc_max_threads())
+    ref = O.find_mems_batch(r, t, cat[: sample * L], offs[: sample + 1], min_len, args.min_occ, mode=mode, threads=cores)
+    nm = int(ref["mem_offsets"][-1])
+    ok = bool(np.array_equal(res["mem_offsets"][: sample + 1], ref["mem_offsets"])
+              and res["mems"][:nm].tobytes() == ref["mems"].tobytes())
+    npos = 0
+    if ok and t is not None:
+        npos = int(ref["pos_offsets"][-1])
+        ok = bool(np.array_equal(res["tag_run_counts"][:nm], ref["tag_run_counts"])
+                  and np.array_equal(res["pos_offsets"][: nm + 1], ref["pos_offsets"])
+                  and np.array_equal(res["positions"][:npos], ref["positions"]))
+    ext_ok = None
+    if idx is not None:  # the same reads as a batch of their own: everything again, and the extension counter (a total per run) against the oracle's
+        own = idx.find_mems(cat[: sample * L], offs[: sample + 1], min_len, args.min_occ, tags=t is not None, device=local)
+        ext_ok = bool(own["n_extensions"] == ref["n_extensions"] and np.array_equal(own["mem_offsets"], ref["mem_offsets"])
+                      and own["mems"].tobytes() == ref["mems"].tobytes()
+                      and (t is None or (np.array_equal(own["pos_offsets"], ref["pos_offsets"]) and np.array_equal(own["positions"], ref["positions"]))))
+        ok = ok and ext_ok
+    return {"reads": int(sample), "mems": nm, "positions": npos, "extensions_of_the_sample": int(ref["n_extensions"]), "identical": ok,
+            "sample_as_its_own_batch_identical_incl_n_extensions": ext_ok,
+            "what": "oracle (CPU restatement of the reference) on the first reads of the measured batch vs the prefix of the device result of the whole batch"}
 
 
 def main():
@@ -294,6 +367,7 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     tot = [float(v) for v in tot.tolist()]
 
+    parity_failed = False
     if rank == 0:
         K, n = args.steps, args.reads
         reads_total = n * world * K
@@ -333,19 +407,25 @@ def main():
             "kernel_ms_per_step": k_ms,
             "speculative_runs": dict(zip(("sized_from_the_previous_run", "repeated_with_exact_sizes"), batch.spec_stats())),
             "pairs_kernel": {"used": bool(batch.timing().pairs_reads), "reads_handed_to_the_dense2_kernel": int(batch.timing().redo_reads)},
-            "roofline": roofline_record(info, len(cat), n, counts, k_ms["find_mems"], args.workload, args.min_len, not args.no_tags),
+            "roofline": roofline_record(info, len(cat), n, counts, k_ms, batch.timing(), args.workload, args.min_len, not args.no_tags),
         }
         if args.pcie:
             line["pcie_inclusive_reads_per_s"] = pcie_rate(idx, cat, offs, args, local)
             line["pcie_inclusive_note"] = "long-lived batch: pgx_batch_upload (H2D of reads + offsets), pgx_batch_run, pgx_batch_result (D2H of MEMs / positions into host arrays)"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, ri, None if args.no_tags else tags, cat, offs, args.min_len)
+        if world == 1 and not args.no_parity:
+            # the measured configuration itself under the oracle: the result of the last timed step, downloaded, against the oracle on a prefix
+            sample = min(n, args.parity_reads)
+            line["parity_sample"] = parity_sample(args, ri, None if args.no_tags else tags, cat, offs, args.min_len, batch.result(), sample, idx, local)
+            parity_failed = parity_failed or not line["parity_sample"]["identical"]
     batch.free()
     idx.close()
     del cat, offs
     if rank == 0:
         if args.workload == "chr22" and world == 1 and not args.no_secondary:
             line["secondary"] = secondary_x(args, P, wd, local, stream, torch)
+            parity_failed = parity_failed or not line["secondary"].get("parity_sample", {}).get("identical", True)
         print(json.dumps(line), flush=True)
     barrier()
     if use_dist:
@@ -354,6 +434,9 @@ def main():
         import shutil
 
         shutil.rmtree(own_tmp, ignore_errors=True)
+    if parity_failed:
+        sys.stderr.write("[bench] PARITY MISMATCH between the device result and the oracle on the sample\n")
+        sys.exit(3)
 
 
 def pcie_rate(idx, cat, offs, args, local, min_len=None, reps=5):
@@ -387,10 +470,12 @@ def secondary_x(args, P, wd, local, stream, torch):
         "value": n * args.steps / dt, "unit": "reads/s", "ms_per_step": dt / args.steps * 1e3, "min_len": min_len,
         "mems_per_step": counts[0], "positions_per_step": counts[1], "extensions_per_step": counts[2], "kernel_ms_per_step": k_ms,
         "image_in_lds": bool(info.image_in_lds),
-        "roofline": roofline_record(info, len(cat), n, counts, k_ms["find_mems"], "x", min_len, not args.no_tags),
+        "roofline": roofline_record(info, len(cat), n, counts, k_ms, batch.timing(), "x", min_len, not args.no_tags),
         "pcie_inclusive_reads_per_s": pcie_rate(idx, cat, offs, args, local, min_len=min_len),
         "caveat": "no-N index: COMPAT searches die at every T (SURVEY 8a quirk 1), reads/s is inflated relative to a proper FMD index",
     }
+    if not args.no_parity:
+        out["parity_sample"] = parity_sample(args, ri, None if args.no_tags else tags, cat, offs, min_len, batch.result(), min(n, args.parity_reads), idx, local)
     batch.free()
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, ri, None if args.no_tags else tags, cat, offs, min_len, seconds=min(args.cpu_seconds, 8.0))
@@ -512,8 +597,7 @@ def cpu_baseline(args, ri, tags, cat, offs, min_len, seconds=None):
     import oracle_ffi as O
 
     seconds = args.cpu_seconds if seconds is None else seconds
-    r = O.RIndex(ri)
-    t = None if tags is None else O.Tags(tags, O.TAGS_COMPACT)
+    r, t = oracle_objects(ri, tags)
     mode = O.MODE_COMPAT if args.mode == "compat" else O.MODE_STRICT
     cores = host_cores(O.lib().orc_max_threads())
     L = args.read_len

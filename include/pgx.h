@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PGX_ABI_VERSION 2 /* 2: pgx_timing grew (pairs_reads, redo_reads), pgx_index_info.image_pairs, PGX_MODE_IMAGE_PAIRS */
+#define PGX_ABI_VERSION 3 /* 2: pgx_timing grew (pairs_reads, redo_reads), pgx_index_info.image_pairs, PGX_MODE_IMAGE_PAIRS; 3: pgx_timing grew (ms_find_mems_main, traffic counters) */
 
 typedef enum {
     PGX_OK = 0,
@@ -254,6 +254,16 @@ typedef struct {
     uint32_t heavy_reads; /* reads whose rest went through the heavy-read kernel (filled by every run, timed or not) */
     uint32_t pairs_reads; /* 1 = the run used the two-step PAIRS kernel */
     uint32_t redo_reads;  /* reads the PAIRS kernel handed on to the dense2 kernel (they met \n or N in the BWT) */
+    /* the first launch of the find_mems stage alone (the PAIRS kernel when pairs_reads, else pgx_find_mems_kernel): ms_find_mems
+     * also covers the launches behind it (reads handed on, heavy reads) */
+    float ms_find_mems_main;
+    uint32_t seed_depth;  /* depth K of the k-mer seed table the run used (0 = none: no table, or min_len below every table's depth) */
+    /* what the kernels asked of the memory system, counted by the kernels themselves (filled by every run, timed or not; zero for
+     * images staged in LDS): 128-byte lines of the rank image fetched by rank probes -- trips whose line every lane shares (a
+     * stage's first probe of the full interval) are not counted -- and seed / end table entries read (16 bytes, one line each) */
+    uint64_t main_lines, main_seed_loads;   /* the launch ms_find_mems_main times */
+    uint64_t other_lines, other_seed_loads; /* the other pgx_find_mems_kernel launches of the run */
+    uint64_t two_step_trips;                /* PAIRS kernel: lane trips that performed two extensions from one line */
 } pgx_timing;
 
 /* Upload reads (read i = reads[offsets[i] .. offsets[i+1]); the `std::getline` lines of
@@ -333,6 +343,21 @@ typedef struct {
  * result lives in buffers of the communicator until its next exchange. */
 pgx_status pgx_exchange_mems(pgx_comm *c, pgx_batch *const *batches, const uint32_t *shard_ids, uint32_t n_local,
                              const uint32_t *owner_of_shard, uint32_t n_shards, pgx_exchange_result *out);
+/* The host-side plan of an exchange, as a function of its own (no device, no RCCL: the unit tests of the slot arithmetic call it on the
+ * CPU tier).  owner_of_shard as above; gathered = what the metadata all-gather delivers: `world` rows of PGX_XCH_META_HEAD + max_local
+ * u64 each -- {status, n_reads, n_shards, digest of owner_of_shard, max_local, MEMs of the rank's 1st, 2nd, ... shard (ascending shard id)}.
+ * Outputs (caller-allocated): slot[n_shards] = row of shard c in the gathered offsets (owner * max_local + k for the owner's k-th shard),
+ * rec_base[world + 1] = first record of every rank in the gathered record array, src_base[n_shards] = first record of every shard,
+ * *n_reads = the number of reads every rank that owns a shard reports.  PGX_ERR_ARG when any rank reported a non-zero status, ranks
+ * disagree on n_reads / n_shards / the owner table, or the gathered offsets would exceed PGX_XCH_MAX_OFFSET_BYTES (the caller must
+ * then exchange its reads in chunks: at 100 M reads x 24 shards on 8 ranks the offsets alone are 9.6 GB; 16 M reads per call keep
+ * them at 1.5 GB). */
+#define PGX_XCH_META_HEAD 5u
+#define PGX_XCH_MAX_OFFSET_BYTES (4ull << 30)
+pgx_status pgx_exchange_plan(uint32_t world, const uint32_t *owner_of_shard, uint32_t n_shards, const uint64_t *gathered,
+                             uint32_t *max_local, uint32_t *slot, uint64_t *rec_base, uint64_t *src_base, uint64_t *n_reads);
+/* digest of an owner table as the metadata carries it (FNV-1a over the entries) */
+uint64_t pgx_exchange_owner_digest(const uint32_t *owner_of_shard, uint32_t n_shards);
 /* copy the last exchange's result to host arrays (any may be NULL) */
 pgx_status pgx_exchange_download(pgx_comm *c, uint64_t *mem_offsets, pgx_mem *mems, uint32_t *shard_of_mem);
 

@@ -7,6 +7,33 @@
 #include "../../include/pgx.h"
 #include "pgx_image.h"
 
+// Counters of one pgx_batch_run: u64 slots of pgx_batch::counters (the find_mems kernels receive the base pointer as `n_ext_total`).
+// Slots below 16 are cleared per chunk of reads and per attempt; the others once per run.
+enum PgxCounterSlot {
+    PGX_CTR_EXT = 0,          // extensions performed (equal to the oracle's count)
+    PGX_CTR_TAG_OVERFLOW = 1, // tag queries that read past the stored runs (quirk 7)
+    PGX_CTR_CURSOR = 5,       // read cursor of the main launch
+    PGX_CTR_HEAVY = 8,        // reads handed to pgx_find_mems_heavy_kernel
+    PGX_CTR_OVF32 = 9,        // a coordinate left 32 bits (NARROW kernels): the chunk is repeated in 64 bits
+    PGX_CTR_MEMS = 10,        // MEMs of the chunk (scan total)
+    PGX_CTR_REDO = 11,        // reads the pairs kernel handed on
+    PGX_CTR_REDO_CURSOR = 12, // read cursor of the hand-on launch
+    PGX_CTR_SIDE_CURSOR = 13, // read cursor of the side-stream launch (reads with a byte outside A C G T)
+    PGX_CTR_TAG0 = 16,        // 16..24: tag stage (tag_pipeline)
+    PGX_CTR_ABORT = 30,       // abort flag of a speculative run
+    // what the kernels ask of the memory system (always on; bench.py's roofline): lane trips that fetch a rank-image line that is
+    // not one every lane shares (a stage's first trip probes the full interval: block 0 / the last block), seed / end table entries read
+    PGX_CTR_PAIRS_LINES = 32, // pgx_find_mems_pairs_kernel: 128-byte block lines (second-block trips included)
+    PGX_CTR_PAIRS_SEEDS = 33, //                             seed / end table entries (16 bytes each, one line each)
+    PGX_CTR_FM_LINES = 34,    // pgx_find_mems_kernel (global-memory images): 128-byte lines holding the blocks of its probes
+    PGX_CTR_FM_SEEDS = 35,
+    PGX_CTR_PAIRS_TWO = 36,   // pairs kernel: lane trips that performed two extensions
+    // -DPGX_FM_STATS builds only (scripts/fm_stats.sh)
+    PGX_CTR_ST_TRIPS = 40, PGX_CTR_ST_LIVE = 41, PGX_CTR_ST_LONGEST = 42,                  // pgx_find_mems_kernel: wave trips, live lane trips, longest wave
+    PGX_CTR_ST_PAIR_TRIPS = 43, PGX_CTR_ST_PAIR_LIVE = 44, PGX_CTR_ST_PAIR_WAIT = 45, PGX_CTR_ST_PAIR_FRESH = 46,
+    PGX_CTR_SLOTS = 64
+};
+
 #define PGX_DENSE_LDS_U4 5 // uint4 slots per dense block in LDS (64 data bytes + 16 of padding)
 #define PGX_FM_THREADS 256
 #define PGX_FM_WAVES_PER_SIMD 4 // __launch_bounds__ 2nd argument: caps the kernel at 128 VGPRs

@@ -146,23 +146,97 @@ extern "C" pgx_status pgx_comm_init(const uint8_t id[PGX_COMM_ID_BYTES], int ran
     PGX_GUARD_END
 }
 
-extern "C" pgx_status pgx_exchange_mems(pgx_comm *c, pgx_batch *const *batches, const uint32_t *shard_ids, uint32_t n_local,
-                                        const uint32_t *owner_of_shard, uint32_t n_shards, pgx_exchange_result *out) {
-    PGX_GUARD_BEGIN
-    if (!c || !out || !owner_of_shard || !n_shards || (n_local && (!batches || !shard_ids))) throw Error(PGX_ERR_ARG, "pgx_exchange_mems: null argument");
-    pgx_use_device(c->device);
-    hipStream_t s = c->stream;
-    // slots: rank r's k-th shard (ascending shard id) sits at slot r * max_local + k of the gathered offsets
-    std::vector<uint32_t> per_rank(c->world, 0), slot(n_shards), kth(n_shards);
+extern "C" uint64_t pgx_exchange_owner_digest(const uint32_t *owner_of_shard, uint32_t n_shards) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (uint32_t i = 0; owner_of_shard && i < n_shards; i++)
+        for (int b = 0; b < 4; b++) { h ^= (owner_of_shard[i] >> (8 * b)) & 0xFFu; h *= 0x100000001b3ull; }
+    return h;
+}
+
+// shards per rank and the largest such count (rows per rank in the gathered offsets)
+static uint32_t shards_per_rank(uint32_t world, const uint32_t *owner_of_shard, uint32_t n_shards, std::vector<uint32_t> &per_rank, std::vector<uint32_t> &kth) {
+    per_rank.assign(world, 0);
+    kth.assign(n_shards, 0);
     for (uint32_t sh = 0; sh < n_shards; sh++) {
-        if (owner_of_shard[sh] >= (uint32_t)c->world) throw Error(PGX_ERR_ARG, "pgx_exchange_mems: owner rank out of range");
+        if (owner_of_shard[sh] >= world) throw Error(PGX_ERR_ARG, "pgx_exchange_mems: owner rank out of range");
         kth[sh] = per_rank[owner_of_shard[sh]]++;
     }
     uint32_t max_local = 1;
     for (uint32_t v : per_rank) max_local = std::max(max_local, v);
+    return max_local;
+}
+
+extern "C" pgx_status pgx_exchange_plan(uint32_t world, const uint32_t *owner_of_shard, uint32_t n_shards, const uint64_t *gathered,
+                                        uint32_t *max_local_out, uint32_t *slot, uint64_t *rec_base, uint64_t *src_base, uint64_t *n_reads_out) {
+    PGX_GUARD_BEGIN
+    if (!world || !owner_of_shard || !n_shards || !gathered || !max_local_out || !slot || !rec_base || !src_base || !n_reads_out)
+        throw Error(PGX_ERR_ARG, "pgx_exchange_plan: null argument");
+    std::vector<uint32_t> per_rank, kth;
+    const uint32_t max_local = shards_per_rank(world, owner_of_shard, n_shards, per_rank, kth);
+    const size_t meta_n = PGX_XCH_META_HEAD + max_local;
+    const uint64_t digest = pgx_exchange_owner_digest(owner_of_shard, n_shards);
+    // every rank sees the same rows, so every rank fails (or not) here together
+    for (uint32_t r = 0; r < world; r++) {
+        const uint64_t *m = gathered + (size_t)r * meta_n;
+        if (m[0]) throw Error(PGX_ERR_ARG, "pgx_exchange_mems: rank " + std::to_string(r) + " reported status " + std::to_string(m[0]) + " (its own error message says why)");
+        if (m[2] != n_shards || m[3] != digest || m[4] != max_local) throw Error(PGX_ERR_ARG, "pgx_exchange_mems: rank " + std::to_string(r) + " passed a different owner_of_shard table");
+    }
+    bool have = false;
+    uint64_t n_reads = 0;
+    for (uint32_t r = 0; r < world; r++) { // ranks without shards learn n_reads from the ones that have some
+        if (!per_rank[r]) continue;
+        const uint64_t nr = gathered[(size_t)r * meta_n + 1];
+        if (have && nr != n_reads) throw Error(PGX_ERR_ARG, "pgx_exchange_mems: ranks disagree on the number of reads");
+        n_reads = nr; have = true;
+    }
+    if ((uint64_t)world * max_local * (n_reads + 1) * 4 > PGX_XCH_MAX_OFFSET_BYTES)
+        throw Error(PGX_ERR_ARG, "pgx_exchange_mems: " + std::to_string(n_reads) + " reads x " + std::to_string(world * max_local) +
+                                     " offset rows exceed PGX_XCH_MAX_OFFSET_BYTES: exchange the reads in chunks");
     for (uint32_t sh = 0; sh < n_shards; sh++) slot[sh] = owner_of_shard[sh] * max_local + kth[sh];
-    if (n_local != per_rank[c->rank]) throw Error(PGX_ERR_ARG, "pgx_exchange_mems: this rank passes " + std::to_string(n_local) + " batches but owns " +
-                                                                   std::to_string(per_rank[c->rank]) + " shards");
+    rec_base[0] = 0;
+    for (uint32_t r = 0; r < world; r++) {
+        uint64_t m = 0;
+        for (uint32_t k = 0; k < per_rank[r]; k++) m += gathered[(size_t)r * meta_n + PGX_XCH_META_HEAD + k];
+        rec_base[r + 1] = rec_base[r] + m;
+    }
+    for (uint32_t sh = 0; sh < n_shards; sh++) {
+        const uint32_t r = owner_of_shard[sh];
+        uint64_t b = rec_base[r];
+        for (uint32_t k = 0; k < kth[sh]; k++) b += gathered[(size_t)r * meta_n + PGX_XCH_META_HEAD + k];
+        src_base[sh] = b;
+    }
+    *max_local_out = max_local;
+    *n_reads_out = n_reads;
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+namespace {
+struct GroupGuard { // a throw between ncclGroupStart and ncclGroupEnd must not leave the group open
+    bool open = false;
+    void start() { NCCLCHECK(rccl().GroupStart()); open = true; }
+    void end() { open = false; NCCLCHECK(rccl().GroupEnd()); }
+    ~GroupGuard() { if (open) (void)rccl().GroupEnd(); }
+};
+} // namespace
+
+extern "C" pgx_status pgx_exchange_mems(pgx_comm *c, pgx_batch *const *batches, const uint32_t *shard_ids, uint32_t n_local,
+                                        const uint32_t *owner_of_shard, uint32_t n_shards, pgx_exchange_result *out) {
+    PGX_GUARD_BEGIN
+    // Arguments every rank must agree on BEFORE any collective (world, n_shards > 0): a violation here cannot be reported to the peers.
+    if (!c || !out || !owner_of_shard || !n_shards) throw Error(PGX_ERR_ARG, "pgx_exchange_mems: null argument");
+    pgx_use_device(c->device);
+    hipStream_t s = c->stream;
+    std::vector<uint32_t> per_rank, kth;
+    const uint32_t max_local = shards_per_rank((uint32_t)c->world, owner_of_shard, n_shards, per_rank, kth);
+    // Rank-local validation: a failure becomes the status word of this rank's metadata row -- the rank still enters the metadata
+    // all-gather, and every rank then fails together in pgx_exchange_plan instead of this one leaving its peers blocked in a collective.
+    uint64_t status = 0;
+    std::string why;
+    auto fail = [&](uint64_t code, const std::string &msg) { if (!status) { status = code; why = msg; } };
+    if (n_local && (!batches || !shard_ids)) { fail(PGX_ERR_ARG, "pgx_exchange_mems: null argument"); n_local = 0; }
+    if (n_local != per_rank[c->rank])
+        fail(PGX_ERR_ARG, "pgx_exchange_mems: this rank passes " + std::to_string(n_local) + " batches but owns " + std::to_string(per_rank[c->rank]) + " shards");
     // local batches in ascending shard order
     std::vector<uint32_t> order(n_local);
     for (uint32_t k = 0; k < n_local; k++) order[k] = k;
@@ -170,33 +244,34 @@ extern "C" pgx_status pgx_exchange_mems(pgx_comm *c, pgx_batch *const *batches, 
     uint64_t n_reads = 0;
     std::vector<pgx_device_result> dr(n_local);
     uint64_t m_local = 0;
-    for (uint32_t k = 0; k < n_local; k++) {
+    for (uint32_t k = 0; k < n_local && !status; k++) {
         const uint32_t b = order[k];
-        if (shard_ids[b] >= n_shards || owner_of_shard[shard_ids[b]] != (uint32_t)c->rank || (k && shard_ids[order[k - 1]] == shard_ids[b]))
-            throw Error(PGX_ERR_ARG, "pgx_exchange_mems: shard ids of this rank do not match owner_of_shard");
-        if (pgx_batch_device_result(batches[b], &dr[k]) != PGX_OK) throw Error(PGX_ERR_ARG, std::string("pgx_exchange_mems: ") + pgx_last_error());
+        if (shard_ids[b] >= n_shards || owner_of_shard[shard_ids[b]] != (uint32_t)c->rank || (k && shard_ids[order[k - 1]] == shard_ids[b])) {
+            fail(PGX_ERR_ARG, "pgx_exchange_mems: shard ids of this rank do not match owner_of_shard"); break; }
+        if (pgx_batch_device_result(batches[b], &dr[k]) != PGX_OK) { fail(PGX_ERR_ARG, std::string("pgx_exchange_mems: ") + pgx_last_error()); break; }
         if (k == 0) n_reads = dr[k].n_reads;
-        else if (dr[k].n_reads != n_reads) throw Error(PGX_ERR_ARG, "pgx_exchange_mems: every shard must have searched the same reads");
-        if (dr[k].n_mems >> 32) throw Error(PGX_ERR_UNSUPPORTED, "pgx_exchange_mems: more than 2^32 MEMs in one shard batch (use smaller read batches)");
+        else if (dr[k].n_reads != n_reads) { fail(PGX_ERR_ARG, "pgx_exchange_mems: every shard must have searched the same reads"); break; }
+        if (dr[k].n_mems >> 32) { fail(PGX_ERR_UNSUPPORTED, "pgx_exchange_mems: more than 2^32 MEMs in one shard batch (use smaller read batches)"); break; }
         m_local += dr[k].n_mems;
     }
-    // every rank must name the same n_reads: ranks without shards learn it from the gathered metadata below
-    // ---- 1. metadata: (n_reads, MEMs of every local shard) per rank, gathered as u64
-    const size_t meta_n = 1 + max_local;
+    // ---- 1. metadata row of this rank: {status, n_reads, n_shards, digest of the owner table, max_local, MEMs of every local shard}, gathered as u64
+    const size_t meta_n = PGX_XCH_META_HEAD + max_local;
     std::vector<uint64_t> h_meta(meta_n, 0), h_all_meta((size_t)c->world * meta_n, 0);
-    h_meta[0] = n_reads;
-    for (uint32_t k = 0; k < n_local; k++) h_meta[1 + k] = dr[k].n_mems;
+    h_meta[0] = status; h_meta[1] = n_reads; h_meta[2] = n_shards; h_meta[3] = pgx_exchange_owner_digest(owner_of_shard, n_shards); h_meta[4] = max_local;
+    for (uint32_t k = 0; k < n_local && !status; k++) h_meta[PGX_XCH_META_HEAD + k] = dr[k].n_mems;
     c->meta.ensure((size_t)(c->world + 1) * meta_n * 8);
     uint64_t *d_meta = c->meta.as<uint64_t>(), *d_all_meta = d_meta + meta_n;
     HIPCHECK(hipMemcpyAsync(d_meta, h_meta.data(), meta_n * 8, hipMemcpyHostToDevice, s));
     NCCLCHECK(rccl().AllGather(d_meta, d_all_meta, meta_n, ncclUint64, c->comm, s));
     HIPCHECK(hipMemcpyAsync(h_all_meta.data(), d_all_meta, (size_t)c->world * meta_n * 8, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
-    for (int r = 0; r < c->world; r++) {
-        const uint64_t nr = h_all_meta[(size_t)r * meta_n];
-        if (per_rank[r] && n_reads == 0 && !n_local) n_reads = nr;
-        if (per_rank[r] && nr != n_reads && (n_local || n_reads)) throw Error(PGX_ERR_ARG, "pgx_exchange_mems: ranks disagree on the number of reads");
-    }
+    if (status) throw Error((pgx_status)status, why); // (the peers fail in the plan below, on this rank's status word)
+    // ---- the plan: identical on every rank (same gathered rows), so is its verdict
+    std::vector<uint32_t> slot(n_shards);
+    std::vector<uint64_t> rec_base(c->world + 1, 0), src_base(n_shards, 0);
+    uint32_t ml = 0;
+    if (pgx_exchange_plan((uint32_t)c->world, owner_of_shard, n_shards, h_all_meta.data(), &ml, slot.data(), rec_base.data(), src_base.data(), &n_reads) != PGX_OK)
+        throw Error(PGX_ERR_ARG, pgx_last_error());
     // ---- 2. local offsets (u32) and records (concatenated in shard order)
     const size_t row = n_reads + 1;
     c->local_offs.ensure((size_t)max_local * row * 4);
@@ -213,27 +288,18 @@ extern "C" pgx_status pgx_exchange_mems(pgx_comm *c, pgx_batch *const *batches, 
     HIPCHECK(hipGetLastError());
     NCCLCHECK(rccl().AllGather(c->local_offs.p, c->all_offs.p, (size_t)max_local * row, ncclUint32, c->comm, s));
     // ---- 3. records: one broadcast per rank, each as long as that rank's list
-    std::vector<uint64_t> rec_base(c->world + 1, 0), src_base(n_shards, 0);
-    for (int r = 0; r < c->world; r++) {
-        uint64_t m = 0;
-        for (uint32_t k = 0; k < per_rank[r]; k++) m += h_all_meta[(size_t)r * meta_n + 1 + k];
-        rec_base[r + 1] = rec_base[r] + m;
-    }
-    for (uint32_t sh = 0; sh < n_shards; sh++) {
-        const uint32_t r = owner_of_shard[sh];
-        uint64_t b = rec_base[r];
-        for (uint32_t k = 0; k < kth[sh]; k++) b += h_all_meta[(size_t)r * meta_n + 1 + k];
-        src_base[sh] = b;
-    }
     const uint64_t total = rec_base[c->world];
     c->all_recs.ensure((total ? total : 1) * sizeof(pgx_mem));
-    NCCLCHECK(rccl().GroupStart());
-    for (int r = 0; r < c->world; r++) {
-        const uint64_t m = rec_base[r + 1] - rec_base[r];
-        if (!m) continue;
-        NCCLCHECK(rccl().Broadcast(c->send.p, c->all_recs.as<pgx_mem>() + rec_base[r], m * 4, ncclUint64, r, c->comm, s));
+    {
+        GroupGuard g;
+        g.start();
+        for (int r = 0; r < c->world; r++) {
+            const uint64_t m = rec_base[r + 1] - rec_base[r];
+            if (!m) continue;
+            NCCLCHECK(rccl().Broadcast(c->send.p, c->all_recs.as<pgx_mem>() + rec_base[r], m * 4, ncclUint64, r, c->comm, s));
+        }
+        g.end();
     }
-    NCCLCHECK(rccl().GroupEnd());
     // ---- 4. per-read totals -> scan -> interleave
     c->totals.ensure((n_reads ? n_reads : 1) * 8);
     c->out_offs.ensure((n_reads + 1) * 8);

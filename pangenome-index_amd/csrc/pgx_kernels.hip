@@ -537,6 +537,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     bool ovf = false;                // NARROW: some addition left 32 bits (reported once, when the wave leaves)
     uint64_t rnext = 0, rend = 0;    // wave-uniform reservoir of read ids
     bool exhausted = false;          // wave-uniform: the global cursor has passed n_reads
+    unsigned long long ln_blk = 0, ln_seed = 0; // wave-uniform (scalar registers): image lines / seed entries the wave asked for (PGX_CTR_FM_LINES / _SEEDS; images in global memory)
 #ifdef PGX_FM_STATS
     unsigned long long st_trips = 0, st_live = 0; // diagnostics build only (scripts/fm_stats.sh)
 #endif
@@ -624,6 +625,11 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
         st_trips++;
         st_live += (unsigned long long)__popcll(__ballot(ph > 0));
 #endif
+        // what the wave asks of the memory system in this trip (wave-uniform sums in scalar registers; images in global memory): seed / end table
+        // entries -- one per first trip of a backward stage, an upper bound: windows that hold a byte outside A C G T and stages with fewer than
+        // K extensions to go read the shared entry 0 -- and, counted behind the block, the lines holding the blocks of the two probes
+        if (SEED && !LDS_IMAGE) ln_seed += (unsigned long long)__popcll(__ballot(ph > 0 && fresh != 0u));
+        bool c_blk = false, c_blk2 = false;
         if (ph > 0) {
             // ---- k-mer seed of a backward stage that starts now: the entry is loaded next to the block loads of the ordinary
             //      extension by P[j] (which every lane performs regardless) and replaces its result further down ----
@@ -693,6 +699,10 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                 }
                 A0 = (pos_t)q0; A1 = (pos_t)q1; dB = (pos_t)dq;
                 fin = true;
+                if (s != n) { // (the full interval probes block 0 and the last block: lines every lane shares)
+                    const uint64_t e0 = (uint64_t)kk > (uint64_t)n ? (uint64_t)n : (uint64_t)kk, e1 = (uint64_t)kk + (uint64_t)s > (uint64_t)n ? (uint64_t)n : (uint64_t)kk + (uint64_t)s;
+                    c_blk = true; c_blk2 = (uint32_t)((e0 * 0xAAAAAAABull) >> 40) != (uint32_t)((e1 * 0xAAAAAAABull) >> 40);
+                }
             } else if (NARROW) {
                 const uint32_t ks = (uint32_t)kk + (uint32_t)s;
                 ovf |= ks < (uint32_t)kk; // kk + s left 32 bits (junk coordinates of a COMPAT quirk): the host repeats the chunk in 64 bits
@@ -702,6 +712,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                 pgx_dense_pair32(k0, p0, k1, p1, cv, mrow, a0, a1, d);
                 A0 = (pos_t)a0; A1 = (pos_t)a1; dB = (pos_t)d;
                 fin = true;
+                c_blk = s != n; c_blk2 = c_blk && (p0 >> 7) != (p1 >> 7);
             } else if (DENSE == 1) {
                 // dense image: the two block addresses are known at once (pos >> 6), so both 64-byte loads are in flight
                 // together and every extension is a single trip
@@ -712,6 +723,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                 pgx_dense_rank(k1, p1, cv, mrow, Aq1, Bq1);
                 A0 = (pos_t)Aq0; A1 = (pos_t)Aq1; dB = (pos_t)(Bq1 - Bq0);
                 fin = true;
+                c_blk = s != n; c_blk2 = c_blk && (p0 >> 7) != (p1 >> 7);
             } else if (LDS_IMAGE) {
                 // image in LDS: no memory latency to hide and most extensions of a tiny index need both blocks,
                 // so both trips run back to back (measured 6 % faster than the one-trip-per-iteration form)
@@ -724,6 +736,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                 uint64_t Ap, Bp, As, Bs;
                 bool covered;
                 pgx_probe<LDS_IMAGE>(img, lds_blocks, lds_dir, lds_blow, pend ? p1 : p0, p1, !pend, cv, mrow, Ap, Bp, As, Bs, covered);
+                c_blk = c_blk2 = s != n; // a directory entry and a 64-byte block per trip
                 if (!pend) {
                     A0 = (pos_t)Ap; B0 = (pos_t)Bp;
                     A1 = (pos_t)As; dB = (pos_t)(Bs - Bp);
@@ -787,15 +800,17 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                 if (restart) begin(); // next start position of this read (or the read is finished / handed on)
             }
         }
+        if (!LDS_IMAGE) ln_blk += (unsigned long long)(__popcll(__ballot(c_blk)) + __popcll(__ballot(c_blk2)));
     }
-    if (NARROW && __any(ovf) && lane == 0) n_ext_total[9] = 1;
+    if (NARROW && __any(ovf) && lane == 0) n_ext_total[PGX_CTR_OVF32] = 1;
     // one atomic per wave for the extension counter
     unsigned long long tot = next;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
-    if (lane == 0 && tot) atomicAdd(n_ext_total, tot);
-#ifdef PGX_FM_STATS // wave trips, live lane-trips, longest wave (slots 3, 6, 7 of the counters; stats runs are made without tags)
-    if (lane == 0) { atomicAdd(n_ext_total + 6, st_trips); atomicAdd(n_ext_total + 7, st_live); atomicMax(n_ext_total + 3, st_trips); }
+    if (lane == 0 && tot) atomicAdd(n_ext_total + PGX_CTR_EXT, tot);
+    if (lane == 0 && ln_blk && !LDS_IMAGE) { atomicAdd(n_ext_total + PGX_CTR_FM_LINES, ln_blk); atomicAdd(n_ext_total + PGX_CTR_FM_SEEDS, ln_seed); }
+#ifdef PGX_FM_STATS // wave trips, live lane-trips, longest wave (stats runs are made without tags)
+    if (lane == 0) { atomicAdd(n_ext_total + PGX_CTR_ST_TRIPS, st_trips); atomicAdd(n_ext_total + PGX_CTR_ST_LIVE, st_live); atomicMax(n_ext_total + PGX_CTR_ST_LONGEST, st_trips); }
 #endif
 }
 
@@ -890,7 +905,7 @@ __device__ __forceinline__ uint32_t pgx_window_byte(uint64_t w0, uint64_t w1, ui
     return (uint32_t)(((a & 8ull) ? w1 : w0) >> (8u * (uint32_t)(a & 7ull))) & 0xFFu;
 }
 template <bool SEED>
-__global__ void __launch_bounds__(PGX_FM_THREADS, PGX_FM_WAVES_PER_SIMD) // (96 VGPRs: five waves per SIMD fit and are what the launch uses; four are as fast -- 20.7 against 20.6-21.0 ms at chr22 scale --, three 21.8)
+__global__ void __launch_bounds__(PGX_FM_THREADS, PGX_FM_WAVES_PER_SIMD) // (<= 96 VGPRs: five waves per SIMD fit and are what the launch uses; four are as fast -- 20.7 against 20.6-21.0 ms at chr22 scale --, three 21.8)
 pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                            uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
                            pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
@@ -915,7 +930,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     const uint32_t mo = min_occ > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)min_occ; // sizes are below 2^32: a larger min_occ makes everything "small" either way
     const bool mo_huge = min_occ > 0xFFFFFFFFull;
     uint32_t rid = 0; // (the launch serves fewer than 2^32 reads: pgx_batch_run)
-    uint64_t base = 0, slot = 0;
+    uint64_t base = 0;
     int32_t len = 0, x = 0, j = 0;
     uint32_t k = 0, kp = 0, s = 0, Jk = 0, Js = 0;
     uint32_t nm = 0, next = 0, next0 = 0, nextb = 0; // nextb: value of `next` when the current start position was begun
@@ -926,8 +941,9 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     uint32_t pend = 0, fresh = 0, restart = 0;
     uint64_t rnext = 0, rend = 0;
     bool exhausted = false;
+    unsigned long long ln_blk = 0, ln_seed = 0; // wave-uniform (scalar registers): block lines / seed entries the wave asked for (PGX_CTR_PAIRS_*)
 #ifdef PGX_FM_STATS
-    unsigned long long st_trips = 0, st_live = 0, st_two = 0, st_wait = 0, st_fresh = 0; // diagnostics build only (scripts/fm_stats.sh)
+    unsigned long long st_trips = 0, st_live = 0, st_wait = 0, st_fresh = 0; // diagnostics build only (scripts/fm_stats.sh)
 #endif
 
     auto begin = [&]() __attribute__((always_inline)) {
@@ -950,6 +966,8 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     auto emit = [&]() __attribute__((always_inline)) {
         pgx_mem m;
         m.start = (uint64_t)x; m.end = (uint64_t)j; m.bwt_start = (uint64_t)Jk; m.size = (int64_t)(uint64_t)Js;
+        // (the worst-case offset of the read is looked up only by a fifth MEM: the first PGX_FAST_SLOTS have their own line)
+        const uint64_t slot = nm < PGX_FAST_SLOTS ? 0ull : slot_off[rid] - slot_base;
         slots[pgx_slot_index((uint64_t)rid - first_read, n_reads - first_read, slot, nm)] = m;
         nm++;
         k = 0; kp = 0; s = n;
@@ -981,7 +999,6 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 else {
                     base = offsets[rid];
                     len = (int32_t)(offsets[rid + 1] - base);
-                    slot = slot_off[rid] - slot_base;
                     x = 0; nm = 0;
                     next0 = next;
                     begin();
@@ -1002,6 +1019,11 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         st_live += (unsigned long long)__popcll(__ballot(ph > 0));
         st_fresh += (unsigned long long)__popcll(__ballot(ph > 0 && fresh != 0u));
 #endif
+        // what the wave asks of the memory system in this trip (wave-uniform sums in scalar registers): a live lane fetches one block line, except in a
+        // stage's first trip, which reads block 0 like every other such lane and takes its result from first_ext / the seed table
+        // (seed / end table entries: one per first trip -- an upper bound: a stage with fewer than K extensions to go reads the shared entry 0)
+        ln_blk += (unsigned long long)__popcll(__ballot(ph > 0 && fresh == 0u));
+        if (SEED) ln_seed += (unsigned long long)__popcll(__ballot(ph > 0 && fresh != 0u));
         if (ph > 0) {
             const bool fr = fresh != 0u; // first extension of a backward stage: from first_ext / the seed table
             bool seed_lane = false;
@@ -1126,9 +1148,6 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                     j = fwd ? j + 1 : j - 1;
                 }
                 next += do2 ? 2u : 1u;
-#ifdef PGX_FM_STATS
-                st_two += do2 ? 1ull : 0ull;
-#endif
                 s = ns;
                 k = fwd ? nq : nk;
                 kp = fwd ? nk : nq;
@@ -1164,11 +1183,12 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     unsigned long long tot = next;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
-    if (lane == 0 && tot) atomicAdd(n_ext_total, tot);
-#ifdef PGX_FM_STATS // slots 2, 4 wave trips / live lane-trips, 13, 14, 15 lane-trips with two extensions / waiting for the second block / fresh
+    if (lane == 0 && tot) atomicAdd(n_ext_total + PGX_CTR_EXT, tot);
+    if (lane == 0 && ln_blk) { atomicAdd(n_ext_total + PGX_CTR_PAIRS_LINES, ln_blk); atomicAdd(n_ext_total + PGX_CTR_PAIRS_SEEDS, ln_seed); }
+#ifdef PGX_FM_STATS // wave trips / live lane-trips, lane-trips waiting for the second block / fresh
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { st_two += __shfl_down(st_two, off, 64); st_wait += __shfl_down(st_wait, off, 64); }
-    if (lane == 0) { atomicAdd(n_ext_total + 2, st_trips); atomicAdd(n_ext_total + 4, st_live); atomicAdd(n_ext_total + 13, st_two); atomicAdd(n_ext_total + 14, st_wait); atomicAdd(n_ext_total + 15, st_fresh); }
+    for (int off = 32; off > 0; off >>= 1) st_wait += __shfl_down(st_wait, off, 64);
+    if (lane == 0) { atomicAdd(n_ext_total + PGX_CTR_ST_PAIR_TRIPS, st_trips); atomicAdd(n_ext_total + PGX_CTR_ST_PAIR_LIVE, st_live); atomicAdd(n_ext_total + PGX_CTR_ST_PAIR_WAIT, st_wait); atomicAdd(n_ext_total + PGX_CTR_ST_PAIR_FRESH, st_fresh); }
 #endif
 }
 template __global__ void pgx_find_mems_pairs_kernel<false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t, const uint64_t *, pgx_mem *,

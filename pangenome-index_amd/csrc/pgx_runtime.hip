@@ -270,8 +270,8 @@ void pgx_scan_u64(const uint64_t *in, uint64_t n, uint64_t *out, uint64_t *tmp, 
 // copy a staged, blocking transfer) -> caller.  One buffer per host thread.
 static void read_scalars(void *dst, const void *dptr, size_t bytes, hipStream_t s) {
     static thread_local void *pin = nullptr;
-    if (!pin) HIPCHECK(hipHostMalloc(&pin, 256, hipHostMallocPortable));
-    if (bytes > 256) throw Error(PGX_ERR_ARG, "read_scalars: too many bytes");
+    if (!pin) HIPCHECK(hipHostMalloc(&pin, 512, hipHostMallocPortable));
+    if (bytes > 512) throw Error(PGX_ERR_ARG, "read_scalars: too many bytes");
     HIPCHECK(hipMemcpyAsync(pin, dptr, bytes, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
     std::memcpy(dst, pin, bytes);
@@ -886,7 +886,7 @@ struct pgx_batch {
     // host copies
     HostBuf h_mem_off, h_mems, h_run_nums, h_pos_off, h_positions;
     // timing
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // [8]: behind the first find_mems launch
     bool timed = false;
     pgx_timing timing{};
 };
@@ -1001,11 +1001,10 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     for (int pass = 0;; pass++) {
     b->n_mems = b->n_positions = b->n_ext = b->n_tag_overflow = 0;
     std::memset(&b->timing, 0, sizeof b->timing);
-    b->counters.ensure(256); // [0] extensions [1] tag overflows [5] read cursor [3,6,7] stats builds [8] heavy reads [9] 32-bit overflow
-                             // [10] MEMs [16..24] tag stage (tag_pipeline) [30] abort flag of a speculative run
-    HIPCHECK(hipMemsetAsync(b->counters.p, 0, 256, s));
+    b->counters.ensure(PGX_CTR_SLOTS * 8); // layout: PgxCounterSlot (pgx_device.h)
+    HIPCHECK(hipMemsetAsync(b->counters.p, 0, PGX_CTR_SLOTS * 8, s));
     unsigned long long *d_next = b->counters.as<unsigned long long>();
-    unsigned long long *d_nover = d_next + 1;
+    unsigned long long *d_nover = d_next + PGX_CTR_TAG_OVERFLOW;
 
     record(b, 0, s);
     // 1. worst-case MEM slots per read: cap = min(len, len - min_len + 1).  The slot buffer is bounded by
@@ -1049,7 +1048,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     for (auto &c : chunks) max_chunk_reads = std::max(max_chunk_reads, c.r1 - c.r0);
     b->slots.ensure((max_slots + 4 * max_chunk_reads) * sizeof(pgx_mem)); // 4 = PGX_FAST_SLOTS (pgx_kernels.hip pgx_slot_index): dense array of the first MEMs + worst-case region
     // 2. the hot kernel, 3. CSR offsets + compaction (per chunk)
-    float ms_fm = 0, ms_cp = 0;
+    float ms_fm = 0, ms_cp = 0, ms_main = 0;
     uint64_t mem_base = 0;
     int occ = 0, cus = 0;
     const void *kfn = nullptr, *kfn_wide = nullptr, *kfn_pairs = nullptr;
@@ -1090,20 +1089,20 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     }
     uint32_t heavy_ext = PGX_FM_HEAVY_EXT; // extensions on one read before its rest goes to the heavy-read kernel (0 = never)
     if (const char *e = std::getenv("PGX_FM_HEAVY_EXT")) heavy_ext = (uint32_t)std::strtoul(e, nullptr, 10);
-    unsigned long long *d_heavy_count = d_next + 8;
+    unsigned long long *d_heavy_count = d_next + PGX_CTR_HEAVY;
     if (heavy_ext) {
         b->heavy_list.ensure((size_t)PGX_FM_HEAVY_CAP * sizeof(pgx_heavy_item));
         b->heavy_scratch.ensure((size_t)PGX_FM_HEAVY_GRID * PGX_FM_HEAVY_MAXLEN * sizeof(PgxHeavyResult));
     }
-    unsigned long long *d_cursor = d_next + 5; // counters layout: see the allocation above
-    unsigned long long *d_redo_count = d_next + 11, *d_redo_cursor = d_next + 12;
+    unsigned long long *d_cursor = d_next + PGX_CTR_CURSOR;
+    unsigned long long *d_redo_count = d_next + PGX_CTR_REDO, *d_redo_cursor = d_next + PGX_CTR_REDO_CURSOR;
     if (kfn_pairs) b->redo_list.ensure((n ? n : 1) * sizeof(pgx_heavy_item));
     const char *spec_env = std::getenv("PGX_SPEC");
     const bool spec = pass == 0 && chunks.size() == 1 && b->shape_valid && b->shape_reads == n && b->shape_min_len == min_len && b->shape_min_occ == min_occ &&
                       b->shape_tags == want_tags && (!want_tags || (b->tw.have_last && b->tw.last_largest <= PGX_SORT_WG_LDS_CAP)) &&
                       !(spec_env && spec_env[0] == '0') && !std::getenv("PGX_FM_NARROW_FORCE_REDO");
     const uint64_t cm_cap = with_slack(b->last_mems);
-    uint64_t *d_abort = reinterpret_cast<uint64_t *>(d_next + 30);
+    uint64_t *d_abort = reinterpret_cast<uint64_t *>(d_next + PGX_CTR_ABORT);
     for (size_t ci = 0; ci < chunks.size(); ci++) {
         const pgx_chunk &c = chunks[ci];
         const uint64_t cn = c.r1 - c.r0;
@@ -1121,8 +1120,8 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         uint64_t cm = 0;
         const void *kf = kfn;
         for (int attempt = 0;; attempt++) {
-            // per-chunk counters: [0] extensions [5] cursor [8] heavy reads [9] 32-bit overflow flag [10] MEMs of the chunk
-            if (ci || attempt) HIPCHECK(hipMemsetAsync(d_next, 0, 128, s));
+            // per-chunk counters (slots below PGX_CTR_TAG0): extensions, cursors, heavy reads, 32-bit overflow flag, MEMs of the chunk
+            if (ci || attempt) HIPCHECK(hipMemsetAsync(d_next, 0, PGX_CTR_TAG0 * 8, s));
             const uint8_t *a_reads = b->reads.as<uint8_t>();
             const uint64_t *a_off = b->offsets.as<uint64_t>(), *a_slot_off = b->slot_off.as<uint64_t>();
             uint64_t a_n = c.r1, a_min_len = min_len, a_min_occ = min_occ, a_base = c.slot_base, a_first = c.r0;
@@ -1174,7 +1173,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                     HIPCHECK(hipStreamWaitEvent(b->side, b->ev_side[0], 0));
                     const pgx_heavy_item *s_list = b->side_list.as<pgx_heavy_item>();
                     const unsigned long long *s_count = b->side_count.as<unsigned long long>();
-                    unsigned long long *s_cur = d_next + 13;
+                    unsigned long long *s_cur = d_next + PGX_CTR_SIDE_CURSOR;
                     void *sargs[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &s_cur, &a_first, &a_base,
                                      &a_hext, &a_hcap, &a_hlist, &a_hcount, &s_list, &s_count};
                     HIPCHECK(hipLaunchKernel(kf, dim3(std::min<unsigned>(grid, (unsigned)cus)), dim3(PGX_FM_THREADS), sargs, b->dimg->lds_bytes, b->side));
@@ -1187,6 +1186,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                 void *pargs[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_first, &a_base,
                                  &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_redo, &a_redo_n, &a_skip};
                 HIPCHECK(hipLaunchKernel(kfn_pairs, dim3(grid), dim3(PGX_FM_THREADS), pargs, pairs_lds, s));
+                record(b, 8, s);
                 a_rlist = a_redo; a_rcount = d_redo_count; a_cur = d_redo_cursor;
                 // the few reads handed on have the device to themselves: the launch lasts as long as its longest read, and a read that ends a
                 // sequence (the usual reason to be here) runs until the heavy-read threshold: a quarter of it (chr22 scale: 21.2 -> 20.7 ms)
@@ -1197,6 +1197,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             void *args[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_first, &a_base,
                             &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_rlist, &a_rcount};
             HIPCHECK(hipLaunchKernel(kf, dim3(grid), dim3(PGX_FM_THREADS), args, b->dimg->lds_bytes, s)); // one of the variants
+            if (!kfn_pairs) record(b, 8, s);
             if (side_running) HIPCHECK(hipStreamWaitEvent(s, b->ev_side[1], 0)); // the other stream's reads are done (they may have queued heavy reads)
             if (heavy_ext) { // the rest of reads that spent heavy_ext extensions (usually none: the launch then costs a few microseconds)
                 if (b->dimg->lds_bytes)
@@ -1211,16 +1212,16 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             HIPCHECK(hipGetLastError());
             b->timing.find_mems_launches++;
             record(b, 2, s);
-            scan_excl(0, b->mem_count.as<uint32_t>() + c.r0, cn, 0, local, b->scan_tmp, s, reinterpret_cast<uint64_t *>(d_next + 10));
+            scan_excl(0, b->mem_count.as<uint32_t>() + c.r0, cn, 0, local, b->scan_tmp, s, reinterpret_cast<uint64_t *>(d_next + PGX_CTR_MEMS));
             if (spec) { cm = cm_cap; break; } // nothing is read back: the MEM total stays on the device
             unsigned long long cc[12];
             read_scalars(cc, d_next, sizeof cc, s);
             const bool forced = attempt == 0 && kf != kfn_wide && std::getenv("PGX_FM_NARROW_FORCE_REDO") != nullptr; // tests
-            if ((cc[9] || forced) && kf != kfn_wide) { kf = kfn_wide; continue; } // a coordinate left 32 bits: repeat the chunk in 64 bits
-            n_ext_host += cc[0];
-            b->timing.heavy_reads += (uint32_t)std::min<unsigned long long>(cc[8], PGX_FM_HEAVY_CAP);
-            b->timing.redo_reads += (uint32_t)cc[11];
-            cm = cc[10];
+            if ((cc[PGX_CTR_OVF32] || forced) && kf != kfn_wide) { kf = kfn_wide; continue; } // a coordinate left 32 bits: repeat the chunk in 64 bits
+            n_ext_host += cc[PGX_CTR_EXT];
+            b->timing.heavy_reads += (uint32_t)std::min<unsigned long long>(cc[PGX_CTR_HEAVY], PGX_FM_HEAVY_CAP);
+            b->timing.redo_reads += (uint32_t)cc[PGX_CTR_REDO];
+            cm = cc[PGX_CTR_MEMS];
             break;
         }
         b->mems.ensure_keep((mem_base + cm ? mem_base + cm : 1) * sizeof(pgx_mem), mem_base * sizeof(pgx_mem));
@@ -1232,14 +1233,16 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         mem_base += cm;
         if (b->timed && chunks.size() > 1) { // events are reused per chunk: accumulate now
             HIPCHECK(hipStreamSynchronize(s));
-            float t1 = 0, t2 = 0;
+            float t1 = 0, t2 = 0, t3 = 0;
             HIPCHECK(hipEventElapsedTime(&t1, b->ev[1], b->ev[2]));
             HIPCHECK(hipEventElapsedTime(&t2, b->ev[2], b->ev[3]));
-            ms_fm += t1; ms_cp += t2;
+            HIPCHECK(hipEventElapsedTime(&t3, b->ev[1], b->ev[8]));
+            ms_fm += t1; ms_cp += t2; ms_main += t3;
         }
     }
     b->n_mems = mem_base;
     b->timing.pairs_reads = kfn_pairs ? 1u : 0u;
+    b->timing.seed_depth = (img.seed_k != 0 && min_len >= img.seed_k && img.dense) ? img.seed_k : 0u;
     if (chunks.size() != 1) { // global CSR offsets (a single chunk's local offsets already are global)
         if (chunks.empty()) { record(b, 1, s); record(b, 2, s); }
         scan_excl(0, b->mem_count.p, n, 0, b->mem_off.as<uint64_t>(), b->scan_tmp, s);
@@ -1249,44 +1252,55 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     record(b, 3, s);
     // 4. tag queries (find_mems.cpp:129)
     if (want_tags) {
-        unsigned long long *d_nbig = d_next + 16;
+        unsigned long long *d_nbig = d_next + PGX_CTR_TAG0;
         tag_pipeline(img, b->mems.as<pgx_mem>(), nullptr, nullptr, b->n_mems, b->tw, d_nover, d_nbig, s,
-                     [&](int stage) { record(b, 4 + stage, s); }, spec, reinterpret_cast<const uint64_t *>(d_next + 10), d_abort);
+                     [&](int stage) { record(b, 4 + stage, s); }, spec, reinterpret_cast<const uint64_t *>(d_next + PGX_CTR_MEMS), d_abort);
         b->n_positions = b->tw.n_positions;
         b->ran_tags = true;
     }
     record(b, 7, s);
-    unsigned long long cnt[32];
+    unsigned long long cnt[PGX_CTR_SLOTS];
     read_scalars(cnt, b->counters.p, sizeof cnt, s);
     if (spec) {
         b->spec_runs++;
-        if (cnt[30] || cnt[9] || cnt[10] > cm_cap) { b->spec_fallbacks++; b->ran_tags = false; continue; } // a capacity was too small: once more, exactly
-        b->n_mems = cnt[10];
-        n_ext_host = cnt[0];
-        b->timing.heavy_reads = (uint32_t)std::min<unsigned long long>(cnt[8], PGX_FM_HEAVY_CAP);
-        b->timing.redo_reads = (uint32_t)cnt[11];
+        if (cnt[PGX_CTR_ABORT] || cnt[PGX_CTR_OVF32] || cnt[PGX_CTR_MEMS] > cm_cap) { b->spec_fallbacks++; b->ran_tags = false; continue; } // a capacity was too small: once more, exactly
+        b->n_mems = cnt[PGX_CTR_MEMS];
+        n_ext_host = cnt[PGX_CTR_EXT];
+        b->timing.heavy_reads = (uint32_t)std::min<unsigned long long>(cnt[PGX_CTR_HEAVY], PGX_FM_HEAVY_CAP);
+        b->timing.redo_reads = (uint32_t)cnt[PGX_CTR_REDO];
         if (want_tags) {
             TagWork &w = b->tw;
-            w.last_big = cnt[16]; w.last_large = cnt[17]; w.last_largest = cnt[18]; w.last_G = cnt[19]; w.last_small = cnt[21];
-            w.last_rep = cnt[22]; w.last_dup = cnt[23]; w.last_P = cnt[24];
-            w.n_positions = cnt[24];
-            b->n_positions = cnt[24];
+            const unsigned long long *tc = cnt + PGX_CTR_TAG0; // (scalars of tag_pipeline)
+            w.last_big = tc[0]; w.last_large = tc[1]; w.last_largest = tc[2]; w.last_G = tc[3]; w.last_small = tc[5];
+            w.last_rep = tc[6]; w.last_dup = tc[7]; w.last_P = tc[8];
+            w.n_positions = tc[8];
+            b->n_positions = tc[8];
         }
     }
+    // the kernels' own traffic counters (accumulated over the chunks of the run)
+    if (kfn_pairs) {
+        b->timing.main_lines = cnt[PGX_CTR_PAIRS_LINES]; b->timing.main_seed_loads = cnt[PGX_CTR_PAIRS_SEEDS];
+        b->timing.other_lines = cnt[PGX_CTR_FM_LINES]; b->timing.other_seed_loads = cnt[PGX_CTR_FM_SEEDS];
+        b->timing.two_step_trips = cnt[PGX_CTR_PAIRS_TWO];
+    } else { b->timing.main_lines = cnt[PGX_CTR_FM_LINES]; b->timing.main_seed_loads = cnt[PGX_CTR_FM_SEEDS]; }
     b->last_mems = b->n_mems;
     b->shape_valid = true; b->shape_reads = n; b->shape_min_len = min_len; b->shape_min_occ = min_occ; b->shape_tags = want_tags;
-    if (cnt[6] && std::getenv("PGX_FM_STATS")) // only a -DPGX_FM_STATS build of the kernels fills these (scripts/fm_stats.sh)
-        std::fprintf(stderr, "[pgx] find_mems wave trips %llu, live lane-trips %llu (%.1f%% of lanes), longest wave %llu trips, extensions %llu\n", cnt[6], cnt[7],
-                     100.0 * (double)cnt[7] / (64.0 * (double)cnt[6]), cnt[3], cnt[0]);
-    if (cnt[2] && std::getenv("PGX_FM_STATS"))
+    if (cnt[PGX_CTR_ST_TRIPS] && std::getenv("PGX_FM_STATS")) // only a -DPGX_FM_STATS build of the kernels fills these (scripts/fm_stats.sh)
+        std::fprintf(stderr, "[pgx] find_mems wave trips %llu, live lane-trips %llu (%.1f%% of lanes), longest wave %llu trips, extensions %llu\n", cnt[PGX_CTR_ST_TRIPS],
+                     cnt[PGX_CTR_ST_LIVE], 100.0 * (double)cnt[PGX_CTR_ST_LIVE] / (64.0 * (double)cnt[PGX_CTR_ST_TRIPS]), cnt[PGX_CTR_ST_LONGEST], cnt[PGX_CTR_EXT]);
+    if (cnt[PGX_CTR_ST_PAIR_TRIPS] && std::getenv("PGX_FM_STATS"))
         std::fprintf(stderr, "[pgx] pairs kernel wave trips %llu, live lane-trips %llu (%.1f%%), with two extensions %llu, waiting for a second block %llu, fresh %llu, reads handed on %llu\n",
-                     cnt[2], cnt[4], 100.0 * (double)cnt[4] / (64.0 * (double)cnt[2]), cnt[13], cnt[14], cnt[15], cnt[11]);
-    if (std::getenv("PGX_DEBUG_COUNTERS")) std::fprintf(stderr, "[pgx] counters %llu %llu %llu %llu %llu %llu %llu %llu %llu redo %llu\n", cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[6], cnt[7], cnt[8], cnt[11]);
+                     cnt[PGX_CTR_ST_PAIR_TRIPS], cnt[PGX_CTR_ST_PAIR_LIVE], 100.0 * (double)cnt[PGX_CTR_ST_PAIR_LIVE] / (64.0 * (double)cnt[PGX_CTR_ST_PAIR_TRIPS]),
+                     cnt[PGX_CTR_PAIRS_TWO], cnt[PGX_CTR_ST_PAIR_WAIT], cnt[PGX_CTR_ST_PAIR_FRESH], cnt[PGX_CTR_REDO]);
+    if (std::getenv("PGX_DEBUG_COUNTERS"))
+        std::fprintf(stderr, "[pgx] counters: extensions %llu tag overflows %llu heavy %llu redo %llu lines %llu + %llu seeds %llu + %llu\n", cnt[PGX_CTR_EXT], cnt[PGX_CTR_TAG_OVERFLOW],
+                     cnt[PGX_CTR_HEAVY], cnt[PGX_CTR_REDO], cnt[PGX_CTR_PAIRS_LINES], cnt[PGX_CTR_FM_LINES], cnt[PGX_CTR_PAIRS_SEEDS], cnt[PGX_CTR_FM_SEEDS]);
     b->n_ext = n_ext_host;
-    b->n_tag_overflow = cnt[1];
+    b->n_tag_overflow = cnt[PGX_CTR_TAG_OVERFLOW];
     if (b->timed) {
         auto el = [&](int a, int c) { float ms = 0; HIPCHECK(hipEventElapsedTime(&ms, b->ev[a], b->ev[c])); return ms; };
         b->timing.ms_find_mems = chunks.size() > 1 ? ms_fm : el(1, 2);
+        b->timing.ms_find_mems_main = chunks.size() > 1 ? ms_main : (n ? el(1, 8) : 0.0f);
         b->timing.ms_compact = chunks.size() > 1 ? ms_cp : el(2, 3);
         if (want_tags) {
             b->timing.ms_tag_locate = el(3, 4); // locate + scans

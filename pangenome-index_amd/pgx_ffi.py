@@ -67,6 +67,8 @@ class Timing(C.Structure):
         ("ms_find_mems", C.c_float), ("ms_compact", C.c_float), ("ms_tag_locate", C.c_float),
         ("ms_tag_gather", C.c_float), ("ms_tag_sort", C.c_float), ("ms_total", C.c_float),
         ("find_mems_launches", u32), ("heavy_reads", u32), ("pairs_reads", u32), ("redo_reads", u32),
+        ("ms_find_mems_main", C.c_float), ("seed_depth", u32),
+        ("main_lines", u64), ("main_seed_loads", u64), ("other_lines", u64), ("other_seed_loads", u64), ("two_step_trips", u64),
     ]
 
 
@@ -379,6 +381,33 @@ def find_mems_sharded(index, devices, reads_cat, offsets, min_len, min_occ, tags
 
 
 COMM_ID_BYTES = 128
+
+
+XCH_META_HEAD = 5
+XCH_MAX_OFFSET_BYTES = 4 << 30
+
+
+def exchange_owner_digest(owner_of_shard):
+    L = lib()
+    L.pgx_exchange_owner_digest.restype = u64
+    own = (u32 * max(len(owner_of_shard), 1))(*owner_of_shard)
+    return int(L.pgx_exchange_owner_digest(own, len(owner_of_shard)))
+
+
+def exchange_plan(world, owner_of_shard, gathered):
+    """pgx_exchange_plan (host only, no device): gathered = `world` metadata rows of XCH_META_HEAD + max_local u64 each.
+    Returns dict(max_local, slot, rec_base, src_base, n_reads)."""
+    L = lib()
+    n = len(owner_of_shard)
+    own = (u32 * max(n, 1))(*owner_of_shard)
+    g = np.ascontiguousarray(gathered, dtype=np.uint64).reshape(-1)
+    ml, nr = u32(0), u64(0)
+    slot = np.zeros(n, dtype=np.uint32)
+    rec_base = np.zeros(world + 1, dtype=np.uint64)
+    src_base = np.zeros(n, dtype=np.uint64)
+    _check(L.pgx_exchange_plan(u32(world), own, u32(n), C.c_void_p(g.ctypes.data), C.byref(ml), C.c_void_p(slot.ctypes.data),
+                               C.c_void_p(rec_base.ctypes.data), C.c_void_p(src_base.ctypes.data), C.byref(nr)))
+    return dict(max_local=int(ml.value), slot=slot, rec_base=rec_base, src_base=src_base, n_reads=int(nr.value))
 
 
 def comm_unique_id():

@@ -51,6 +51,73 @@ def test_lpt_assign():
     assert S.lpt_assign([5, 5], 4) == [[0], [1], [], []]
 
 
+def _meta_rows(world, owner, n_reads, mems_per_shard, status=None):
+    """what the metadata all-gather of pgx_exchange_mems delivers: one row per rank"""
+    import pgx_ffi as P
+
+    per_rank = [[c for c, o in enumerate(owner) if o == r] for r in range(world)]
+    ml = max(1, max(len(x) for x in per_rank))
+    rows = np.zeros((world, P.XCH_META_HEAD + ml), dtype=np.uint64)
+    for r in range(world):
+        rows[r, 0] = (status or {}).get(r, 0)
+        rows[r, 1] = n_reads if per_rank[r] else 0  # a rank without shards has searched nothing
+        rows[r, 2] = len(owner)
+        rows[r, 3] = P.exchange_owner_digest(owner)
+        rows[r, 4] = ml
+        for k, c in enumerate(per_rank[r]):
+            rows[r, P.XCH_META_HEAD + k] = mems_per_shard[c]
+    return rows, ml
+
+
+def test_exchange_plan_uneven_and_zero_shard_owners(built):
+    """the host-side plan of pgx_exchange_mems (slots, record bases) for ranks with different shard counts and ranks without shards:
+    the RCCL path with more than one rank cannot run on the one-GPU box, its arithmetic can"""
+    import pgx_ffi as P
+
+    owner = [2, 0, 2, 2, 0, 3]  # rank 1 owns nothing, rank 2 three shards, rank 0 two, rank 3 one
+    mems = [7, 0, 11, 5, 3, 2]
+    rows, ml = _meta_rows(4, owner, 1000, mems)
+    plan = P.exchange_plan(4, owner, rows)
+    assert plan["max_local"] == ml == 3 and plan["n_reads"] == 1000
+    # rank r's k-th shard (ascending shard id) sits in row r * max_local + k
+    assert list(plan["slot"]) == [2 * 3 + 0, 0 * 3 + 0, 2 * 3 + 1, 2 * 3 + 2, 0 * 3 + 1, 3 * 3 + 0]
+    # records: rank 0's (shards 1, 4), rank 1's (none), rank 2's (0, 2, 3), rank 3's (5)
+    assert list(plan["rec_base"]) == [0, 0 + 3, 3, 3 + 7 + 11 + 5, 26 + 2]
+    assert list(plan["src_base"]) == [3, 0, 3 + 7, 3 + 7 + 11, 0, 26]
+    # every rank computes the same plan from the same rows; a one-rank world is the degenerate case the GPU test runs
+    rows1, _ = _meta_rows(1, [0, 0, 0], 5, [1, 2, 3])
+    p1 = P.exchange_plan(1, [0, 0, 0], rows1)
+    assert list(p1["slot"]) == [0, 1, 2] and list(p1["src_base"]) == [0, 1, 3] and list(p1["rec_base"]) == [0, 6]
+
+
+def test_exchange_plan_failures_are_collective(built):
+    import pgx_ffi as P
+
+    owner = [0, 1, 1]
+    rows, _ = _meta_rows(2, owner, 10, [1, 1, 1], status={1: P.ERR_ARG})
+    with pytest.raises(P.PgxError) as e:  # one rank's local validation failed: every rank sees its status word and fails
+        P.exchange_plan(2, owner, rows)
+    assert "rank 1 reported status" in str(e.value)
+    rows, _ = _meta_rows(2, owner, 10, [1, 1, 1])
+    rows[1, 1] = 11
+    with pytest.raises(P.PgxError) as e:
+        P.exchange_plan(2, owner, rows)
+    assert "disagree on the number of reads" in str(e.value)
+    rows, _ = _meta_rows(2, owner, 10, [1, 1, 1])
+    rows[0, 3] ^= 1  # a rank that was handed another owner table
+    with pytest.raises(P.PgxError) as e:
+        P.exchange_plan(2, owner, rows)
+    assert "different owner_of_shard" in str(e.value)
+    # the gathered offsets are world x max_local x (n_reads + 1) u32: the caller must chunk its reads
+    big = P.XCH_MAX_OFFSET_BYTES // (2 * 2 * 4) + 1
+    rows, _ = _meta_rows(2, owner, big, [1, 1, 1])
+    with pytest.raises(P.PgxError) as e:
+        P.exchange_plan(2, owner, rows)
+    assert "in chunks" in str(e.value)
+    with pytest.raises(P.PgxError):
+        P.exchange_plan(2, [0, 5], np.zeros((2, 6), dtype=np.uint64))  # owner rank out of range
+
+
 def test_exchange_single_process(workdir):
     paths, cat, offs = _setup(workdir)
     indexes = [O.RIndex(p) for p in paths]
