@@ -44,6 +44,8 @@ typedef enum {
 #define PGX_MODE_IMAGE_DENSE2 0x400u /* two bit planes + exception runs, n / 3 bytes (384 symbols per 128-byte block; n < 2^32) */
 #define PGX_MODE_IMAGE_PAIRS 0x800u  /* dense2 + the two-step PAIRS image, 4 n / 3 bytes more (n < 2^32, textbook extension tables, few N runs);
                                       * by default a PAIRS image accompanies whichever dense layout is chosen, when the index qualifies */
+#define PGX_MODE_IMAGE_WIDE 0x1000u  /* modifier: the 64-bit form of dense2 / PAIRS (header counts as deltas against superblock bases, 64-bit
+                                      * kernels), automatic for BWTs of 2^32 symbols or more; alone it selects dense2 + PAIRS */
 #define PGX_MODE_MASK 0xFFu
 
 /* tag file formats (SURVEY section 5 "Tag formats") */
@@ -95,6 +97,8 @@ typedef struct {
     uint32_t image_kind;    /* 0 = run-length blocks + directory, 1 = dense bit planes (64 symbols per 64-byte block),
                              * 2 = dense2 (384 symbols per 128-byte block, two planes + exception runs) */
     uint32_t image_pairs;   /* 1 = a PAIRS image (two extensions per cache line) accompanies the dense / dense2 image */
+    uint32_t image_wide;    /* 1 = the 64-bit form of dense2 / PAIRS (BWTs of 2^32 symbols or more, or PGX_MODE_IMAGE_WIDE) */
+    uint32_t reserved_info;
 } pgx_index_info;
 
 const char *pgx_last_error(void);
@@ -128,7 +132,8 @@ pgx_status pgx_index_to_device(pgx_index *h, int device);
  * 14 locate constants (PgxLocConsts); 15 exception runs of the dense2 rank image (u32);
  * literal count image of an encoded index without N: 16 block starts (u64), 17 six cumulative counts per
  * block (u64), 18 runs as the reference's late scan sees them (u64: code << 56 | length), 19 first run of every block (u32);
- * two-step PAIRS image (pgx_image.h; empty without one): 20 blocks (32 dwords each), 21 ptab (8 dwords per special-run count). */
+ * two-step PAIRS image (pgx_image.h; empty without one): 20 blocks (32 dwords each);
+ * WIDE images: 22 superblock bases of the dense2 image (8 u64 each), 23 of the PAIRS image (24 u64 each). */
 pgx_status pgx_index_image_view(const pgx_index *h, int which, const void **ptr, uint64_t *bytes);
 
 /* ---- index construction (build side; CPU, run once) --------------------------------------- */
@@ -142,6 +147,11 @@ pgx_status pgx_build_rlbwt(const char *text_path, const char *out_rlbwt_path);
  * directly, so the sampling walk of FastLocate(std::string) (src/r-index.cpp:993-1130) is not repeated; the .ri written
  * is byte-identical to pgx_build_rlbwt + pgx_build_rindex. */
 pgx_status pgx_build_index_from_text(const char *text_path, const char *out_rlbwt_path, const char *out_ri_path, int encoded);
+/* The same for a collection handed over as several texts ("chromosomes"; their sequences in the order of the texts): one suffix array
+ * per text, built side by side, then a k-way merge of the sorted suffix lists split over host threads.  The files are byte-identical
+ * to what the single call writes for the concatenation; every text must stay below 2^31 symbols, the collection may have any size
+ * (the reference takes grlBWT's output of any size: FastLocate(std::string), src/r-index.cpp:778-1139). */
+pgx_status pgx_build_index_from_texts(const char *const *text_paths, uint32_t n_texts, const char *out_rlbwt_path, const char *out_ri_path, int encoded);
 /* Write a compact sdsl tag file (format 3, src/tag_arrays.cpp:940-974 + :622-654) from parallel
  * arrays of run values (already `offset | rev<<10 | node<<11`) and run lengths. */
 pgx_status pgx_write_compact_tags(const char *out_path, const uint64_t *values,

@@ -113,19 +113,21 @@ struct Sais {
 // convention of the reference's fixtures and of tests/test_rindex.cpp:35-60: rotations of the text
 // with distinct increasing terminators).  Output: grlBWT run file (u64 bytes/symbol = 1,
 // u64 bytes/length, then (symbol, length) records).
-// Suffix array of the collection (row 0 = the extra terminator, row p + 1 = BWT position p) and its BWT runs.
+// The BWT of a collection as the builders below hand it on: grlBWT-style maximal runs, and -- for the SA samples of the .ri -- the text
+// position of the suffix at the first and at the last BWT position of every LOGICAL run (every endmarker is a run of its own,
+// src/r-index.cpp:840-848), so that no suffix array has to outlive the merge that produced it.
 struct TextBwt {
-    std::vector<uint8_t> text;                        // newline-terminated
-    std::vector<int32_t> SA;                          // n + 1 entries
+    uint64_t n = 0;                                   // symbols of the collection (every sequence ends in \n)
+    std::vector<uint64_t> seq_start;                  // text position of every sequence
     std::vector<std::pair<uint8_t, uint64_t>> runs;   // grlBWT-style maximal runs (endmarkers not split)
+    std::vector<uint64_t> head, tail;                 // per logical run: text position of its first / last suffix
     uint64_t max_len = 1;
 };
-static void build_text_bwt(const char *text_path, TextBwt &o) {
-    o.text = read_whole_file(text_path);
-    std::vector<uint8_t> &text = o.text;
-    if (!text.empty() && text.back() != '\n') text.push_back('\n');
+
+// suffix array of one newline-terminated text (row 0 = the extra terminator, row p + 1 = the p-th suffix); endmarkers order by sequence
+static void suffix_array_of(const std::vector<uint8_t> &text, std::vector<int32_t> &SA) {
     const uint64_t n = text.size();
-    if (n + 1 >= (1ull << 31)) throw Error(PGX_ERR_UNSUPPORTED, "text longer than 2^31 - 2 symbols");
+    if (n + 1 >= (1ull << 31)) throw Error(PGX_ERR_UNSUPPORTED, "a text longer than 2^31 - 2 symbols (pass the collection as several texts: pgx_build_index_from_texts)");
     uint64_t m = 0;
     for (uint8_t c : text) m += (c == '\n');
     // alphabet: 0 = extra terminator, 1..m = endmarkers by sequence, then present bytes by value
@@ -136,19 +138,197 @@ static void build_text_bwt(const char *text_path, TextBwt &o) {
     for (int c = 0; c < 256; c++)
         if (present[c] && c != '\n') rank_of[c] = K++;
     std::vector<int32_t> s(n + 1);
-    o.SA.resize(n + 1);
+    SA.resize(n + 1);
     int32_t seq = 0;
     for (uint64_t i = 0; i < n; i++) s[i] = text[i] == '\n' ? ++seq : rank_of[text[i]];
     s[n] = 0;
-    Sais::run(s.data(), o.SA.data(), (int32_t)(n + 1), K);
-    s.clear();
-    s.shrink_to_fit();
-    for (uint64_t i = 1; i <= n; i++) { // SA[0] is the extra terminator
-        uint64_t p = (uint64_t)o.SA[i];
-        uint8_t c = p ? text[p - 1] : text[n - 1];
-        if (!o.runs.empty() && o.runs.back().first == c) { o.runs.back().second++; o.max_len = std::max(o.max_len, o.runs.back().second); }
-        else o.runs.emplace_back(c, 1);
+    Sais::run(s.data(), SA.data(), (int32_t)(n + 1), K);
+}
+
+// ---- the collection as several texts ("chromosomes"): one suffix array each, built side by side, then ONE k-way merge of the sorted
+// suffix lists, split over threads by sampled splitter suffixes.  A collection of any size builds this way as long as every text stays
+// below 2^31 symbols (FastLocate(std::string) takes grlBWT's output of any size, src/r-index.cpp:778-1139); the order is that of one
+// suffix array over the concatenation: symbols compare by byte value, an endmarker is smaller than any symbol, two endmarkers
+// compare by sequence number.
+namespace {
+struct Chunk {
+    std::vector<uint8_t> text; // newline-terminated, 8 bytes of padding behind it
+    std::vector<int32_t> SA;   // n + 1 entries, [0] = the extra terminator
+    uint64_t n = 0, base = 0;  // symbols, text position of its first symbol in the collection
+    std::vector<uint64_t> seq_start; // local
+    uint64_t seq_base = 0;
+};
+struct Suf { uint32_t c; uint64_t i; };
+
+static inline uint64_t load64(const uint8_t *p) { uint64_t v; std::memcpy(&v, p, 8); return v; }
+static inline uint64_t seq_of(const Chunk &c, uint64_t pos) {
+    return c.seq_base + (uint64_t)(std::upper_bound(c.seq_start.begin(), c.seq_start.end(), pos) - c.seq_start.begin()) - 1;
+}
+// suffix (a, i) < suffix (b, j) in the order of the collection
+static bool suffix_less(const Chunk &A, uint64_t i, const Chunk &B, uint64_t j) {
+    const uint8_t *a = A.text.data() + i, *b = B.text.data() + j;
+    for (uint64_t o = 0;; o += 8) {
+        const uint64_t wa = load64(a + o), wb = load64(b + o);
+        const uint64_t x = wa ^ wb, v = wa ^ 0x0A0A0A0A0A0A0A0Aull;
+        const uint64_t nl = (v - 0x0101010101010101ull) & ~v & 0x8080808080808080ull; // lowest set flag = first \n of wa
+        if (!x && !nl) continue;
+        const unsigned pd = x ? (unsigned)__builtin_ctzll(x) >> 3 : 8u, pn = nl ? (unsigned)__builtin_ctzll(nl) >> 3 : 8u;
+        if (pn < pd) { // equal up to and including an endmarker: the sequences' numbers decide
+            const uint64_t sa = seq_of(A, i + o + pn), sb = seq_of(B, j + o + pn);
+            return sa < sb;
+        }
+        return a[o + pd] < b[o + pd]; // (\n = 10 sorts below A C G N T as bytes)
     }
+}
+// the first 21 symbols of a suffix as one integer that orders like the suffix: 3 bits per symbol, nothing behind an endmarker
+static inline uint64_t suffix_key(const Chunk &C, uint64_t i) {
+    const uint8_t *p = C.text.data() + i;
+    uint64_t k = 0;
+    int d = 0;
+    for (; d < 21; d++) {
+        const uint8_t ch = p[d];
+        if (ch == '\n') break;
+        // A C G N T -> 1 2 3 4 5 (byte order)
+        const uint64_t v = ch == 'A' ? 1u : ch == 'C' ? 2u : ch == 'G' ? 3u : ch == 'N' ? 4u : ch == 'T' ? 5u : (ch < 'A' ? 1u : 6u);
+        k |= v << (60 - 3 * d);
+    }
+    return k;
+}
+} // namespace
+
+static void merge_chunks(std::vector<Chunk> &ch, TextBwt &o) {
+    const size_t C = ch.size();
+    uint64_t n = 0, n_seq = 0;
+    for (auto &c : ch) { c.base = n; c.seq_base = n_seq; n += c.n; n_seq += c.seq_start.size(); }
+    o.n = n;
+    o.seq_start.clear();
+    for (auto &c : ch) for (uint64_t v : c.seq_start) o.seq_start.push_back(c.base + v);
+    unsigned T = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 32u));
+    if (const char *e = std::getenv("PGX_BUILD_THREADS")) T = (unsigned)std::max<long>(1, std::min<long>(std::atol(e), 256));
+    if (n < (1u << 16)) T = std::min(T, 2u);
+    // splitters: T - 1 suffixes that cut the merged order into even parts -- candidates at even ranks of every chunk, sorted, every C-th taken
+    std::vector<Suf> cand;
+    for (uint32_t c = 0; c < C; c++)
+        for (unsigned t = 1; t < T; t++) cand.push_back({c, (uint64_t)ch[c].SA[1 + ch[c].n * t / T]});
+    std::sort(cand.begin(), cand.end(), [&](const Suf &a, const Suf &b) { return (a.c != b.c || a.i != b.i) && suffix_less(ch[a.c], a.i, ch[b.c], b.i); });
+    std::vector<Suf> split;
+    for (unsigned t = 1; t < T; t++) split.push_back(cand[(size_t)t * C - (C + 1) / 2]);
+    // lo[t][c] = first rank of chunk c that belongs to part t (suffixes >= splitter t - 1)
+    std::vector<std::vector<uint64_t>> lo(T + 1, std::vector<uint64_t>(C, 0));
+    for (uint32_t c = 0; c < C; c++) {
+        lo[T][c] = ch[c].n;
+        for (unsigned t = 1; t < T; t++) {
+            const Suf &sp = split[t - 1];
+            uint64_t a = 0, b = ch[c].n; // first rank whose suffix is not smaller than the splitter
+            while (a < b) {
+                const uint64_t mid = (a + b) >> 1, pos = (uint64_t)ch[c].SA[1 + mid];
+                const bool less = (c == sp.c && pos == sp.i) ? false : suffix_less(ch[c], pos, ch[sp.c], sp.i);
+                if (less) a = mid + 1; else b = mid;
+            }
+            lo[t][c] = a;
+        }
+        for (unsigned t = 1; t <= T; t++) lo[t][c] = std::max(lo[t][c], lo[t - 1][c]); // (equal candidates: keep the parts nested)
+    }
+    struct Part { std::vector<uint8_t> sym; std::vector<uint64_t> len, head, tail; };
+    std::vector<Part> parts(T);
+    std::vector<std::thread> th;
+    std::exception_ptr err;
+    std::mutex mu;
+    for (unsigned t = 0; t < T; t++)
+        th.emplace_back([&, t]() {
+            try {
+                Part &P = parts[t];
+                std::vector<uint64_t> at(C), end(C), key(C), pos(C);
+                std::vector<uint8_t> live(C, 0);
+                auto load = [&](size_t c) {
+                    if (at[c] < end[c]) {
+                        pos[c] = (uint64_t)ch[c].SA[1 + at[c]];
+                        key[c] = C > 1 ? suffix_key(ch[c], pos[c]) : 0; // (a single text: nothing to compare)
+                        live[c] = 1;
+                        if (at[c] + 16 < end[c]) __builtin_prefetch(ch[c].text.data() + (uint64_t)ch[c].SA[1 + at[c] + 16]);
+                    } else live[c] = 0;
+                };
+                for (size_t c = 0; c < C; c++) { at[c] = lo[t][c]; end[c] = lo[t + 1][c]; load(c); }
+                for (;;) {
+                    int best = -1;
+                    for (size_t c = 0; c < C; c++) {
+                        if (!live[c]) continue;
+                        if (best < 0 || key[c] < key[(size_t)best] ||
+                            (key[c] == key[(size_t)best] && suffix_less(ch[c], pos[c], ch[(size_t)best], pos[(size_t)best])))
+                            best = (int)c;
+                    }
+                    if (best < 0) break;
+                    const Chunk &K = ch[(size_t)best];
+                    const uint64_t i = pos[(size_t)best], g = K.base + i;
+                    const uint8_t sym = i ? K.text[i - 1] : (uint8_t)'\n'; // the symbol before a text is the endmarker of the sequence before it
+                    if (!P.sym.empty() && P.sym.back() == sym && sym != '\n') { P.len.back()++; P.tail.back() = g; }
+                    else { P.sym.push_back(sym); P.len.push_back(1); P.head.push_back(g); P.tail.push_back(g); }
+                    at[(size_t)best]++;
+                    load((size_t)best);
+                }
+            } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
+        });
+    for (auto &x : th) x.join();
+    if (err) std::rethrow_exception(err);
+    // stitch the parts: a logical run that continues over a part border is one run
+    uint64_t R = 0;
+    for (auto &P : parts) R += P.sym.size();
+    o.runs.clear(); o.head.clear(); o.tail.clear();
+    o.head.reserve(R); o.tail.reserve(R);
+    uint8_t last_sym = 0;
+    bool have = false;
+    for (auto &P : parts) {
+        for (size_t r = 0; r < P.sym.size(); r++) {
+            const uint8_t sym = P.sym[r];
+            if (have && last_sym == sym && sym != '\n') { // continues the previous logical (and file) run
+                o.runs.back().second += P.len[r];
+                o.tail.back() = P.tail[r];
+            } else {
+                if (have && last_sym == sym) o.runs.back().second += P.len[r]; // endmarkers: one file run, a logical run each
+                else o.runs.emplace_back(sym, P.len[r]);
+                o.head.push_back(P.head[r]);
+                o.tail.push_back(P.tail[r]);
+            }
+            o.max_len = std::max(o.max_len, o.runs.back().second);
+            last_sym = sym; have = true;
+        }
+        Part().sym.swap(P.sym); std::vector<uint64_t>().swap(P.len); std::vector<uint64_t>().swap(P.head); std::vector<uint64_t>().swap(P.tail);
+    }
+}
+
+static void load_chunk(const char *path, Chunk &c) {
+    c.text = read_whole_file(path);
+    if (!c.text.empty() && c.text.back() != '\n') c.text.push_back('\n');
+    c.n = c.text.size();
+    if (c.n == 0) throw Error(PGX_ERR_FORMAT, std::string("empty text: ") + path);
+    c.seq_start.clear();
+    c.seq_start.push_back(0);
+    for (uint64_t i = 0; i + 1 < c.n; i++)
+        if (c.text[i] == '\n') c.seq_start.push_back(i + 1);
+    c.text.resize(c.n + 8, 0); // the 8-byte loads of suffix_less stop at the final endmarker, inside the padding at the latest
+}
+
+static void build_texts_bwt(const char *const *text_paths, uint32_t n_texts, TextBwt &o) {
+    std::vector<Chunk> ch(n_texts);
+    std::vector<std::thread> th;
+    std::exception_ptr err;
+    std::mutex mu;
+    for (uint32_t c = 0; c < n_texts; c++)
+        th.emplace_back([&, c]() {
+            try {
+                load_chunk(text_paths[c], ch[c]);
+                std::vector<uint8_t> bare(ch[c].text.begin(), ch[c].text.begin() + (std::ptrdiff_t)ch[c].n);
+                suffix_array_of(bare, ch[c].SA);
+            } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
+        });
+    for (auto &x : th) x.join();
+    if (err) std::rethrow_exception(err);
+    merge_chunks(ch, o);
+}
+
+static void build_text_bwt(const char *text_path, TextBwt &o) {
+    const char *one[1] = {text_path};
+    build_texts_bwt(one, 1, o);
 }
 static void write_rlbwt(const char *out_rlbwt_path, const TextBwt &b) {
     uint64_t bl = 1;
@@ -260,18 +440,14 @@ static void build_rindex_core(const std::vector<std::pair<uint8_t, uint64_t>> &f
     uint64_t max_length = 1; // Header(): max_length(1)
     if (tb) {
         // sequence starts in the text; an endmarker belongs to its sequence (offset = length)
-        std::vector<uint64_t> seq_start;
-        seq_start.push_back(0);
-        for (uint64_t i = 0; i + 1 < tb->text.size(); i++)
-            if (tb->text[i] == '\n') seq_start.push_back(i + 1);
-        if (seq_start.size() != n_seq || tb->text.size() != n) throw Error(PGX_ERR_FORMAT, "suffix array and BWT runs disagree");
+        const std::vector<uint64_t> &seq_start = tb->seq_start;
+        const uint64_t R = run_start.size();
+        if (seq_start.size() != n_seq || tb->n != n || tb->head.size() != R || tb->tail.size() != R) throw Error(PGX_ERR_FORMAT, "suffix samples and BWT runs disagree");
         for (uint64_t i = 0; i < n_seq; i++) max_length = std::max(max_length, (i + 1 < n_seq ? seq_start[i + 1] : n) - seq_start[i]);
-        auto sample_at = [&](uint64_t p, uint64_t r) { // BWT position p = suffix SA[p + 1]
-            const uint64_t t = (uint64_t)tb->SA[p + 1];
+        auto sample_of = [&](uint64_t t, uint64_t r) { // text position t of a suffix -> (sequence, offset)
             const uint64_t q = (uint64_t)(std::upper_bound(seq_start.begin(), seq_start.end(), t) - seq_start.begin()) - 1;
             return Sample{q, t - seq_start[q], r};
         };
-        const uint64_t R = run_start.size();
         heads.resize(R);
         tails.resize(R);
         unsigned nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 16u));
@@ -279,13 +455,14 @@ static void build_rindex_core(const std::vector<std::pair<uint8_t, uint64_t>> &f
         for (unsigned t = 0; t < nt; t++)
             th.emplace_back([&, t]() {
                 for (uint64_t r = R * t / nt; r < R * (t + 1) / nt; r++) {
-                    heads[r] = sample_at(run_start[r], r);
-                    tails[r] = sample_at(run_start[r] + run_len(r) - 1, r);
+                    heads[r] = sample_of(tb->head[r], r);
+                    tails[r] = sample_of(tb->tail[r], r);
                 }
             });
         for (auto &t : th) t.join();
-        // the reference's walk also records a tail at BWT position n_seq - 1 whether or not a run ends there (:1036)
-        if (n_seq && run_start[run_of(n_seq - 1)] + run_len(run_of(n_seq - 1)) - 1 != n_seq - 1) tails.push_back(sample_at(n_seq - 1, run_of(n_seq - 1)));
+        // the reference's walk also records a tail at BWT position n_seq - 1 whether or not a run ends there (:1036); the first n_seq BWT
+        // positions are the endmarker suffixes in sequence order, so that suffix is the endmarker of the last sequence
+        if (n_seq && run_start[run_of(n_seq - 1)] + run_len(run_of(n_seq - 1)) - 1 != n_seq - 1) tails.push_back(sample_of(n - 1, run_of(n_seq - 1)));
     } else {
         // run ids of the first n_seq BWT positions by symbol change (src/r-index.cpp:993-1008)
         std::vector<uint64_t> endmarker_runs(n_seq, 0);
@@ -426,6 +603,19 @@ extern "C" pgx_status pgx_build_index_from_text(const char *text_path, const cha
     if (!text_path || !out_ri_path) throw Error(PGX_ERR_ARG, "pgx_build_index_from_text: null argument");
     TextBwt b;
     build_text_bwt(text_path, b);
+    if (out_rlbwt_path) write_rlbwt(out_rlbwt_path, b);
+    build_rindex_core(b.runs, &b, out_ri_path, encoded);
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_build_index_from_texts(const char *const *text_paths, uint32_t n_texts, const char *out_rlbwt_path, const char *out_ri_path, int encoded) {
+    PGX_GUARD_BEGIN
+    if (!text_paths || !n_texts || !out_ri_path) throw Error(PGX_ERR_ARG, "pgx_build_index_from_texts: null argument");
+    for (uint32_t i = 0; i < n_texts; i++)
+        if (!text_paths[i]) throw Error(PGX_ERR_ARG, "pgx_build_index_from_texts: null path");
+    TextBwt b;
+    build_texts_bwt(text_paths, n_texts, b);
     if (out_rlbwt_path) write_rlbwt(out_rlbwt_path, b);
     build_rindex_core(b.runs, &b, out_ri_path, encoded);
     return PGX_OK;

@@ -68,11 +68,14 @@ struct PgxDevImage {
     // host side only (pgx_batch_run puts one of the two tables into seed / seed_k of the copy it launches with): the first table and a shallower one
     uint32_t seed_k_main, seed_k_small;
     const uint4 *seed_main, *seed_small;
-    // PAIRS image (NULL without one): blocks, ptab (8 dwords per special-run count), first extensions of the full interval
+    // PAIRS image (NULL without one): blocks, first extensions of the full interval
     const uint4 *pairs;
-    const uint32_t *ptab;
     const uint4 *first_ext;
     uint32_t pair_runs;
+    // WIDE images (pgx_image.h): superblock bases and shifts; dense = 3 then (dense2 blocks with delta counts, 64-bit positions)
+    const uint64_t *sbase2, *pbase;
+    uint32_t d2_sb_shift, pairs_sb_shift, n_sb2, n_sbp;
+    uint32_t wide;
 };
 #define PGX_SEED_UNUSABLE 255u // depth value of entries the kernels must not use (a coordinate does not fit the entry)
 #define PGX_SEED_MAX_K 16
@@ -106,13 +109,13 @@ __global__ void pgx_find_mems_kernel(PgxDevImage img, const uint8_t *reads, cons
                                      uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap, pgx_heavy_item *heavy_list, unsigned long long *heavy_count,
                                      const pgx_heavy_item *rid_list, const unsigned long long *rid_count);
 // PAIRS image (pgx_image.h): two extensions per loop trip; reads that meet a special position go to redo_list (then served by the kernel above)
-template <bool SEED>
+template <bool SEED, bool WIDE, bool PACKED>
 __global__ void pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
                                            uint64_t min_len, uint64_t min_occ, const uint64_t *slot_off, pgx_mem *slots,
                                            uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor, uint64_t first_read,
                                            uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap, pgx_heavy_item *heavy_list, unsigned long long *heavy_count,
-                                           pgx_heavy_item *redo_list, unsigned long long *redo_count, const uint8_t *skip);
-__global__ void pgx_bad_chunks_kernel(const uint8_t *reads, uint64_t n_bytes, uint64_t *chunks, unsigned long long *count, uint64_t cap);
+                                           pgx_heavy_item *redo_list, unsigned long long *redo_count, const uint8_t *skip, const uint32_t *packed, uint32_t pk_words);
+__global__ void pgx_bad_chunks_kernel(const uint8_t *reads, uint64_t n_bytes, uint64_t *chunks, unsigned long long *count, uint64_t cap, uint32_t *packed);
 __global__ void pgx_classify_reads_kernel(const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads, const uint64_t *chunks, const unsigned long long *n_chunks,
                                           uint64_t cap, uint32_t *flag_words, pgx_heavy_item *list, unsigned long long *count);
 __global__ void pgx_first_ext_kernel(PgxDevImage img, uint4 *out); // out[byte] = {k, k', s, 0} of the full interval extended backward by byte; out[256 + byte]: by 0, then by byte

@@ -128,7 +128,7 @@ struct HostImage {
     std::vector<uint16_t> blow;   // device: low dir_shift bits of each block start
     std::vector<uint32_t> exc;    // DENSE2: exception runs (pgx_image.h)
     std::vector<uint8_t> pairs;   // PAIRS image blocks (pgx_image.h), empty without one
-    std::vector<uint32_t> ptab;   // PAIRS: 8 dwords per special-run count
+    std::vector<uint64_t> sbase2, pbase; // WIDE images: superblock bases of the DENSE2 / PAIRS image (pgx_image.h)
     std::vector<uint64_t> tstart, tvals;
     std::vector<uint32_t> tdir;
     uint64_t n_runs = 0;

@@ -74,18 +74,26 @@
  * in order, onto the interval after the first extension, and BWT there is c2 -- from the same cache line that answers one:
  * find_mems performs half the dependent line fetches.  96 symbols per 128-byte block, 4 n / 3 bytes in all:
  *   dw 4 y + x   (y, x in A C G T = 0..3) number of positions q < 96 b with c1(q) = y, c2(q) = x
- *   dw 16        bit 31: the block holds a SPECIAL position (c1 or c2 is \n or N); bits 0..30: special runs (maximal runs of
- *                consecutive special positions) that start before the block;  dw 17..19 unused
+ *   dw 16 + y    bits 0..30: number of positions q < 96 b with c1(q) = y and c2(q) SPECIAL (\n or N) -- what the pair counts of row y do
+ *                not see of the symbol y; bit 31 of dw 16: the block holds a special position (c1 or c2 is \n or N)
  *   dw 20..22 / 23..25   bit planes of c1 (bit 0, bit 1);  dw 26..28 / 29..31  bit planes of c2
- *   ptab[8 r ..]  for the r special runs a block has behind it: {special positions, positions with c2 special and c1 = A, C, G, T}
- *                (what the pair counts do not see; 3 unused dwords)
- * A kernel probe reads the row of its first symbol (16 bytes), dw 16 and the planes (48 bytes).  A kernel uses a block only when it
- * is not flagged, and two blocks together only when they are neighbours with the same run count (nothing special in either):
- * every count that involves \n or N then cancels out of the differences it needs.  Anything else goes to the image it accompanies
- * (pgx_find_mems_pairs_kernel hands such reads on). */
+ * A kernel probe reads the row of its first symbol (16 bytes), dw 16..19 and the planes (48 bytes).  A kernel uses unflagged blocks
+ * only, and two neighbouring blocks together only when neither is flagged: every count that involves \n or N then cancels out of the
+ * differences it needs.  Anything else goes to the image it accompanies (pgx_find_mems_pairs_kernel hands such reads on).
+ * (Until round 3 the dw 16 + y counts lived in an LDS table indexed by a per-block run count, which limited the image to indexes
+ * with at most 1023 special runs -- a few dozen sequences; now any number of sequences qualifies.) */
 #define PGX_PAIRS_SYMS 96u
 #define PGX_PAIRS_BLOCK_BYTES 128u
-#define PGX_PAIRS_MAX_RUNS 1023u /* ptab lives in LDS (32 bytes per run) */
+/* WIDE variants of DENSE2 and PAIRS (BWTs of 2^32 symbols or more, up to PGX_SB_MAX superblocks; FastLocate is size_t end to end,
+ * r-index.hpp:118-130): the same 128-byte blocks, but every count in a block header is a 32-bit DELTA against its superblock --
+ * 2^sb_shift consecutive blocks, at most 2^31 symbols -- whose 64-bit bases sit in a small table the kernels stage in LDS:
+ *   sbase2[8 s ..]   DENSE2, superblock s: counts of A C G T N before it, their sum, two unused words
+ *   pbase[24 s ..]   PAIRS, superblock s: the sixteen pair counts before it (4 y + x), the four row sums (16 + y), four unused words
+ * Positions, interval coordinates, C and pair_t2w are 64-bit in the kernels that walk these.  A narrow image is the special case of one
+ * superblock with zero bases (the narrow kernels never read the tables).  PGX_MODE_IMAGE_WIDE forces the wide form on any index. */
+#define PGX_SB_MAX 64u
+#define PGX_D2_SB_SHIFT 22u    /* 384 * 2^22 = 1.6e9 symbols per superblock */
+#define PGX_PAIRS_SB_SHIFT 24u /*  96 * 2^24 = 1.6e9 */
 
 /* ext_tab entry (one per byte value and direction): how to extend by that byte */
 #define PGX_EXT_CV(e) ((e) & 7u)            /* nuc code whose rank gives the new interval     */
@@ -118,8 +126,14 @@ typedef struct {
     uint32_t image_kind;  /* PGX_IMAGE_RL / PGX_IMAGE_DENSE / PGX_IMAGE_DENSE2 */
     uint32_t has_pairs;   /* a PAIRS image accompanies the DENSE / DENSE2 image */
     uint32_t pair_t2[32]; /* [8 y + c], y = 2-bit code of a regular symbol, c = nuc code: number of c in BWT[0, first suffix starting with y) */
-    uint32_t pair_runs;   /* special runs (ptab has pair_runs + 1 entries) */
+    uint32_t pair_runs;   /* special runs of the PAIRS image: maximal runs of positions whose c1 or c2 is \n or N (statistics only) */
     uint32_t reserved1;
+    /* WIDE images (appended: the offsets above are what tests/image_emu.py reads) */
+    uint32_t wide;            /* header counts are deltas against superblock bases; 64-bit kernels */
+    uint32_t d2_sb_shift, pairs_sb_shift; /* blocks per superblock = 1 << shift */
+    uint32_t n_sb2, n_sbp;    /* superblocks of the DENSE2 / PAIRS image */
+    uint32_t reserved2;
+    uint64_t pair_t2w[32];    /* pair_t2 in 64 bits (always filled) */
 } PgxConsts;
 
 /* locate image (FastLocate::locate / locateNext / decompressSA, src/r-index.cpp:1252-1366): three sorted

@@ -416,10 +416,22 @@ static void build_dense_image(const RiFile &ri, HostImage &img) {
 }
 
 // dense2 image: 384 symbols per 128-byte block as three sub-blocks of two bit planes + exception runs for \n and N (pgx_image.h)
-static void build_dense2_image(const RiFile &ri, HostImage &img) {
+// (wide: header counts are deltas against the bases of the block's superblock, 2^sb_shift blocks each)
+static uint32_t sb_shift_for(uint64_t nb, uint32_t want) { // the requested shift, raised until PGX_SB_MAX superblocks suffice
+    uint32_t sh = want;
+    while (((nb - 1) >> sh) + 1 > PGX_SB_MAX) sh++;
+    return sh;
+}
+static void build_dense2_image(const RiFile &ri, HostImage &img, bool wide, uint32_t sb_shift_want) {
     PgxConsts &c = img.consts;
-    if (c.n >> 32) throw Error(PGX_ERR_UNSUPPORTED, "BWT too long for the dense2 image");
+    if ((c.n >> 32) && !wide) throw Error(PGX_ERR_UNSUPPORTED, "BWT too long for the narrow dense2 image");
     const uint64_t nb = c.n / PGX_D2_SYMS + 1;
+    if (nb >> 32) throw Error(PGX_ERR_UNSUPPORTED, "BWT too long for the dense2 image");
+    const uint32_t sb_shift = wide ? sb_shift_for(nb, sb_shift_want) : 31u;
+    if (wide && (PGX_D2_SYMS << sb_shift) > (1ull << 31)) throw Error(PGX_ERR_UNSUPPORTED, "BWT too long for the wide dense2 image (more than PGX_SB_MAX superblocks)");
+    const uint64_t n_sb = wide ? ((nb - 1) >> sb_shift) + 1 : 1;
+    img.sbase2.assign(n_sb * 8, 0);
+    uint64_t base[6] = {0, 0, 0, 0, 0, 0};
     img.blocks.assign(nb * PGX_D2_BLOCK_BYTES, 0);
     img.bstart.clear();
     img.dir.assign(1, 0);
@@ -431,9 +443,21 @@ static void build_dense2_image(const RiFile &ri, HostImage &img) {
     static const int two_bit[6] = {0, 0, 1, 2, 0, 3};   // plane code (\n and N are exceptions stored as 0)
     auto put_header = [&](uint64_t b) {
         uint32_t *h = dw + b * 32;
-        for (int i = 1; i < 6; i++) h[hdr_slot[i]] = (uint32_t)c6[i];
+        if (wide && (b & ((1ull << sb_shift) - 1)) == 0) { // a superblock starts here
+            uint64_t *sb = img.sbase2.data() + (b >> sb_shift) * 8;
+            uint64_t sum = 0;
+            for (int i = 1; i < 6; i++) { base[i] = c6[i]; sb[hdr_slot[i]] = c6[i]; sum += c6[i]; }
+            sb[5] = sum;
+        }
+        for (int i = 1; i < 6; i++) h[hdr_slot[i]] = (uint32_t)(c6[i] - base[i]);
         if (img.exc.size() >> 24) throw Error(PGX_ERR_UNSUPPORTED, "too many exception runs for the dense2 image");
         h[5] = (uint32_t)img.exc.size();
+    };
+    auto set_bits = [](uint32_t *words, uint32_t lo, uint32_t hi) { // bits [lo, hi) of a plane of 128 bits
+        for (uint32_t w = lo >> 5; w <= ((hi - 1) >> 5); w++) {
+            const uint32_t a = std::max(lo, w << 5) & 31u, e = std::min(hi, (w + 1) << 5) - (w << 5); // bits [a, e) of word w
+            words[w] |= (e == 32 ? 0xFFFFFFFFu : ((1u << e) - 1u)) & ~((1u << a) - 1u);
+        }
     };
     auto finish_block = [&](uint64_t b) { // sub-block counts from the finished planes
         uint32_t *h = dw + b * 32;
@@ -462,11 +486,12 @@ static void build_dense2_image(const RiFile &ri, HostImage &img) {
                 uint32_t *h = dw + b * 32;
                 const int tb = two_bit[code];
                 if (tb)
-                    for (uint32_t i = off; i < off + take; i++) {
-                        uint32_t *sb = h + 8 + 8 * (i >> 7); // sub-block: 4 dwords of plane 0, then 4 of plane 1
-                        const uint32_t r = i & 127u;
-                        if (tb & 1) sb[r >> 5] |= 1u << (r & 31);
-                        if (tb & 2) sb[4 + (r >> 5)] |= 1u << (r & 31);
+                    for (uint32_t i = off; i < off + (uint32_t)take;) { // sub-block by sub-block: 4 dwords of plane 0, then 4 of plane 1
+                        uint32_t *sb = h + 8 + 8 * (i >> 7);
+                        const uint32_t lo = i & 127u, hi = std::min<uint32_t>(128u, lo + (off + (uint32_t)take - i));
+                        if (tb & 1) set_bits(sb, lo, hi);
+                        if (tb & 2) set_bits(sb + 4, lo, hi);
+                        i += hi - lo;
                     }
                 if (code == 0 || code == 4) {
                     const uint32_t kind = code == 4 ? 1u : 0u;
@@ -492,19 +517,22 @@ static void build_dense2_image(const RiFile &ri, HostImage &img) {
     c.dir_shift = 0;
     c.dir_entries = 1;
     c.image_kind = PGX_IMAGE_DENSE2;
+    c.wide = wide ? 1u : 0u;
+    c.d2_sb_shift = sb_shift;
+    c.n_sb2 = (uint32_t)n_sb;
 }
 
 // PAIRS image (pgx_image.h): c2(p) = BWT[LF(p)] for every position whose BWT symbol is A C G T, pair counts per 128 positions.
 // Returns false (and leaves img without one) when the index does not qualify: an extension entry that ranks a regular symbol must
 // place its interval at that symbol's true C value -- the second step of a pair relies on LF mapping the positions with c1 = a
 // onto the interval after the first -- and the special runs must fit ptab.
-static bool build_pairs_image(const RiFile &ri, HostImage &img) {
+static bool build_pairs_image(const RiFile &ri, HostImage &img, bool wide, uint32_t sb_shift_want) {
     PgxConsts &c = img.consts;
-    img.pairs.clear(); img.ptab.clear();
+    img.pairs.clear(); img.pbase.clear();
     c.has_pairs = 0; c.pair_runs = 0;
     const uint64_t n = c.n;
-    if (n == 0 || (n >> 32) || c.excl_mask) return false;
-    for (int i = 0; i < 8; i++) if (c.C[i] >> 32) return false;
+    if (n == 0 || ((n >> 32) && !wide) || c.excl_mask) return false;
+    if (!wide) for (int i = 0; i < 8; i++) if (c.C[i] >> 32) return false;
     // the BWT as nuc codes, counts, true C
     std::vector<uint8_t> bw(n);
     uint64_t tot[6] = {0, 0, 0, 0, 0, 0};
@@ -600,28 +628,62 @@ static bool build_pairs_image(const RiFile &ri, HostImage &img) {
                 for (int i = 0; i < 5; i++) runs.back().cnt[i] += sr.cnt[i];
             } else runs.push_back(sr);
         }
-    if (runs.size() > PGX_PAIRS_MAX_RUNS) return false;
-    img.ptab.assign((runs.size() + 1) * 8, 0);
-    for (size_t r = 0; r < runs.size(); r++)
-        for (int i = 0; i < 5; i++) img.ptab[(r + 1) * 8 + i] = img.ptab[r * 8 + i] + (uint32_t)runs[r].cnt[i];
+    {
+        uint64_t special = 0;
+        for (const Special &sr : runs) special += sr.cnt[0];
+        if (special >> 31) return false; // (the header counts of special positions are 31-bit)
+    }
+    // positions with c2 special and c1 = A, C, G, T in every chunk (the blocks carry their running sums)
+    std::vector<std::array<uint64_t, 4>> spec_cnt(nt, std::array<uint64_t, 4>{});
+    for (size_t t = 0; t < nt; t++)
+        for (const Special &sr : spec_of[t])
+            for (int i = 0; i < 4; i++) spec_cnt[t][i] += sr.cnt[1 + i];
+    // superblocks (wide): bases of the sixteen pair counts and their four row sums
+    if ((nb >> 32)) return false;
+    const uint32_t sb_shift = wide ? sb_shift_for(nb, sb_shift_want) : 31u;
+    if (wide && ((uint64_t)PGX_PAIRS_SYMS << sb_shift) > (1ull << 31)) return false;
+    const uint64_t n_sb = wide ? ((nb - 1) >> sb_shift) + 1 : 1;
+    img.pbase.assign(n_sb * 24, 0);
+    if (wide) { // pair counts before every superblock: those before its chunk + a scan of the chunk's positions before it
+        std::vector<std::thread> th;
+        const unsigned par = (unsigned)std::min<uint64_t>(n_sb, 16);
+        for (unsigned w = 0; w < par; w++)
+            th.emplace_back([&, w]() {
+                for (uint64_t sbi = w; sbi < n_sb; sbi += par) {
+                    const uint64_t b = sbi << sb_shift;
+                    size_t t = 0;
+                    while (t + 1 < nt && range_of[t].second <= b) t++;
+                    std::array<uint64_t, 16> pc{};
+                    for (size_t u = 0; u < t; u++) for (int i = 0; i < 16; i++) pc[i] += pair_cnt[u][i];
+                    for (uint64_t p = std::min<uint64_t>(range_of[t].first * PGX_PAIRS_SYMS, n); p < std::min<uint64_t>(b * PGX_PAIRS_SYMS, n); p++)
+                        if (!(pr[p] & 0x80)) pc[pr[p]]++;
+                    uint64_t *sb = img.pbase.data() + sbi * 24;
+                    for (int i = 0; i < 16; i++) { sb[i] = pc[i]; sb[16 + (i >> 2)] += pc[i]; }
+                }
+            });
+        for (auto &x : th) x.join();
+    }
     // blocks
     img.pairs.assign(nb * PGX_PAIRS_BLOCK_BYTES, 0);
     uint32_t *dw = reinterpret_cast<uint32_t *>(img.pairs.data());
     run_chunks([&](size_t t, uint64_t p0, uint64_t p1) {
         std::array<uint64_t, 16> pc{};
-        for (size_t u = 0; u < t; u++) for (int i = 0; i < 16; i++) pc[i] += pair_cnt[u][i];
+        std::array<uint64_t, 4> ps{};
+        for (size_t u = 0; u < t; u++) { for (int i = 0; i < 16; i++) pc[i] += pair_cnt[u][i]; for (int i = 0; i < 4; i++) ps[i] += spec_cnt[u][i]; }
         const uint64_t b0 = range_of[t].first, b1 = range_of[t].second;
         size_t r = std::lower_bound(runs.begin(), runs.end(), b0 * PGX_PAIRS_SYMS, [](const Special &a, uint64_t v) { return a.start < v; }) - runs.begin(); // runs starting before the block
         for (uint64_t b = b0; b < b1; b++) {
             uint32_t *h = dw + b * 32;
             const uint64_t s0 = b * PGX_PAIRS_SYMS, s1 = std::min<uint64_t>(s0 + PGX_PAIRS_SYMS, n);
             while (r < runs.size() && runs[r].start < s0) r++;
-            for (int i = 0; i < 16; i++) h[i] = (uint32_t)pc[i];
+            const uint64_t *sb = img.pbase.data() + (wide ? (b >> sb_shift) : 0) * 24; // (zero in a narrow image)
+            for (int i = 0; i < 16; i++) h[i] = (uint32_t)(pc[i] - sb[i]);
             bool flag = (r > 0 && runs[r - 1].start + runs[r - 1].len > s0) || (r < runs.size() && runs[r].start < s1);
-            h[16] = (uint32_t)r | (flag ? 0x80000000u : 0u);
+            for (int i = 0; i < 4; i++) h[16 + i] = (uint32_t)ps[i];
+            if (flag) h[16] |= 0x80000000u;
             for (uint64_t p = std::min(s0, p1); p < std::min(s1, p1); p++) {
                 const uint8_t v = pr[p];
-                if (v & 0x80) continue;
+                if (v & 0x80) { if (v > 0x80) ps[v - 0x81]++; continue; }
                 const uint32_t i = (uint32_t)(p - s0), bit = 1u << (i & 31), w = i >> 5;
                 if (v & 4) h[20 + w] |= bit;
                 if (v & 8) h[23 + w] |= bit;
@@ -640,10 +702,12 @@ static bool build_pairs_image(const RiFile &ri, HostImage &img) {
         for (; t + 1 < nt && std::min<uint64_t>(range_of[t].second * PGX_PAIRS_SYMS, n) <= P; t++)
             for (int i = 0; i < 6; i++) cnt[i] += code_cnt[t][i];
         for (uint64_t p = std::min<uint64_t>(range_of[t].first * PGX_PAIRS_SYMS, n); p < P; p++) cnt[bw[p]]++;
-        for (int i = 0; i < 6; i++) c.pair_t2[8 * y + i] = (uint32_t)cnt[i];
+        for (int i = 0; i < 6; i++) { c.pair_t2[8 * y + i] = (uint32_t)cnt[i]; c.pair_t2w[8 * y + i] = cnt[i]; }
     }
     c.has_pairs = 1;
     c.pair_runs = (uint32_t)runs.size();
+    c.pairs_sb_shift = sb_shift;
+    c.n_sbp = (uint32_t)n_sb;
     return true;
 }
 
@@ -651,21 +715,32 @@ static bool build_pairs_image(const RiFile &ri, HostImage &img) {
 // not stay cache resident either; PGX_MODE_IMAGE_* / the environment variable PGX_IMAGE force one
 // returns PGX_IMAGE_RL / PGX_IMAGE_DENSE / PGX_IMAGE_DENSE2
 // pairs: 0 = no PAIRS image, 1 = one if the index qualifies, 2 = required (forced)
-static uint32_t choose_image(const RiFile &ri, uint32_t mode_bits, const PgxConsts &c, int &pairs) {
+// wide: the 64-bit form of dense2 / pairs (forced by PGX_MODE_IMAGE_WIDE / PGX_IMAGE=wide, automatic from 2^32 symbols on)
+static uint32_t choose_image(const RiFile &ri, uint32_t mode_bits, const PgxConsts &c, int &pairs, bool &wide) {
     const bool can = c.excl_mask == 0;
     const uint32_t all = PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE | PGX_MODE_IMAGE_DENSE2 | PGX_MODE_IMAGE_PAIRS;
     uint32_t force = mode_bits & all;
     pairs = 0;
-    if (!force)
+    wide = (mode_bits & PGX_MODE_IMAGE_WIDE) != 0;
+    if (!force && !wide)
         if (const char *e = std::getenv("PGX_IMAGE")) {
             const std::string v(e);
             force = v == "dense" ? PGX_MODE_IMAGE_DENSE : v == "dense2" ? PGX_MODE_IMAGE_DENSE2 : v == "rl" ? PGX_MODE_IMAGE_RL : v == "pairs" ? PGX_MODE_IMAGE_PAIRS : 0u;
+            if (v == "wide" || v == "wide-pairs") { wide = true; force = PGX_MODE_IMAGE_PAIRS; }
+            if (v == "wide-dense2") { wide = true; force = PGX_MODE_IMAGE_DENSE2; }
         }
     if (force & (force - 1)) throw Error(PGX_ERR_ARG, "pgx_index_open: more than one image layout forced");
+    if (wide && (force & (PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE))) throw Error(PGX_ERR_ARG, "pgx_index_open: PGX_MODE_IMAGE_WIDE goes with dense2 / pairs only");
+    if (wide && !force) force = PGX_MODE_IMAGE_PAIRS;
+    // dense2 blocks of 384 symbols in at most PGX_SB_MAX superblocks of 2^31 symbols
+    const bool fits_wide = c.n < ((uint64_t)PGX_SB_MAX << 30);
     if (force & (PGX_MODE_IMAGE_DENSE | PGX_MODE_IMAGE_DENSE2 | PGX_MODE_IMAGE_PAIRS)) {
         if (!can) throw Error(PGX_ERR_UNSUPPORTED, "dense image: not available for a legacy-layout index without N in COMPAT mode");
-        if ((force & (PGX_MODE_IMAGE_DENSE2 | PGX_MODE_IMAGE_PAIRS)) && (c.n >> 32)) throw Error(PGX_ERR_UNSUPPORTED, "dense2 image: BWT of 2^32 symbols or more");
-        if (force & PGX_MODE_IMAGE_PAIRS) pairs = 2;
+        if ((force & (PGX_MODE_IMAGE_DENSE2 | PGX_MODE_IMAGE_PAIRS)) && (c.n >> 32)) {
+            if (!fits_wide) throw Error(PGX_ERR_UNSUPPORTED, "dense2 image: BWT too long");
+            wide = true;
+        }
+        if (force & PGX_MODE_IMAGE_PAIRS) pairs = wide && !(mode_bits & PGX_MODE_IMAGE_PAIRS) && !std::getenv("PGX_IMAGE") ? 1 : 2;
         return (force & PGX_MODE_IMAGE_DENSE) ? PGX_IMAGE_DENSE : PGX_IMAGE_DENSE2;
     }
     if ((force & PGX_MODE_IMAGE_RL) || !can) return PGX_IMAGE_RL;
@@ -680,6 +755,7 @@ static uint32_t choose_image(const RiFile &ri, uint32_t mode_bits, const PgxCons
     //  2.66 against 3.17 ms --, everything else on the 64-byte image)
     if (dense_bytes0 <= (224ull << 20)) { pairs = (c.n >> 32) ? 0 : 1; return PGX_IMAGE_DENSE; }
     if (!(c.n >> 32)) { pairs = 1; return PGX_IMAGE_DENSE2; } // + the two-step PAIRS image when the index qualifies
+    if (fits_wide) { pairs = 1; wide = true; return PGX_IMAGE_DENSE2; } // the same in 64 bits (pgx_image.h "WIDE")
     uint64_t runs = 0;
     for (const auto &b : ri.blocks) runs += b.runs.size();
     const uint64_t dense_bytes = dense_blocks * PGX_BLOCK_BYTES, rl_bytes = (runs / PGX_BLOCK_RUNS + 1) * (PGX_BLOCK_BYTES + 4);
@@ -696,16 +772,20 @@ void build_rank_image(const RiFile &ri, uint32_t mode_bits, HostImage &img) {
     build_ext_tables(ri, mode, c);
     build_count_table(ri, mode, c);
     int pairs = 0;
-    const uint32_t kind = choose_image(ri, mode_bits, c, pairs);
-    img.pairs.clear(); img.ptab.clear();
+    bool wide = false;
+    const uint32_t kind = choose_image(ri, mode_bits, c, pairs, wide);
+    img.pairs.clear(); img.sbase2.clear(); img.pbase.clear();
+    // superblock sizes (tests shrink them so that small indexes have many: PGX_SB_SHIFT = blocks of the dense2 image per superblock, log2)
+    uint32_t sh2 = PGX_D2_SB_SHIFT, shp = PGX_PAIRS_SB_SHIFT;
+    if (const char *e = std::getenv("PGX_SB_SHIFT")) { sh2 = (uint32_t)std::min<unsigned long>(std::strtoul(e, nullptr, 10), PGX_D2_SB_SHIFT); shp = sh2 + 2; }
     if (kind == PGX_IMAGE_DENSE) {
         build_dense_image(ri, img);
-        if (pairs) (void)build_pairs_image(ri, img);
+        if (pairs) (void)build_pairs_image(ri, img, false, shp);
         return;
     }
     if (kind == PGX_IMAGE_DENSE2) {
-        build_dense2_image(ri, img);
-        if (pairs && !build_pairs_image(ri, img) && pairs == 2)
+        build_dense2_image(ri, img, wide, sh2);
+        if (pairs && !build_pairs_image(ri, img, wide, shp) && pairs == 2)
             throw Error(PGX_ERR_UNSUPPORTED, "pairs image: the index does not qualify (extension tables of a COMPAT quirk, or too many N / endmarker runs)");
         return;
     }
@@ -894,7 +974,7 @@ extern "C" int pgx_abi_version(void) { return PGX_ABI_VERSION; }
 void pgx_release_device_images(pgx_index *h); // pgx_runtime.hip
 
 static pgx_index *open_impl(const uint8_t *ri, uint64_t ri_n, const uint8_t *tags, uint64_t tags_n, uint32_t tags_format, uint32_t mode) {
-    if ((mode & PGX_MODE_MASK) > PGX_MODE_STRICT || (mode & ~(PGX_MODE_MASK | PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE | PGX_MODE_IMAGE_DENSE2 | PGX_MODE_IMAGE_PAIRS)))
+    if ((mode & PGX_MODE_MASK) > PGX_MODE_STRICT || (mode & ~(PGX_MODE_MASK | PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE | PGX_MODE_IMAGE_DENSE2 | PGX_MODE_IMAGE_PAIRS | PGX_MODE_IMAGE_WIDE)))
         throw Error(PGX_ERR_ARG, "pgx_index_open: bad mode");
     if (!ri && !tags) throw Error(PGX_ERR_ARG, "pgx_index_open: neither an r-index nor a tag array given");
     std::unique_ptr<pgx_index> h(new pgx_index());
@@ -917,7 +997,7 @@ extern "C" pgx_status pgx_index_open(const char *ri_path, const char *tags_path,
                                      uint32_t mode, pgx_index **out) {
     PGX_GUARD_BEGIN
     if (!ri_path || !out) throw Error(PGX_ERR_ARG, "pgx_index_open: null argument");
-    if ((mode & PGX_MODE_MASK) > PGX_MODE_STRICT || (mode & ~(PGX_MODE_MASK | PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE | PGX_MODE_IMAGE_DENSE2 | PGX_MODE_IMAGE_PAIRS)))
+    if ((mode & PGX_MODE_MASK) > PGX_MODE_STRICT || (mode & ~(PGX_MODE_MASK | PGX_MODE_IMAGE_RL | PGX_MODE_IMAGE_DENSE | PGX_MODE_IMAGE_DENSE2 | PGX_MODE_IMAGE_PAIRS | PGX_MODE_IMAGE_WIDE)))
         throw Error(PGX_ERR_ARG, "pgx_index_open: bad mode");
     *out = nullptr;
     std::vector<uint8_t> f, t;
@@ -976,7 +1056,8 @@ extern "C" pgx_status pgx_index_info_get(const pgx_index *h, pgx_index_info *inf
     info->n_tag_runs = c.n_tag_runs;
     info->tag_dir_entries = c.tag_dir_entries;
     info->tag_dir_shift = c.tag_dir_shift;
-    info->image_bytes = h->img.blocks.size() + h->img.dir.size() * 8 + h->img.blow.size() * 2 + h->img.exc.size() * 4 + h->img.pairs.size() + h->img.ptab.size() * 4;
+    info->image_bytes = h->img.blocks.size() + h->img.dir.size() * 8 + h->img.blow.size() * 2 + h->img.exc.size() * 4 + h->img.pairs.size() +
+                        (h->img.sbase2.size() + h->img.pbase.size()) * 8;
     info->tag_image_bytes = h->img.tstart.size() * 8 + h->img.tvals.size() * 8 + h->img.tdir.size() * 4;
     info->image_in_lds = h->img.consts.image_kind == PGX_IMAGE_DENSE ? (uint64_t)h->img.consts.n_blocks * 80 + 16 <= 48 * 1024
                                                                      : (h->img.consts.image_kind == PGX_IMAGE_RL && info->image_bytes <= 48 * 1024);
@@ -985,6 +1066,7 @@ extern "C" pgx_status pgx_index_info_get(const pgx_index *h, pgx_index_info *inf
     info->n_samples = h->ri.samples.size();
     info->image_kind = c.image_kind;
     info->image_pairs = c.has_pairs;
+    info->image_wide = c.wide;
     return PGX_OK;
     PGX_GUARD_END
 }
@@ -1019,7 +1101,8 @@ extern "C" pgx_status pgx_index_image_view(const pgx_index *h, int which, const 
     case 7: *ptr = m.blow.data(); *bytes = m.blow.size() * 2; break;
     case 15: *ptr = m.exc.data(); *bytes = m.exc.size() * 4; break;
     case 20: *ptr = m.pairs.data(); *bytes = m.pairs.size(); break;
-    case 21: *ptr = m.ptab.data(); *bytes = m.ptab.size() * 4; break;
+    case 22: *ptr = m.sbase2.data(); *bytes = m.sbase2.size() * 8; break;
+    case 23: *ptr = m.pbase.data(); *bytes = m.pbase.size() * 8; break;
     case 16: case 17: case 18: case 19: {
         if (!(h->ri.encoded && !h->ri.hasN)) throw Error(PGX_ERR_ARG, "pgx_index_image_view: the literal count image exists for encoded indexes without N only");
         pgx::LitHostImage &l = const_cast<pgx_index *>(h)->lit;

@@ -218,6 +218,61 @@ __device__ __forceinline__ void pgx_dense2_rank(const PgxDevImage &img, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------
+// WIDE DENSE2 (pgx_image.h): the same blocks, header counts as deltas against the 64-bit bases of the block's superblock; positions
+// and counts in 64 bits.  `sb` = the base table (img.sbase2 or its LDS copy): 8 words per superblock {A, C, G, T, N, their sum}.
+__device__ __forceinline__ PgxDense2Blk pgx_dense2w_load(const PgxDevImage &img, uint64_t pos, uint32_t &rel, uint32_t &blk) {
+    blk = (uint32_t)(__umul64hi(pos, 0xAAAAAAAAAAAAAAABull) >> 8); // pos / 384
+    rel = (uint32_t)(pos - (uint64_t)blk * PGX_D2_SYMS);
+    const uint4 *bp = img.blocks + (size_t)blk * 8;
+    PgxDense2Blk b;
+    b.h0 = bp[0]; b.h1 = bp[1];
+    const uint4 *sp = bp + 2 + 2 * (rel >> 7);
+    b.p0 = sp[0]; b.p1 = sp[1];
+    return b;
+}
+__device__ __forceinline__ void pgx_dense2w_counts(const PgxDevImage &img, const uint64_t *__restrict__ sb, const PgxDense2Blk &b, uint64_t pos, uint32_t rel,
+                                                   uint32_t blk, uint64_t c[6]) {
+    uint32_t d[6];
+    pgx_dense2_counts(img, b, rel, rel, d); // with pos = rel: d[0] = -(sum of the five deltas) + e0, the others delta + in-block count
+    const uint64_t *base = sb + (size_t)(blk >> img.d2_sb_shift) * 8;
+    c[0] = (pos - rel) - base[5] + (uint64_t)(int64_t)(int32_t)d[0]; // (the deltas of a superblock stay below 2^31: d[0] is a small negative number)
+    c[1] = base[0] + d[1];
+    c[2] = base[1] + d[2];
+    c[3] = base[2] + d[3];
+    c[4] = base[4] + d[4];
+    c[5] = base[3] + d[5];
+}
+__device__ __forceinline__ void pgx_dense2w_pair(const PgxDevImage &img, const uint64_t *__restrict__ sb, uint64_t p0, uint64_t p1, uint32_t cv, uint32_t mrow,
+                                                 uint64_t &A0, uint64_t &A1, uint64_t &dB) {
+    uint32_t r0, r1, b0, b1;
+    const PgxDense2Blk k0 = pgx_dense2w_load(img, p0, r0, b0), k1 = pgx_dense2w_load(img, p1, r1, b1);
+    uint64_t c0[6], c1[6];
+    pgx_dense2w_counts(img, sb, k0, p0, r0, b0, c0);
+    pgx_dense2w_counts(img, sb, k1, p1, r1, b1, c1);
+    uint64_t a0 = 0, a1 = 0, d = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        a0 = (cv == (uint32_t)i) ? c0[i] : a0;
+        a1 = (cv == (uint32_t)i) ? c1[i] : a1;
+        d += (c1[i] - c0[i]) * (uint64_t)((mrow >> (3 * i)) & 7u);
+    }
+    A0 = a0; A1 = a1; dB = d;
+}
+__device__ __forceinline__ void pgx_dense2w_rank(const PgxDevImage &img, uint64_t pos, uint32_t cv, uint32_t mrow, uint64_t &A, uint64_t &B) {
+    uint32_t rel, blk;
+    const PgxDense2Blk k = pgx_dense2w_load(img, pos, rel, blk);
+    uint64_t c[6];
+    pgx_dense2w_counts(img, img.sbase2, k, pos, rel, blk, c);
+    uint64_t a = 0, bb = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        a = (cv == (uint32_t)i) ? c[i] : a;
+        bb += c[i] * (uint64_t)((mrow >> (3 * i)) & 7u);
+    }
+    A = a; B = bb;
+}
+
+// ------------------------------------------------------------------------------------------
 // rank probe: A = count of code `cv` in BWT[0,pos), B = sum over codes of mult[code] * count(code)
 // (both modulo 2^64; only differences of two probes are ever used).
 template <bool LDS_IMAGE>
@@ -225,6 +280,7 @@ __device__ __forceinline__ void pgx_rank_ab(const PgxDevImage &img, const uint4 
                                             const uint64_t *__restrict__ lds_dir, const uint16_t *__restrict__ lds_blow,
                                             uint64_t pos, uint32_t cv, uint32_t mrow, uint64_t &A, uint64_t &B) {
     if (pos > img.n) pos = img.n; // predecessor(pos >= size) = last block, rel past the end = totals
+    if (img.dense == 3) { pgx_dense2w_rank(img, pos, cv, mrow, A, B); return; }
     if (img.dense == 2) { pgx_dense2_rank(img, (uint32_t)pos, cv, mrow, A, B); return; }
     if (img.dense) {
         pgx_dense_rank(pgx_dense_load<LDS_IMAGE>(img, lds_blocks, pos), pos, cv, mrow, A, B);
@@ -334,6 +390,7 @@ __device__ __forceinline__ void pgx_rank_pair(const PgxDevImage &img, const uint
                                               uint64_t &A1, uint64_t &dB) {
     const uint64_t p0 = pos0 > img.n ? img.n : pos0, p1 = pos1 > img.n ? img.n : pos1;
     uint64_t B0 = 0, B1 = 0;
+    if (MAYBE_DENSE && img.dense == 3) { pgx_dense2w_pair(img, img.sbase2, p0, p1, cv, mrow, A0, A1, dB); return; }
     if (MAYBE_DENSE && img.dense == 2) { pgx_dense2_pair<false>(img, (uint32_t)p0, (uint32_t)p1, cv, mrow, A0, A1, dB); return; }
     if (MAYBE_DENSE && img.dense) { // two independent block loads, no directory
         const PgxDenseBlk k0 = pgx_dense_load<LDS_IMAGE>(img, lds_blocks, p0), k1 = pgx_dense_load<LDS_IMAGE>(img, lds_blocks, p1);
@@ -509,7 +566,9 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                      const pgx_heavy_item *__restrict__ rid_list, const unsigned long long *__restrict__ rid_count) {
     __shared__ uint32_t s_ext[512];
     __shared__ uint64_t s_C[8];
+    __shared__ uint64_t s_sb[DENSE == 3 ? PGX_SB_MAX * 8 : 1]; // WIDE dense2: superblock bases
     PGX_LDS_CARVE(img);
+    if (DENSE == 3) for (uint32_t i = threadIdx.x; i < img.n_sb2 * 8u; i += blockDim.x) s_sb[i] = img.sbase2[i];
     pgx_stage_tables<LDS_IMAGE>(img, s_ext, s_C, lds_blocks, lds_dir, lds_blow);
     // rid_list (may be NULL): the launch serves the reads listed there (handed on by pgx_find_mems_pairs_kernel), *rid_count of them, each from
     // the start position it was handed on at, keeping the MEMs written before
@@ -518,7 +577,8 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
 
     static_assert(!NARROW || DENSE, "the 32-bit state exists for the dense image only");
     static_assert(!SEED || DENSE, "k-mer seeds exist for the dense images");
-    static_assert(DENSE != 2 || !LDS_IMAGE, "the dense2 image is never staged in LDS");
+    static_assert(DENSE < 2 || !LDS_IMAGE, "the dense2 image is never staged in LDS");
+    static_assert(DENSE != 3 || !NARROW, "the wide dense2 image is walked in 64 bits");
     typedef typename std::conditional<NARROW, uint32_t, uint64_t>::type pos_t;
     const int lane = threadIdx.x & 63;
     const pos_t n = (pos_t)img.n;
@@ -685,7 +745,16 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
             const pos_t kk = fwd ? kp : k, kq = fwd ? k : kp;
             bool fin;
             pos_t A1, dB;
-            if (DENSE == 2) {
+            if (DENSE == 3) {
+                // wide dense2: the same probes with 64-bit positions and superblock bases from LDS
+                const uint64_t p0 = kk > n ? n : kk, p1 = (kk + s) > n ? n : (kk + s);
+                uint64_t q0, q1, dq;
+                pgx_dense2w_pair(img, s_sb, p0, p1, cv, mrow, q0, q1, dq);
+                A0 = (pos_t)q0; A1 = (pos_t)q1; dB = (pos_t)dq;
+                fin = true;
+                c_blk = s != n;
+                c_blk2 = c_blk && (uint32_t)(__umul64hi(p0, 0xAAAAAAAAAAAAAAABull) >> 8) != (uint32_t)(__umul64hi(p1, 0xAAAAAAAAAAAAAAABull) >> 8);
+            } else if (DENSE == 2) {
                 // dense2: header + one sub-block per probe, all within one 128-byte line (usually the same line for both probes)
                 uint64_t q0, q1, dq;
                 if (NARROW) {
@@ -833,6 +902,8 @@ PGX_FM_INSTANTIATE(false, 2, false, false)
 PGX_FM_INSTANTIATE(false, 2, true, false)
 PGX_FM_INSTANTIATE(false, 2, false, true)
 PGX_FM_INSTANTIATE(false, 2, true, true)
+PGX_FM_INSTANTIATE(false, 3, false, false)
+PGX_FM_INSTANTIATE(false, 3, false, true)
 
 // ------------------------------------------------------------------------------------------
 // Reads with a byte outside A C G T (upper case): no seed applies to a window that holds one, so the two-step kernel could only hand
@@ -840,14 +911,18 @@ PGX_FM_INSTANTIATE(false, 2, true, true)
 // Found once per upload, they go to the dense2 kernel on a second stream WHILE the two-step kernel runs, which skips them.
 // Two passes: a streaming one over the read bytes (16 per lane, coalesced) that lists the 16-byte chunks holding such a byte, and one
 // thread per listed chunk that finds the reads its bad bytes belong to (binary search in the offsets), flags them and lists each once.
+// (packed != NULL: the same pass writes the reads as two bits per symbol, 16 symbols per dword, A C T G = 0 1 2 3 -- the code order of the seed
+//  index --, for pgx_find_mems_pairs_kernel<.., PACKED>; symbols of a chunk that holds another byte are junk, and so is what the reads flagged here stand for)
 __global__ void __launch_bounds__(256)
-pgx_bad_chunks_kernel(const uint8_t *__restrict__ reads, uint64_t n_bytes, uint64_t *__restrict__ chunks, unsigned long long *__restrict__ count, uint64_t cap) {
+pgx_bad_chunks_kernel(const uint8_t *__restrict__ reads, uint64_t n_bytes, uint64_t *__restrict__ chunks, unsigned long long *__restrict__ count, uint64_t cap,
+                      uint32_t *__restrict__ packed) {
     const uint64_t n_chunks = (n_bytes + 15) >> 4; // (32 zero bytes follow the last read: the last chunk may be read whole)
     for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * blockDim.x) {
         const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(reads + (c << 4));
         uint64_t b0, b1;
-        (void)pgx_seed_codes(v.x, b0);
-        (void)pgx_seed_codes(v.y, b1);
+        const uint32_t c0 = pgx_seed_codes(v.x, b0);
+        const uint32_t c1 = pgx_seed_codes(v.y, b1);
+        if (packed) packed[c] = c0 | (c1 << 16);
         const uint64_t left = n_bytes - (c << 4); // bytes of the chunk that belong to reads
         if (left < 8) { b0 &= (1ull << (8 * left)) - 1ull; b1 = 0; }
         else if (left < 16) b1 &= (1ull << (8 * (left - 8))) - 1ull;
@@ -904,40 +979,55 @@ pgx_classify_reads_kernel(const uint8_t *__restrict__ reads, const uint64_t *__r
 __device__ __forceinline__ uint32_t pgx_window_byte(uint64_t w0, uint64_t w1, uint64_t a) { // byte a of the 16-byte window
     return (uint32_t)(((a & 8ull) ? w1 : w0) >> (8u * (uint32_t)(a & 7ull))) & 0xFFu;
 }
-template <bool SEED>
+// WIDE: the 64-bit form (pgx_image.h "WIDE"): header counts are deltas against the bases of the block's superblock (staged in LDS), interval state,
+// C and pair_t2 in 64 bits; everything else is the same kernel.
+// PACKED: the reads as two bits per symbol (pgx_pack_reads_kernel: A C T G = 0 1 2 3, the order of the seed index), every lane's read copied
+// into LDS when the lane takes it: the loop then reads its symbols (and whole seed windows, which ARE the seed index) from LDS instead of
+// re-fetching 16-byte windows of the read bytes through L2 -- a fifth of the kernel's memory requests at chr22 scale (941 M requests per step of
+// which 213 M were such windows: the ~300 k live reads do not stay in L2).  Only for launches that skip every read with a byte outside A C G T.
+template <bool SEED, bool WIDE, bool PACKED>
 __global__ void __launch_bounds__(PGX_FM_THREADS, PGX_FM_WAVES_PER_SIMD) // (<= 96 VGPRs: five waves per SIMD fit and are what the launch uses; four are as fast -- 20.7 against 20.6-21.0 ms at chr22 scale --, three 21.8)
 pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                            uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
                            pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
                            unsigned long long *__restrict__ cursor, uint64_t first_read, uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap,
                            pgx_heavy_item *__restrict__ heavy_list, unsigned long long *__restrict__ heavy_count,
-                           pgx_heavy_item *__restrict__ redo_list, unsigned long long *__restrict__ redo_count, const uint8_t *__restrict__ skip) {
+                           pgx_heavy_item *__restrict__ redo_list, unsigned long long *__restrict__ redo_count, const uint8_t *__restrict__ skip,
+                           const uint32_t *__restrict__ packed, uint32_t pk_words) {
+    typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type pos_t;
     __shared__ uint32_t s_ext[512];
-    __shared__ uint32_t s_C[8];
-    __shared__ uint32_t s_t2[32];
-    __shared__ uint4 s_fe[512]; // first_ext: [byte] the full interval extended by byte, [256 + byte] extended by 0 and then by byte
+    __shared__ pos_t s_C[8];
+    __shared__ pos_t s_t2[32];
+    __shared__ uint64_t s_pb[WIDE ? PGX_SB_MAX * 24 : 1]; // WIDE: per superblock the sixteen pair-count bases and their four row sums
+    __shared__ uint4 s_fe[512]; // first_ext: [byte] the full interval extended by byte, [256 + byte] extended by 0 and then by byte (packed like a seed entry)
     extern __shared__ __align__(16) unsigned char pgx_dyn_lds[];
-    uint32_t *s_pt = reinterpret_cast<uint32_t *>(pgx_dyn_lds); // 8 dwords per special-run count
+    uint32_t *s_rd = reinterpret_cast<uint32_t *>(pgx_dyn_lds); // PACKED: word w of this thread's read at s_rd[w * blockDim.x + threadIdx.x] (pk_words words per thread)
+    const uint32_t rd_stride = blockDim.x;
     for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) s_ext[i] = img.consts->ext_tab[i];
-    if (threadIdx.x < 8) s_C[threadIdx.x] = (uint32_t)img.consts->C[threadIdx.x];
-    if (threadIdx.x < 32) s_t2[threadIdx.x] = img.consts->pair_t2[threadIdx.x];
+    if (threadIdx.x < 8) s_C[threadIdx.x] = (pos_t)img.consts->C[threadIdx.x];
+    if (threadIdx.x < 32) s_t2[threadIdx.x] = (pos_t)img.consts->pair_t2w[threadIdx.x];
+    if (WIDE) for (uint32_t i = threadIdx.x; i < img.n_sbp * 24u; i += blockDim.x) s_pb[i] = img.pbase[i];
     for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) s_fe[i] = img.first_ext[i];
-    for (uint32_t i = threadIdx.x; i < (img.pair_runs + 1u) * 8u; i += blockDim.x) s_pt[i] = img.ptab[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const uint32_t n = (uint32_t)img.n;
-    const uint32_t mo = min_occ > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)min_occ; // sizes are below 2^32: a larger min_occ makes everything "small" either way
-    const bool mo_huge = min_occ > 0xFFFFFFFFull;
+    const pos_t n = (pos_t)img.n;
+    const pos_t mo = WIDE ? (pos_t)min_occ : (pos_t)(min_occ > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)min_occ); // narrow: sizes are below 2^32, a larger min_occ makes everything "small" either way
+    const bool mo_huge = !WIDE && min_occ > 0xFFFFFFFFull;
+    // an entry of the seed tables / first_ext: {k lo, k' lo, s lo, k hi | k' hi << 8 | s hi << 16 | depth << 24}
+    auto ent_k = [](const uint4 &e) { return WIDE ? (pos_t)((uint64_t)e.x | ((uint64_t)(e.w & 0xFFu) << 32)) : (pos_t)e.x; };
+    auto ent_q = [](const uint4 &e) { return WIDE ? (pos_t)((uint64_t)e.y | ((uint64_t)((e.w >> 8) & 0xFFu) << 32)) : (pos_t)e.y; };
+    auto ent_s = [](const uint4 &e) { return WIDE ? (pos_t)((uint64_t)e.z | ((uint64_t)((e.w >> 16) & 0xFFu) << 32)) : (pos_t)e.z; };
     uint32_t rid = 0; // (the launch serves fewer than 2^32 reads: pgx_batch_run)
     uint64_t base = 0;
     int32_t len = 0, x = 0, j = 0;
-    uint32_t k = 0, kp = 0, s = 0, Jk = 0, Js = 0;
+    pos_t k = 0, kp = 0, s = 0, Jk = 0, Js = 0;
     uint32_t nm = 0, next = 0, next0 = 0, nextb = 0; // nextb: value of `next` when the current start position was begun
     int ph = 0;
     uint64_t win = 0, win_hi = 0;
     uint32_t win_at = ~0u; // the cached 16 bytes of the reads buffer: their offset / 16 (16 rather than 32 bytes: four registers less, no difference in time)
-    uint32_t X0a = 0, X0b = 0, X0c = 0, X0d = 0, X0e = 0, X0f = 0, ri0 = 0; // sums over the first block of an interval that runs on into the next
+    uint32_t X0a = 0, X0b = 0, X0c = 0, X0d = 0; // sums over the first block of an interval that runs on into the next
+    pos_t X0e = 0, X0f = 0;                                   // ... and the two absolute ranks at its start
     uint32_t pend = 0, fresh = 0, restart = 0;
     uint64_t rnext = 0, rend = 0;
     bool exhausted = false;
@@ -999,6 +1089,11 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 else {
                     base = offsets[rid];
                     len = (int32_t)(offsets[rid + 1] - base);
+                    if (PACKED) { // the read's packed words into this thread's LDS column (the host sized pk_words for the longest read of the launch)
+                        const uint32_t *src = packed + (base >> 4);
+                        const uint32_t nw = ((uint32_t)(base & 15ull) + (uint32_t)len + 15u) >> 4;
+                        for (uint32_t w = 0; w < nw; w++) s_rd[w * rd_stride + threadIdx.x] = src[w];
+                    }
                     x = 0; nm = 0;
                     next0 = next;
                     begin();
@@ -1036,6 +1131,12 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                     const int32_t K = endw ? (int32_t)img.seed_end_k : (int32_t)img.seed_k;
                     const int32_t avail = (ph == 1) ? (j - x + 1) : (j - x);
                     if (K && avail >= K + (endw ? 1 : 0)) {
+                        if (PACKED) { // the window's 2 K bits of the packed read are the index
+                            const uint32_t q = (uint32_t)(base & 15ull) + (uint32_t)((endw ? len - 1 : j) - K + 1);
+                            const uint32_t w0 = s_rd[(q >> 4) * rd_stride + threadIdx.x], w1 = s_rd[((q >> 4) + 1u) * rd_stride + threadIdx.x]; // (one word of padding per thread)
+                            const uint32_t sidx = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (2u * (q & 15u))) & ((1u << (2 * K)) - 1u);
+                            seed_lane = true; sp = (endw ? img.seed_end : img.seed) + sidx; kuse = (uint32_t)K + (endw ? 1u : 0u);
+                        } else {
                         const uint64_t a = base + (uint64_t)((endw ? len - 1 : j) - K + 1);
                         const uint32_t sh = (uint32_t)(a & 7ull) * 8u;
                         const uint64_t *wp = reinterpret_cast<const uint64_t *>(reads + (a & ~7ull));
@@ -1043,6 +1144,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                         const uint64_t lo = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0, hi = sh ? (w1 >> sh) | (w2 << (64u - sh)) : w1;
                         uint32_t sidx;
                         if (pgx_seed_index(lo, hi, (uint32_t)K, sidx)) { seed_lane = true; sp = (endw ? img.seed_end : img.seed) + sidx; kuse = (uint32_t)K + (endw ? 1u : 0u); }
+                        }
                     }
                 }
                 se = *sp;
@@ -1054,6 +1156,16 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             // its first TWO extensions (by 0, then by the last symbol of the read) come from first_ext: the rows of the endmarkers
             // (block 0 of the image) have the sequences' last symbols before them, often N
             const bool at_end = j >= len;
+            uint32_t byte, byte2;
+            bool have2;
+            if (PACKED) { // both symbols from the packed read in LDS ("ACTG"[code]); the second one is always at hand
+                const uint32_t qa = (uint32_t)(base & 15ull) + (uint32_t)(at_end ? len : j);
+                const uint32_t q1 = at_end ? qa - 1u : qa, q2 = (fwd && !at_end) ? qa + 1u : (qa ? qa - 1u : 0u); // (q2 is meaningless where the stage has no second symbol: rem2)
+                const uint32_t wa = s_rd[(q1 >> 4) * rd_stride + threadIdx.x], wb = s_rd[(q2 >> 4) * rd_stride + threadIdx.x];
+                byte = at_end ? 0u : ((0x47544341u >> (8u * ((wa >> (2u * (q1 & 15u))) & 3u))) & 0xFFu);
+                byte2 = (0x47544341u >> (8u * ((wb >> (2u * (q2 & 15u))) & 3u))) & 0xFFu;
+                have2 = true;
+            } else {
             const uint64_t atw = at_end ? at - 1ull : at; // (a live read has len >= 1)
             if ((uint32_t)(atw >> 4) != win_at) {
                 win_at = (uint32_t)(atw >> 4);
@@ -1062,31 +1174,32 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             }
             // (a function of values: as a lambda capturing the window by reference it turned into loads through a selected address,
             //  with the window in scratch memory)
-            const uint32_t byte = at_end ? 0u : pgx_window_byte(win, win_hi, at);
+            byte = at_end ? 0u : pgx_window_byte(win, win_hi, at);
             // the symbol after this one in the direction of the stage, when the cached window holds it
             const uint64_t at2 = (fwd && !at_end) ? at + 1ull : at - 1ull;
-            const bool have2 = (uint32_t)(at2 >> 4) == win_at;
-            const uint32_t byte2 = pgx_window_byte(win, win_hi, at2);
+            have2 = (uint32_t)(at2 >> 4) == win_at;
+            byte2 = pgx_window_byte(win, win_hi, at2);
+            }
             const uint32_t e1 = s_ext[(fwd ? 256u : 0u) + byte], e2 = s_ext[(fwd ? 256u : 0u) + byte2];
             const uint32_t cv1 = PGX_EXT_CV(e1), cv2 = PGX_EXT_CV(e2);
             const bool reg1 = !PGX_EXT_KILL(e1) && ((0x2Eu >> cv1) & 1u), reg2 = !PGX_EXT_KILL(e2) && ((0x2Eu >> cv2) & 1u); // A C G T
             const uint32_t t1 = reg1 ? cv1 - 1u - (cv1 >> 2) : 0u, t2 = reg2 ? cv2 - 1u - (cv2 >> 2) : 0u;                    // their 2-bit codes
             const bool rem2 = ph == 1 ? (j - 1 >= x) : (fwd ? (j + 1 < len) : (j - 1 > x)); // the stage has a second extension to make
             const bool two = !fr && rem2 && have2 && reg1 && reg2;
-            const uint32_t kk = fwd ? kp : k, kq = fwd ? k : kp;
-            const uint32_t p0 = kk, p1 = kk + s;
+            const pos_t kk = fwd ? kp : k, kq = fwd ? k : kp;
+            const pos_t p0 = kk, p1 = kk + s;
             // the block of p0 (96 positions); a second trip (pend) reads the block after it
-            const uint32_t bfirst = (uint32_t)(((uint64_t)(p0 >> 5) * 0xAAAAAAABull) >> 33); // p0 / 96
-            const uint32_t endrel = p1 - bfirst * PGX_PAIRS_SYMS;                             // p1 relative to the first block
+            const uint32_t bfirst = (uint32_t)(((uint64_t)(p0 >> 5) * 0xAAAAAAABull) >> 33); // p0 / 96 (p0 < 2^37)
+            const pos_t endrel_p = p1 - (pos_t)bfirst * PGX_PAIRS_SYMS;                       // p1 relative to the first block
+            const uint32_t endrel = endrel_p > (pos_t)0xFFFFu ? 0xFFFFu : (uint32_t)endrel_p; // (anything beyond two blocks is "far")
             const uint32_t relA = pend ? 0u : p0 - bfirst * PGX_PAIRS_SYMS;
             const uint32_t relB = pend ? endrel - PGX_PAIRS_SYMS : (endrel < PGX_PAIRS_SYMS ? endrel : PGX_PAIRS_SYMS);
             const uint4 *bp = img.pairs + (size_t)(bfirst + pend) * 8;
             const uint4 row = bp[t1];                                                          // pairs (t1, A C G T) before the block
-            const uint32_t hw = reinterpret_cast<const uint32_t *>(bp)[16];
+            const uint4 hs = bp[4];                                                            // positions before the block with c2 special and c1 = A, C, G, T; bit 31 of .x: flag
             const uint4 d0 = bp[5], d1 = bp[6], d2 = bp[7];                                    // planes: c1 bit 0, c1 bit 1, c2 bit 0, c2 bit 1, three dwords each
-            const bool flagged = (hw >> 31) != 0u;
-            const uint32_t ri = hw & 0x7FFFFFFFu;
-            const uint32_t pts = s_pt[8u * ri + 1u + t1];
+            const bool flagged = (hs.x >> 31) != 0u;
+            const uint32_t pts = t1 == 0u ? (hs.x & 0x7FFFFFFFu) : (t1 == 1u ? hs.y : (t1 == 2u ? hs.z : hs.w));
             // masks that turn "code == t" / "code > t" into plane expressions: (x ^ i0) & (y ^ i1) and (y & ua) | (x & (y | va) & wa)
             const uint32_t i0 = (t1 & 1u) ? 0u : 0xFFFFFFFFu, i1 = (t1 & 2u) ? 0u : 0xFFFFFFFFu, j0 = (t2 & 1u) ? 0u : 0xFFFFFFFFu, j1 = (t2 & 2u) ? 0u : 0xFFFFFFFFu;
             const uint32_t ua = t1 < 2u ? 0xFFFFFFFFu : 0u, va = t1 == 0u ? 0xFFFFFFFFu : 0u, wa = (t1 & 1u) ? 0u : 0xFFFFFFFFu;
@@ -1107,10 +1220,15 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 e1p += __popc(m1 & mP); e2p += __popc(q2 & mP);
                 e1r += __popc(m1 & mR); g1r += __popc(g1 & mR); e2r += __popc(q2 & mR); g2r += __popc(g2 & mR);
             }
-            const uint32_t a01 = row.x + row.y + row.z + row.w + pts + e1p;                       // rank of the first symbol at p0
-            const uint32_t a02 = (t2 == 0u ? row.x : (t2 == 1u ? row.y : (t2 == 2u ? row.z : row.w))) + e2p; // rank of the pair at p0
+            pos_t a01 = (pos_t)(row.x + row.y + row.z + row.w + pts + e1p);                       // rank of the first symbol at p0
+            pos_t a02 = (pos_t)((t2 == 0u ? row.x : (t2 == 1u ? row.y : (t2 == 2u ? row.z : row.w))) + e2p); // rank of the pair at p0
+            if (WIDE) { // the counts of a block are deltas against its superblock
+                const uint64_t *pb = s_pb + (size_t)((bfirst + pend) >> img.pairs_sb_shift) * 24u;
+                a01 += (pos_t)pb[16u + t1];
+                a02 += (pos_t)pb[4u * t1 + t2];
+            }
             const bool straddle = endrel > PGX_PAIRS_SYMS, far = endrel > 2u * PGX_PAIRS_SYMS;
-            const bool bail = !fr && (flagged || far || (pend && ri != ri0));
+            const bool bail = !fr && (flagged || far); // (a second block is used only when it is not flagged either: nothing special between the two ends)
             const bool wait = !fr && !pend && straddle && !bail; // the interval runs on into the next block: next trip
 #ifdef PGX_FM_STATS
             st_wait += wait ? 1ull : 0ull;
@@ -1122,25 +1240,26 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 redo_list[atomicAdd(redo_count, 1ull)] = it;
                 ph = 0; next = nextb; pend = 0u;
             } else if (wait) {
-                X0a = e1r; X0b = g1r; X0c = e2r; X0d = g2r; X0e = a01; X0f = a02; ri0 = ri;
+                X0a = e1r; X0b = g1r; X0c = e2r; X0d = g2r; X0e = a01; X0f = a02;
                 pend = 1u;
             } else {
                 const uint32_t c1 = pend ? X0a + e1r : e1r, w1 = pend ? X0b + g1r : g1r, c2 = pend ? X0c + e2r : e2r, w2 = pend ? X0d + g2r : g2r;
-                const uint32_t r1 = pend ? X0e : a01, r2 = pend ? X0f : a02;
+                const pos_t r1 = pend ? X0e : a01, r2 = pend ? X0f : a02;
                 pend = 0u;
                 // first extension (src/r-index.cpp:713-764); a symbol that is not A C G T has no occurrence in a range free of special positions
-                uint32_t s1 = reg1 ? c1 : 0u;
-                uint32_t k1 = r1 + s_C[PGX_EXT_V(e1)], q1v = kq + w1;
-                if (fr) { const uint4 f = s_fe[byte]; k1 = f.x; q1v = f.y; s1 = f.z; }
+                pos_t s1 = reg1 ? (pos_t)c1 : (pos_t)0;
+                pos_t k1 = r1 + s_C[PGX_EXT_V(e1)], q1v = kq + (pos_t)w1;
+                if (fr) { const uint4 f = s_fe[byte]; k1 = ent_k(f); q1v = ent_q(f); s1 = ent_s(f); }
                 const bool small1 = s1 == 0u || s1 < mo || mo_huge;
                 // a usable seed entry stands for the first extension and the ones after it
                 const uint32_t sdepth = se.w >> 24;
-                const bool seed_alive = SEED && seed_lane && se.z != 0u && se.z >= mo && !mo_huge;
-                const bool seed_dead = SEED && seed_lane && se.z == 0u && sdepth != PGX_SEED_UNUSABLE && min_occ <= 1;
+                const pos_t se_s = ent_s(se);
+                const bool seed_alive = SEED && seed_lane && se_s != 0u && se_s >= mo && !mo_huge;
+                const bool seed_dead = SEED && seed_lane && se_s == 0u && sdepth != PGX_SEED_UNUSABLE && min_occ <= 1;
                 const bool do2 = (fr ? (at_end && rem2 && have2 && !seed_alive && !seed_dead) : two) && !small1;
-                uint32_t s2 = c2, k2 = r2 + s_C[PGX_EXT_V(e2)] + s_t2[8u * t1 + cv2], q2v = q1v + w2;
-                if (fr) { const uint4 f = s_fe[256u + byte2]; k2 = f.x; q2v = f.y; s2 = f.z; }
-                uint32_t ns = do2 ? s2 : s1, nk = do2 ? k2 : k1, nq = do2 ? q2v : q1v;
+                pos_t s2 = (pos_t)c2, k2 = r2 + s_C[PGX_EXT_V(e2)] + s_t2[8u * t1 + cv2], q2v = q1v + (pos_t)w2;
+                if (fr) { const uint4 f = s_fe[256u + byte2]; k2 = ent_k(f); q2v = ent_q(f); s2 = ent_s(f); }
+                pos_t ns = do2 ? s2 : s1, nk = do2 ? k2 : k1, nq = do2 ? q2v : q1v;
                 if (ns == 0u) { nk = 0u; nq = 0u; }
                 if (do2) { // the first of the two: what a trip of its own would have left behind
                     Jk = fwd ? q1v : Jk;
@@ -1153,7 +1272,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 kp = fwd ? nk : nq;
                 bool small = ns == 0u || ns < mo || mo_huge;
                 if (seed_alive) { // all its extensions at once: sizes only shrink along a stage, so none of the skipped ones was "small"
-                    k = se.x; kp = se.y; s = se.z;
+                    k = ent_k(se); kp = ent_q(se); s = se_s;
                     small = false;
                     j -= (int32_t)kuse - 1;
                     next += kuse - 1u;
@@ -1191,12 +1310,15 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     if (lane == 0) { atomicAdd(n_ext_total + PGX_CTR_ST_PAIR_TRIPS, st_trips); atomicAdd(n_ext_total + PGX_CTR_ST_PAIR_LIVE, st_live); atomicAdd(n_ext_total + PGX_CTR_ST_PAIR_WAIT, st_wait); atomicAdd(n_ext_total + PGX_CTR_ST_PAIR_FRESH, st_fresh); }
 #endif
 }
-template __global__ void pgx_find_mems_pairs_kernel<false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t, const uint64_t *, pgx_mem *,
-                                                           uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t, uint32_t, uint32_t,
-                                                           pgx_heavy_item *, unsigned long long *, pgx_heavy_item *, unsigned long long *, const uint8_t *);
-template __global__ void pgx_find_mems_pairs_kernel<true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t, const uint64_t *, pgx_mem *,
-                                                          uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t, uint32_t, uint32_t,
-                                                          pgx_heavy_item *, unsigned long long *, pgx_heavy_item *, unsigned long long *, const uint8_t *);
+#define PGX_PAIRS_INSTANTIATE(...)                                                                                                                \
+    template __global__ void pgx_find_mems_pairs_kernel<__VA_ARGS__>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t, const uint64_t *, \
+                                                                     pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t, uint32_t, \
+                                                                     uint32_t, pgx_heavy_item *, unsigned long long *, pgx_heavy_item *, unsigned long long *,       \
+                                                                     const uint8_t *, const uint32_t *, uint32_t);
+PGX_PAIRS_INSTANTIATE(true, false, false)
+PGX_PAIRS_INSTANTIATE(true, true, false)
+PGX_PAIRS_INSTANTIATE(true, false, true)
+PGX_PAIRS_INSTANTIATE(true, true, true)
 
 // first extension of every backward stage: the full interval extended by each byte value
 __global__ void __launch_bounds__(256) pgx_first_ext_kernel(PgxDevImage img, uint4 *__restrict__ out) { // out[512]
@@ -1205,11 +1327,14 @@ __global__ void __launch_bounds__(256) pgx_first_ext_kernel(PgxDevImage img, uin
     pgx_stage_tables<false>(img, s_ext, s_C, nullptr, nullptr, nullptr);
     uint64_t k = 0, kp = 0, s = img.n;
     pgx_extend<false>(img, nullptr, nullptr, nullptr, s_ext, s_C, k, kp, s, threadIdx.x, false);
-    out[threadIdx.x] = make_uint4((uint32_t)k, (uint32_t)kp, (uint32_t)s, 0u);
+    auto pack = [](uint64_t k_, uint64_t q_, uint64_t s_) { // like a seed entry: low dwords, then the bits 32..39 of each
+        return make_uint4((uint32_t)k_, (uint32_t)q_, (uint32_t)s_, (uint32_t)((k_ >> 32) & 0xFFu) | ((uint32_t)((q_ >> 32) & 0xFFu) << 8) | ((uint32_t)((s_ >> 32) & 0xFFu) << 16));
+    };
+    out[threadIdx.x] = pack(k, kp, s);
     k = 0; kp = 0; s = img.n; // by 0 (what pattern[len] reads as), then by the byte
     pgx_extend<false>(img, nullptr, nullptr, nullptr, s_ext, s_C, k, kp, s, 0u, false);
     if (s) pgx_extend<false>(img, nullptr, nullptr, nullptr, s_ext, s_C, k, kp, s, threadIdx.x, false);
-    out[256 + threadIdx.x] = make_uint4((uint32_t)k, (uint32_t)kp, (uint32_t)s, 0u);
+    out[256 + threadIdx.x] = pack(k, kp, s);
 }
 
 // find_mems_function(pattern, min_len, min_occ, x) (algorithm.hpp:653-736) for ONE start position: the MEM it emits (if any), the

@@ -48,7 +48,7 @@ static void use_device(int device) {
 struct pgx_device_image {
     int device = -1;
     PgxDevImage img{};
-    DevBuf blocks, dir, blow, consts, tstart, tvals, tdir, tpair, seed, seed_small, seed_end, exc, pairs, ptab, first_ext;
+    DevBuf blocks, dir, blow, consts, tstart, tvals, tdir, tpair, seed, seed_small, seed_end, exc, pairs, first_ext, sbase2, pbase;
     DevBuf rstart, rsamp, rdir, lpos, lnext, ldir; // locate image, uploaded on first use
     DevBuf lit_bstart, lit_cum, lit_runs, lit_roff, lit_tabs; // literal count image (quirk 3), uploaded on first use
     PgxLitImage lit{};
@@ -63,7 +63,7 @@ void pgx_release_device_images(pgx_index *h) {
         if (!d) continue;
         if (hipSetDevice(d->device) == hipSuccess) {
             d->blocks.release(); d->dir.release(); d->blow.release(); d->consts.release();
-            d->tstart.release(); d->tvals.release(); d->tdir.release(); d->tpair.release(); d->seed.release(); d->seed_small.release(); d->seed_end.release(); d->exc.release(); d->pairs.release(); d->ptab.release(); d->first_ext.release();
+            d->tstart.release(); d->tvals.release(); d->tdir.release(); d->tpair.release(); d->seed.release(); d->seed_small.release(); d->seed_end.release(); d->exc.release(); d->pairs.release(); d->first_ext.release(); d->sbase2.release(); d->pbase.release();
             d->lit_bstart.release(); d->lit_cum.release(); d->lit_runs.release(); d->lit_roff.release(); d->lit_tabs.release();
             d->rstart.release(); d->rsamp.release(); d->rdir.release(); d->lpos.release(); d->lnext.release(); d->ldir.release();
         }
@@ -177,27 +177,34 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
     g.excl_mask = m.consts.excl_mask;
     g.tag_dir_shift = m.consts.tag_dir_shift;
     g.dense = m.consts.image_kind; // PGX_IMAGE_RL / _DENSE / _DENSE2
+    g.wide = m.consts.wide;
+    if (g.dense == PGX_IMAGE_DENSE2 && g.wide) g.dense = 3; // dense2 blocks with delta counts: the 64-bit kernels (pgx_image.h "WIDE")
+    upload(d->sbase2, m.sbase2.data(), m.sbase2.size() * 8);
+    g.sbase2 = d->sbase2.as<uint64_t>();
+    g.d2_sb_shift = m.consts.d2_sb_shift; g.n_sb2 = m.consts.n_sb2;
+    g.pbase = nullptr; g.pairs_sb_shift = 0; g.n_sbp = 0;
     g.exc = d->exc.as<uint32_t>();
     size_t img_bytes = m.blocks.size() + m.dir.size() * 8 + m.blow.size() * 2;
     if (g.dense == 1) img_bytes = (size_t)m.consts.n_blocks * 16 * PGX_DENSE_LDS_U4 + 16; // padded blocks, no directory (pgx_dense_load)
-    d->lds_bytes = (g.dense != 2 && img_bytes <= 48 * 1024) ? ((img_bytes + 15) & ~(size_t)15) : 0; // the dense2 image is never staged in LDS
+    d->lds_bytes = (g.dense < 2 && img_bytes <= 48 * 1024) ? ((img_bytes + 15) & ~(size_t)15) : 0; // the dense2 image is never staged in LDS
     g.seed_k = 0;
     g.seed = nullptr;
     g.seed_end_k = 0;
     g.seed_end = nullptr;
     g.seed_k_main = g.seed_k_small = 0;
     g.seed_main = g.seed_small = nullptr;
-    g.pairs = nullptr; g.ptab = nullptr; g.first_ext = nullptr; g.pair_runs = 0;
+    g.pairs = nullptr; g.first_ext = nullptr; g.pair_runs = 0;
     if (g.dense && h->has_rank) build_seed_table(d.get());
     if (m.consts.has_pairs && !m.pairs.empty() && h->has_rank) { // the two-step image next to dense2 (pgx_image.h)
         upload(d->pairs, m.pairs.data(), m.pairs.size());
-        upload(d->ptab, m.ptab.data(), m.ptab.size() * 4);
+        upload(d->pbase, m.pbase.data(), m.pbase.size() * 8);
+        g.pbase = d->pbase.as<uint64_t>();
+        g.pairs_sb_shift = m.consts.pairs_sb_shift; g.n_sbp = m.consts.n_sbp;
         d->first_ext.ensure(512 * sizeof(uint4));
         hipLaunchKernelGGL(pgx_first_ext_kernel, dim3(1), dim3(256), 0, nullptr, g, d->first_ext.as<uint4>());
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipDeviceSynchronize());
         g.pairs = d->pairs.as<uint4>();
-        g.ptab = d->ptab.as<uint32_t>();
         g.first_ext = d->first_ext.as<uint4>();
         g.pair_runs = m.consts.pair_runs;
     }
@@ -874,7 +881,8 @@ struct pgx_batch {
     uint64_t plan_min_len = 0, plan_budget = 0;
     DevBuf reads, offsets;
     // run state
-    DevBuf slot_off, slots, mem_count, mem_off, mems, scan_tmp, counters, heavy_list, heavy_scratch, redo_list, read_flags, side_list, side_count;
+    DevBuf slot_off, slots, mem_count, mem_off, mems, scan_tmp, counters, heavy_list, heavy_scratch, redo_list, read_flags, side_list, side_count, packed;
+    uint64_t max_read_len = 0; // longest read of the upload (sizes the LDS columns of the packed pairs kernel)
     TagWork tw;
     uint64_t n_mems = 0, n_positions = 0, n_ext = 0, n_tag_overflow = 0;
     bool ran = false, ran_tags = false;
@@ -895,7 +903,7 @@ static void batch_release(pgx_batch *b) {
     if (!b) return;
     if (hipSetDevice(b->device) == hipSuccess) {
         DevBuf *all[] = {&b->reads, &b->offsets, &b->slot_off, &b->slots, &b->mem_count, &b->mem_off, &b->mems, &b->scan_tmp,
-                         &b->counters, &b->heavy_list, &b->heavy_scratch, &b->redo_list, &b->read_flags, &b->side_list, &b->side_count};
+                         &b->counters, &b->heavy_list, &b->heavy_scratch, &b->redo_list, &b->read_flags, &b->side_list, &b->side_count, &b->packed};
         for (DevBuf *d : all) d->release();
         b->tw.release();
         HostBuf *hb[] = {&b->h_mem_off, &b->h_mems, &b->h_run_nums, &b->h_pos_off, &b->h_positions};
@@ -929,6 +937,8 @@ static void batch_upload(pgx_batch *b, const uint8_t *reads, const uint64_t *off
     if (b->read_bytes) HIPCHECK(hipMemcpyAsync(b->reads.p, reads + lo, b->read_bytes, hipMemcpyHostToDevice, b->own));
     b->h_offsets.resize(n_reads + 1);
     for (uint64_t i = 0; i <= n_reads; i++) b->h_offsets[i] = offsets[i] - lo;
+    b->max_read_len = 0;
+    for (uint64_t i = 0; i < n_reads; i++) b->max_read_len = std::max(b->max_read_len, offsets[i + 1] - offsets[i]);
     b->offsets.ensure((n_reads + 1) * 8);
     HIPCHECK(hipMemcpyAsync(b->offsets.p, b->h_offsets.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, b->own));
     HIPCHECK(hipStreamSynchronize(b->own));
@@ -1057,10 +1067,11 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     if (n) {
         // persistent grid: as many workgroups as the device keeps resident (no inter-workgroup
         // dependency exists, so any grid size is correct; this one avoids a tail of late blocks)
-        const bool in_lds = b->dimg->lds_bytes != 0, dense = img.dense != 0, d2 = img.dense == 2;
+        const bool in_lds = b->dimg->lds_bytes != 0, dense = img.dense != 0, d2 = img.dense == 2, d3 = img.dense == 3;
         const bool seeded = img.seed_k != 0 && min_len >= img.seed_k; // (no stage of a shorter search has room for a seed)
         kfn_wide = in_lds ? (dense ? (seeded ? (const void *)pgx_find_mems_kernel<true, 1, false, true> : (const void *)pgx_find_mems_kernel<true, 1, false, false>)
                                    : (const void *)pgx_find_mems_kernel<true, 0, false, false>)
+                   : d3   ? (seeded ? (const void *)pgx_find_mems_kernel<false, 3, false, true> : (const void *)pgx_find_mems_kernel<false, 3, false, false>)
                    : d2   ? (seeded ? (const void *)pgx_find_mems_kernel<false, 2, false, true> : (const void *)pgx_find_mems_kernel<false, 2, false, false>)
                           : (dense ? (seeded ? (const void *)pgx_find_mems_kernel<false, 1, false, true> : (const void *)pgx_find_mems_kernel<false, 1, false, false>)
                                    : (const void *)pgx_find_mems_kernel<false, 0, false, false>);
@@ -1069,7 +1080,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         const char *nv = std::getenv("PGX_FM_NARROW");
         bool c_fits = true; // C[] comes straight from the file: a (corrupt) value beyond 2^32 must not be truncated by the 32-bit state
         for (int i = 0; i < 8; i++) c_fits = c_fits && !(b->h->img.consts.C[i] >> 32);
-        if (dense && img.n < (1ull << 30) && c_fits && !(nv && nv[0] == '0'))
+        if (dense && !d3 && img.n < (1ull << 30) && c_fits && !(nv && nv[0] == '0'))
             kfn = in_lds ? (seeded ? (const void *)pgx_find_mems_kernel<true, 1, true, true> : (const void *)pgx_find_mems_kernel<true, 1, true, false>)
                   : d2   ? (seeded ? (const void *)pgx_find_mems_kernel<false, 2, true, true> : (const void *)pgx_find_mems_kernel<false, 2, true, false>)
                          : (seeded ? (const void *)pgx_find_mems_kernel<false, 1, true, true> : (const void *)pgx_find_mems_kernel<false, 1, true, false>);
@@ -1077,8 +1088,9 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         // above then serves the reads the pairs kernel hands on
         const char *pv = std::getenv("PGX_FM_PAIRS");
         // (only behind the seed table: the wide intervals at the start of an unseeded stage always have special positions between their ends)
-        if (img.pairs && seeded && !(n >> 32) && b->read_bytes < (1ull << 35) && !(pv && pv[0] == '0')) kfn_pairs = (const void *)pgx_find_mems_pairs_kernel<true>;
-        pairs_lds = ((size_t)img.pair_runs + 1) * 32;
+        if (img.pairs && seeded && !(n >> 32) && b->read_bytes < (1ull << 35) && !(pv && pv[0] == '0'))
+            kfn_pairs = img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, false> : (const void *)pgx_find_mems_pairs_kernel<true, false, false>;
+        pairs_lds = 0;
         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn_pairs ? kfn_pairs : kfn, PGX_FM_THREADS, kfn_pairs ? pairs_lds : b->dimg->lds_bytes));
         HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
         if (occ < 1) occ = 1;
@@ -1150,11 +1162,12 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                         b->side_list.ensure((cn ? cn : 1) * sizeof(pgx_heavy_item));
                         b->side_count.ensure(16);
                         b->scan_tmp.ensure(cap * 8);
+                        b->packed.ensure(((b->read_bytes + 15) / 16 + 64) * 4); // the reads as two bits per symbol (written by the same pass)
                         HIPCHECK(hipMemsetAsync(b->side_count.p, 0, 16, s));
                         HIPCHECK(hipMemsetAsync(b->read_flags.p, 0, ((cn + 3) & ~3ull) + 4, s));
                         unsigned long long *d_bad = b->side_count.as<unsigned long long>() + 1;
                         hipLaunchKernelGGL(pgx_bad_chunks_kernel, dim3(std::min<unsigned>(grid_for((b->read_bytes + 15) / 16, 256), (unsigned)cus * 16u)), dim3(256), 0, s,
-                                           a_reads, b->read_bytes, b->scan_tmp.as<uint64_t>(), d_bad, cap);
+                                           a_reads, b->read_bytes, b->scan_tmp.as<uint64_t>(), d_bad, cap, b->packed.as<uint32_t>());
                         HIPCHECK(hipGetLastError());
                         unsigned long long n_bad = 0;
                         read_scalars(&n_bad, d_bad, sizeof n_bad, s);
@@ -1183,9 +1196,32 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                 }
                 pgx_heavy_item *a_redo = b->redo_list.as<pgx_heavy_item>();
                 unsigned long long *a_redo_n = d_redo_count;
+                // the reads from LDS, two bits per symbol, when every read the launch serves is pure A C G T (the others are skipped) and a
+                // thread's column stays small enough for four workgroups per CU (reads up to ~350 bp); PGX_FM_PACKED=0 switches it off
+                const void *kp = kfn_pairs;
+                size_t plds = pairs_lds;
+                const uint32_t *a_packed = nullptr;
+                uint32_t a_pkw = 0;
+                unsigned pgrid = grid;
+                {
+                    const uint32_t pkw = (uint32_t)((15 + b->max_read_len + 15) >> 4) + 1u; // words of the longest read at the worst phase + one of padding
+                    const char *pe = std::getenv("PGX_FM_PACKED");
+                    if (a_skip && pkw <= 24 && !(pe && pe[0] == '0')) {
+                        kp = img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, true> : (const void *)pgx_find_mems_pairs_kernel<true, false, true>;
+                        a_packed = b->packed.as<uint32_t>();
+                        a_pkw = pkw;
+                        plds = (size_t)pkw * PGX_FM_THREADS * 4;
+                        int occ_p = 0;
+                        HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_p, kp, PGX_FM_THREADS, plds));
+                        if (occ_p < 1) occ_p = 1;
+                        if (const char *e = std::getenv("PGX_FM_WG_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v < occ_p) occ_p = v; }
+                        else occ_p = (int)std::min<uint64_t>((uint64_t)occ_p, std::max<uint64_t>(2, cn / (5ull * (uint64_t)cus * PGX_FM_THREADS)));
+                        pgrid = std::min(grid_for(cn, 64), (unsigned)(occ_p * cus));
+                    }
+                }
                 void *pargs[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_first, &a_base,
-                                 &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_redo, &a_redo_n, &a_skip};
-                HIPCHECK(hipLaunchKernel(kfn_pairs, dim3(grid), dim3(PGX_FM_THREADS), pargs, pairs_lds, s));
+                                 &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_redo, &a_redo_n, &a_skip, &a_packed, &a_pkw};
+                HIPCHECK(hipLaunchKernel(kp, dim3(pgrid), dim3(PGX_FM_THREADS), pargs, plds, s));
                 record(b, 8, s);
                 a_rlist = a_redo; a_rcount = d_redo_count; a_cur = d_redo_cursor;
                 // the few reads handed on have the device to themselves: the launch lasts as long as its longest read, and a read that ends a

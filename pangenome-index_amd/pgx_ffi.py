@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("PGX_LIB") or os.path.join(PKG_DIR, "libpgx.so")  # PG
 OK, ERR_IO, ERR_FORMAT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_ARG, ERR_NOMEM = range(8)
 MODE_COMPAT, MODE_STRICT = 0, 1
 MODE_IMAGE_RL, MODE_IMAGE_DENSE, MODE_IMAGE_DENSE2, MODE_IMAGE_PAIRS = 0x100, 0x200, 0x400, 0x800  # or-ed into mode: force the layout of the device rank image
+MODE_IMAGE_WIDE = 0x1000  # modifier: the 64-bit form of dense2 / pairs
 IMAGE_RL, IMAGE_DENSE, IMAGE_DENSE2 = 0, 1, 2
 TAGS_AUTO, TAGS_BYTECODE, TAGS_COMPACT = 0, 1, 2
 RUN_TAGS, RUN_TIMING = 1, 2
@@ -33,6 +34,7 @@ class IndexInfo(C.Structure):
         ("mode", u32), ("has_tags", u32), ("tag_format", u32), ("n_tag_runs", u64), ("tag_dir_entries", u64),
         ("tag_dir_shift", u32), ("image_in_lds", u32), ("image_bytes", u64), ("tag_image_bytes", u64),
         ("ref_block_mean_bytes", C.c_double), ("max_length", u64), ("n_samples", u64), ("image_kind", u32), ("image_pairs", u32),
+        ("image_wide", u32), ("reserved_info", u32),
     ]
 
 
@@ -179,6 +181,12 @@ def build_index_from_text(text_path, out_rlbwt_path, out_ri_path, encoded=True):
                                            1 if encoded else 0))
 
 
+def build_index_from_texts(text_paths, out_rlbwt_path, out_ri_path, encoded=True):
+    arr = (C.c_char_p * len(text_paths))(*[t.encode() for t in text_paths])
+    _check(lib().pgx_build_index_from_texts(arr, len(text_paths), out_rlbwt_path.encode() if out_rlbwt_path else None, out_ri_path.encode(),
+                                            1 if encoded else 0))
+
+
 def write_compact_tags(out_path, values, lengths):
     v = np.ascontiguousarray(values, dtype=np.uint64)
     l = np.ascontiguousarray(lengths, dtype=np.uint64)
@@ -192,7 +200,7 @@ def convert_tags(in_path, out_path, compact=False):
 
 _VIEW_DTYPES = {0: np.uint8, 1: np.uint64, 2: np.uint64, 3: np.uint64, 4: np.uint64, 5: np.uint32, 6: np.uint8, 7: np.uint16,
                 8: np.uint64, 9: np.uint64, 10: np.uint32, 11: np.uint64, 12: np.uint64, 13: np.uint32, 14: np.uint8, 15: np.uint32,
-                16: np.uint64, 17: np.uint64, 18: np.uint64, 19: np.uint32, 20: np.uint32, 21: np.uint32}
+                16: np.uint64, 17: np.uint64, 18: np.uint64, 19: np.uint32, 20: np.uint32, 21: np.uint32, 22: np.uint64, 23: np.uint64}
 LOCATE_SEQ_IDS, LOCATE_UNIQUE = 1, 2
 NO_POSITION = 0xFFFFFFFFFFFFFFFF
 

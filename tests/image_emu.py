@@ -30,6 +30,8 @@ class Consts:
         self.image_kind, self.has_pairs = struct.unpack_from("<2I", raw, o); o += 8
         self.pair_t2 = struct.unpack_from("<32I", raw, o); o += 128
         self.pair_runs, _ = struct.unpack_from("<2I", raw, o); o += 8
+        self.wide, self.d2_sb_shift, self.pairs_sb_shift, self.n_sb2, self.n_sbp, _ = struct.unpack_from("<6I", raw, o); o += 24
+        self.pair_t2w = struct.unpack_from("<32Q", raw, o); o += 256
         assert o == len(raw), (o, len(raw))
 
 

@@ -191,3 +191,36 @@ def test_builder_clis(golden, workdir, built):
     assert r.returncode == 0 and O.Tags(out, O.TAGS_COMPACT).L.orc_tags_n_runs(O.Tags(out, O.TAGS_COMPACT).h) > 0
     r = subprocess.run([os.path.join(pkg, "build_rindex"), "/nonexistent.rl_bwt"], capture_output=True, timeout=120)
     assert r.returncode == 1
+
+
+def test_index_from_several_texts_equals_the_index_of_their_concatenation(workdir, built, monkeypatch):
+    """pgx_build_index_from_texts: one suffix array per text ("chromosome") and a k-way merge of the sorted suffix lists, split over
+    threads -- the files must be byte-identical to pgx_build_index_from_text on the concatenation (which reproduces the reference's
+    own .ri files byte for byte, above).  Chromosomes that share long stretches (the same base sequence) and N runs make the merge
+    compare far beyond its 21-symbol keys; one text is a single short sequence, one ends a sequence exactly like another."""
+    import pgx_workload as W
+
+    texts = []
+    for k, (bl, seed) in enumerate(((3000, 5), (2500, 5), (1800, 9), (40, 3))):
+        t = os.path.join(workdir, "multi_%d.txt" % k)
+        W.synth_pangenome_text(t, base_len=bl, n_hap=2 + (k % 2), seed=seed, snp=0.01, indel=0.002, n_runs=2, n_run_len=(10, 200))
+        texts.append(t)
+    dup = os.path.join(workdir, "multi_dup.txt")
+    open(dup, "wb").write(open(texts[2], "rb").read().split(b"\n")[0][-500:] + b"\nACGTNNNNACGT\n")
+    texts.append(dup)
+    cat = os.path.join(workdir, "multi_cat.txt")
+    with open(cat, "wb") as f:
+        for t in texts:
+            f.write(open(t, "rb").read())
+    one_rl, one_ri = os.path.join(workdir, "multi_one.rl_bwt"), os.path.join(workdir, "multi_one.ri")
+    P.build_index_from_text(cat, one_rl, one_ri, True)
+    for threads in ("1", "2", "5", "16"):
+        monkeypatch.setenv("PGX_BUILD_THREADS", threads)
+        many_rl, many_ri = os.path.join(workdir, "multi_many.rl_bwt"), os.path.join(workdir, "multi_many.ri")
+        P.build_index_from_texts(texts, many_rl, many_ri, True)
+        assert open(many_rl, "rb").read() == open(one_rl, "rb").read(), threads
+        assert open(many_ri, "rb").read() == open(one_ri, "rb").read(), threads
+    # and the single-text path still equals the two-step build with the reference's sampling walk
+    two_ri = os.path.join(workdir, "multi_two.ri")
+    P.build_rindex(one_rl, two_ri, True)
+    assert open(two_ri, "rb").read() == open(one_ri, "rb").read()

@@ -36,32 +36,25 @@ def _check(idx, bw):
     special = (y < 0) | (x < 0)
     pair = np.where(special, -1, 4 * y + x)
     blocks = idx.image_view(20).reshape(-1, 32)
-    ptab = idx.image_view(21).reshape(-1, 8)
     nb = n // 96 + 1
     assert len(blocks) == nb
-    # special runs
+    # special runs (statistics) and, per first symbol, the positions whose second symbol is special: what the pair counts do not see of it
     starts = np.flatnonzero(special & ~np.concatenate([[False], special[:-1]]))
-    assert c.pair_runs == len(starts) and len(ptab) == len(starts) + 1
-    run_of = np.cumsum(special & ~np.concatenate([[False], special[:-1]])) - 1  # run index of a special position
-    exp_pt = np.zeros((len(starts) + 1, 8), dtype=np.int64)
-    for r in range(len(starts)):
-        m = special & (run_of == r)
-        exp_pt[r + 1] = exp_pt[r]
-        exp_pt[r + 1, 0] += int(m.sum())
-        for yy in range(4):
-            exp_pt[r + 1, 1 + yy] += int((m & (y == yy) & (x < 0)).sum())
-    assert np.array_equal(ptab.astype(np.int64), exp_pt)
+    assert c.pair_runs == len(starts)
+    half = [np.concatenate([[0], np.cumsum((y == yy) & (x < 0))]) for yy in range(4)]  # half[yy][p] = such positions before p
+    n_special = np.concatenate([[0], np.cumsum(special)])
     cum = np.zeros(16, dtype=np.int64)
     for b in range(nb):
         s0, s1 = 96 * b, min(96 * b + 96, n)
         h = blocks[b]
         assert [int(v) for v in h[:16]] == list(cum), b
-        r = int((starts < s0).sum())
         flag = bool(special[s0:s1].any())
-        assert int(h[16]) == (r | (0x80000000 if flag else 0)), (b, hex(int(h[16])), r, flag)
-        assert [int(v) for v in h[17:20]] == [0, 0, 0]
-        if not flag:  # every position before an unflagged block is a regular pair or one of the special positions of ptab
-            assert s0 - int(cum.sum()) == int(ptab[r, 0])
+        assert int(h[16]) >> 31 == (1 if flag else 0), (b, hex(int(h[16])), flag)
+        assert [int(h[16]) & 0x7FFFFFFF] + [int(v) for v in h[17:20]] == [int(half[yy][s0]) for yy in range(4)], b
+        # every position before a block is a regular pair or a special position; rank of symbol y = its row sum + its half-special count
+        assert s0 - int(cum.sum()) == int(n_special[s0])
+        for yy in range(4):
+            assert int(cum[4 * yy:4 * yy + 4].sum()) + int(half[yy][s0]) == int((y[:s0] == yy).sum())
         for i in range(s1 - s0):
             pv = int(pair[s0 + i])
             bits = [(int(h[20 + 3 * pl + (i >> 5)]) >> (i & 31)) & 1 for pl in range(4)]
@@ -130,7 +123,6 @@ class PairsEmu:
     def __init__(self, idx):
         self.c = Consts(idx.image_view(6))
         self.blocks = idx.image_view(20).reshape(-1, 32)
-        self.ptab = idx.image_view(21).reshape(-1, 8)
 
     def _counts(self, b, rel_a, rel_b, t1, t2):
         h = self.blocks[b]
@@ -164,13 +156,12 @@ class PairsEmu:
         h = self.blocks[bf]
         if int(h[16]) >> 31:
             return None
-        ri = int(h[16]) & 0x7FFFFFFF
         e1p, e2p, e1r, g1r, e2r, g2r = self._counts(bf, p0 - 96 * bf, min(endrel, 96), t1, t2)
-        a01 = sum(int(h[4 * t1 + x]) for x in range(4)) + int(self.ptab[ri, 1 + t1]) + e1p
+        a01 = sum(int(h[4 * t1 + x]) for x in range(4)) + (int(h[16 + t1]) & 0x7FFFFFFF) + e1p
         a02 = int(h[4 * t1 + t2]) + e2p
         if endrel > 96:
             h2 = self.blocks[bf + 1]
-            if (int(h2[16]) >> 31) or (int(h2[16]) & 0x7FFFFFFF) != ri:
+            if int(h2[16]) >> 31:
                 return None
             _, _, a, b, c, d = self._counts(bf + 1, 0, endrel - 96, t1, t2)
             e1r, g1r, e2r, g2r = e1r + a, g1r + b, e2r + c, g2r + d
@@ -256,7 +247,7 @@ def test_pairs_image_does_not_depend_on_the_builder_threads(workdir, monkeypatch
     for threads in ("1", "3", "16"):
         monkeypatch.setenv("PGX_BUILD_THREADS", threads)
         idx = P.Index(ri, mode=P.MODE_STRICT | P.MODE_IMAGE_PAIRS)
-        images.append((idx.image_view(20).tobytes(), idx.image_view(21).tobytes(), bytes(idx.image_view(6))))
+        images.append((idx.image_view(20).tobytes(), bytes(idx.image_view(6))))
         if threads == "16":
             _check(idx, _bwt_codes(os.path.join(workdir, "pairs_thr.rl_bwt")))
     assert images[0] == images[1] == images[2]

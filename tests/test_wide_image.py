@@ -1,0 +1,99 @@
+"""WIDE form of the dense2 / PAIRS images (pgx_image.h "WIDE": BWTs of 2^32 symbols or more; the reference is size_t end to end,
+include/pangenome_index/r-index.hpp:118-130).  CPU tier: the wide image of an index is its narrow image re-based -- every header
+count of a block plus the base of the block's superblock equals the narrow (absolute) count, everything else is the same bytes --,
+for superblocks so small (PGX_SB_SHIFT) that a small index has dozens of them.  The narrow images themselves are checked against
+brute force in tests/test_image.py and tests/test_pairs_image.py.  GPU tier: the 64-bit kernels on such images against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import pgx_ffi as P
+import pgx_workload as W
+from image_emu import Consts
+
+
+@pytest.fixture(scope="module")
+def wide_case(workdir):
+    text = os.path.join(workdir, "wide_case.txt")
+    W.synth_pangenome_text(text, base_len=30_000, n_hap=3, seed=77, snp=0.01, indel=0.001, n_runs=3, n_run_len=(20, 400))
+    ri = W.build_index_from_text(text, workdir, "wide_case", with_tags=True)
+    return ri[0], ri[1], text
+
+
+@pytest.mark.parametrize("shift", ["2", "4", "7"])
+def test_wide_images_are_the_narrow_ones_rebased(wide_case, monkeypatch, shift):
+    ri, _, _ = wide_case
+    narrow = P.Index(ri, None, mode=P.MODE_COMPAT | P.MODE_IMAGE_PAIRS)
+    monkeypatch.setenv("PGX_SB_SHIFT", shift)
+    wide = P.Index(ri, None, mode=P.MODE_COMPAT | P.MODE_IMAGE_PAIRS | P.MODE_IMAGE_WIDE)
+    assert narrow.info().image_wide == 0 and wide.info().image_wide == 1 and wide.info().image_pairs == 1
+    cn, cw = Consts(narrow.image_view(6)), Consts(wide.image_view(6))
+    assert cn.wide == 0 and cw.wide == 1 and cw.n == cn.n and cw.C == cn.C and cw.ext_tab == cn.ext_tab
+    assert list(cw.pair_t2w) == [int(v) for v in cn.pair_t2] == list(cn.pair_t2w)
+    # dense2: header dwords 0..4 (A C G T N) are deltas; dword 5 .. 31 (exceptions, sub-block counts, planes) are the same
+    bn, bw = narrow.image_view(0).view(np.uint32).reshape(-1, 32), wide.image_view(0).view(np.uint32).reshape(-1, 32)
+    sb2 = wide.image_view(22).reshape(-1, 8)
+    assert len(bn) == len(bw) and len(sb2) == cw.n_sb2 == ((len(bw) - 1) >> cw.d2_sb_shift) + 1 and 1 < cw.n_sb2 <= 64
+    assert np.array_equal(bn[:, 5:], bw[:, 5:])
+    which = np.arange(len(bw)) >> cw.d2_sb_shift
+    assert np.array_equal(bw[:, :5].astype(np.uint64) + sb2[which, :5], bn[:, :5].astype(np.uint64))
+    assert np.array_equal(sb2[:, 5], sb2[:, :5].sum(axis=1)) and not sb2[:, 6:].any()
+    assert np.array_equal(sb2[1:, :5], bn[np.arange(1, len(sb2)) << cw.d2_sb_shift, :5])  # a base = the absolute counts at the superblock's first block
+    assert np.array_equal(narrow.image_view(15), wide.image_view(15))
+    # pairs: the sixteen pair counts are deltas, row sums of the bases are kept next to them; dword 16 .. 31 are the same
+    pn, pw = narrow.image_view(20).reshape(-1, 32), wide.image_view(20).reshape(-1, 32)
+    pb = wide.image_view(23).reshape(-1, 24)
+    assert len(pn) == len(pw) and len(pb) == cw.n_sbp == ((len(pw) - 1) >> cw.pairs_sb_shift) + 1 and 1 < cw.n_sbp <= 64
+    assert np.array_equal(pn[:, 16:], pw[:, 16:])
+    whichp = np.arange(len(pw)) >> cw.pairs_sb_shift
+    assert np.array_equal(pw[:, :16].astype(np.uint64) + pb[whichp, :16], pn[:, :16].astype(np.uint64))
+    assert np.array_equal(pb[:, 16:20], pb[:, :16].reshape(-1, 4, 4).sum(axis=2)) and not pb[:, 20:].any()
+    assert (pw[:, :16].astype(np.int64) < (1 << 31)).all()
+    narrow.close(); wide.close()
+
+
+def test_wide_is_refused_for_the_other_layouts(wide_case):
+    ri, _, _ = wide_case
+    for layout in (P.MODE_IMAGE_RL, P.MODE_IMAGE_DENSE):
+        with pytest.raises(P.PgxError) as e:
+            P.Index(ri, None, mode=P.MODE_COMPAT | layout | P.MODE_IMAGE_WIDE)
+        assert e.value.code == P.ERR_ARG
+    idx = P.Index(ri, None, mode=P.MODE_COMPAT | P.MODE_IMAGE_WIDE)  # alone: dense2 + pairs, both wide
+    assert idx.info().image_kind == P.IMAGE_DENSE2 and idx.info().image_wide == 1 and idx.info().image_pairs == 1
+    idx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift", ["2", "22"])
+def test_wide_kernels_against_the_oracle(wide_case, monkeypatch, shift):
+    """pgx_find_mems_pairs_kernel<.., WIDE> + pgx_find_mems_kernel<false, 3, ..> (64-bit state, superblock bases in LDS) on a small index
+    forced into the wide form, many superblocks (shift 2) and one (shift 22): rank at every position, random extensions, find_mems + tags."""
+    ri_path, tags_path, text = wide_case
+    monkeypatch.setenv("PGX_SB_SHIFT", shift)
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    seqs = W.load_sequences(text)
+    cat, offs = W.sample_reads(seqs, 20_000, 150, seed=5)
+    extra = [b"N" * 150, bytes(seqs[0][-150:]), bytes(seqs[1][:150]), b"acgt" * 30, b"ACGTNACGT" * 10, b""]
+    ecat, eoffs = O.pack_reads(extra)
+    cat = np.concatenate([cat, ecat]); offs = np.concatenate([offs, eoffs[1:] + offs[-1]])
+    for force in (P.MODE_IMAGE_PAIRS, P.MODE_IMAGE_DENSE2):
+        idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | force | P.MODE_IMAGE_WIDE)
+        assert idx.info().image_wide == 1 and idx.info().image_pairs == (1 if force == P.MODE_IMAGE_PAIRS else 0)
+        pos = np.arange(0, ri.n + 2, dtype=np.uint64)
+        got = idx.rank_batch(pos, true_codes=True)
+        for p in range(0, ri.n + 1, 97):
+            assert list(got[p]) == ri.rank6_true(p)
+        for min_len, min_occ in ((20, 1), (12, 1), (25, 3), (5, 2), (31, 1)):
+            ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, threads=4)
+            res = idx.find_mems(cat, offs, min_len, min_occ, tags=True)
+            assert np.array_equal(res["mem_offsets"], ref["mem_offsets"]), (force, min_len, min_occ)
+            assert res["mems"].tobytes() == ref["mems"].tobytes()
+            assert res["n_extensions"] == ref["n_extensions"]
+            assert np.array_equal(res["pos_offsets"], ref["pos_offsets"]) and np.array_equal(res["positions"], ref["positions"])
+        b = idx.batch(cat, offs)
+        b.run(20, 1, P.RUN_TIMING)
+        assert b.timing().pairs_reads == (1 if force == P.MODE_IMAGE_PAIRS else 0) and b.timing().seed_depth > 0
+        b.free()
+        idx.close()
