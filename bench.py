@@ -18,6 +18,8 @@ Workloads (config.workload):
          the whole rank image sits in LDS.  min_len defaults to 10: at 20 the reference's rank-cache quirk on this
          no-N index finds zero MEMs (DESIGN.md "Workloads").  Also reported inside the default run as `secondary`.
   chrom  BASELINE configs[4] shape: chromosome-sharded indexes + exchange of per-read MEM lists.
+  wg     one merged index over --chroms (default 8) independent synthetic chromosomes, --haps 32 haplotypes each: n = 4.35e9 > 2^32, the
+         64-bit (WIDE) images and kernels; built by pgx_build_index_from_texts (per-chromosome suffix arrays + k-way merge).
 
 Prints ONE JSON line on rank 0.  The CPU oracle is used here only for the `cpu_baseline` legs.
 """
@@ -40,6 +42,8 @@ DEFAULTS = {  # workload -> (reads per GPU, min_len, base_len)
     "synth": (1_000_000, 20, 4_000_000),
     "x": (1_000_000, 10, None),
     "chrom": (1_000_000, 20, 4_000_000),
+    # whole-genome scale: --chroms independent chromosomes in ONE index of more than 2^32 symbols (8 x 8.5 Mbp x 32 haplotypes x 2 strands = 4.35e9)
+    "wg": (10_000_000, 20, 8_500_000),
 }
 
 
@@ -49,13 +53,13 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="chr22", choices=sorted(DEFAULTS))
-    ap.add_argument("--chroms", type=int, default=6, help="chrom: number of synthetic chromosomes (sharded over the ranks)")
+    ap.add_argument("--chroms", type=int, default=None, help="chrom: synthetic chromosomes sharded over the ranks (default 6); wg: chromosomes of the merged index (default 8)")
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--min-len", type=int, default=None)
     ap.add_argument("--min-occ", type=int, default=1)
     ap.add_argument("--base-len", type=int, default=None, help="chr22 / synth / chrom: base sequence length")
-    ap.add_argument("--haps", type=int, default=8, help="chr22 / synth: haplotypes (each in both strands)")
+    ap.add_argument("--haps", type=int, default=None, help="chr22 / synth: haplotypes (each in both strands), default 8; wg: default 32")
     ap.add_argument("--mode", default="compat", choices=["compat", "strict"])
     ap.add_argument("--no-tags", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -79,6 +83,10 @@ def parse(argv=None):
         args.min_len = d[1]
     if args.base_len is None:
         args.base_len = d[2]
+    if args.haps is None:
+        args.haps = 32 if args.workload == "wg" else 8
+    if args.chroms is None:
+        args.chroms = 8 if args.workload == "wg" else 6
     return args
 
 
@@ -141,6 +149,26 @@ def make_workload(args, workload, rank, wd, barrier, n_reads, base_len):
         seqs = W.load_sequences(os.path.join(golden, "x.newline_separated"))
         seed = 42 + 2
         desc = "x.rl_bwt index (n=3012, sigma=5), BASELINE configs[1]"
+    elif workload == "wg":
+        name = "wg_%d_%d_%d" % (args.chroms, base_len, args.haps)
+        done = os.path.join(wd, name + ".done")
+        texts = [os.path.join(wd, "%s_chr%d.txt" % (name, c)) for c in range(args.chroms)]
+        if rank == 0 and not os.path.exists(done):
+            t0 = time.time()
+            # (two short N runs per haplotype: sigma = 6 as everywhere, without making the k-way merge compare through hundreds of kilobases of N)
+            W.synth_chromosome_texts(wd, name, args.chroms, base_len, args.haps, seed=45, n_runs=2, n_run_len=(1000, 10000))
+            t1 = time.time()
+            W.build_index_from_texts(texts, wd, name)
+            open(done, "w").write("ok\n")
+            build_s = time.time() - t0
+            sys.stderr.write("[bench] %d chromosome texts in %.1f s, merged index built in %.1f s (host: SA-IS per chromosome + k-way merge)\n" % (args.chroms, t1 - t0, time.time() - t1))
+        barrier()
+        ri, tags = os.path.join(wd, name + ".ri"), os.path.join(wd, name + ".compact.tags")
+        seqs = []
+        for t in texts:
+            seqs += W.load_sequences(t)
+        seed = 42 + 5
+        desc = "synthetic whole-genome-scale pangenome: %d chromosomes x %d bp base x %d haplotypes x 2 strands in one index, sigma=6" % (args.chroms, base_len, args.haps)
     else:
         ri, tags, text, build_s = synth_index(W, wd, base_len, args.haps, rank, barrier)
         seqs = W.load_sequences(text)
@@ -372,7 +400,8 @@ def main():
         K, n = args.steps, args.reads
         reads_total = n * world * K
         kinds = {P.IMAGE_RL: "run-length blocks", P.IMAGE_DENSE: "dense bit planes", P.IMAGE_DENSE2: "dense2 bit planes"}
-        image = ("LDS copy of " if info.image_in_lds else "") + kinds[info.image_kind] + (" + two-step pairs image" if info.image_pairs else "")
+        image = (("LDS copy of " if info.image_in_lds else "") + kinds[info.image_kind] + (" + two-step pairs image" if info.image_pairs else "")
+                 + (" (64-bit form: counts as deltas against superblock bases)" if info.image_wide else ""))
         line = {
             "metric": "find_mems reads/sec (150 bp batch)",
             "value": reads_total / dt,
@@ -390,6 +419,7 @@ def main():
             "config": {
                 "workload": {"chr22": "BASELINE configs[2]: chr22-scale synthetic pangenome index (n = %d), %d synthetic %d-bp reads per GPU, 1 MI355X per rank" % (info.bwt_size, n, args.read_len),
                              "synth": desc + ", %d reads per GPU" % n,
+                             "wg": desc + " (n = %d), %d reads per GPU" % (info.bwt_size, n),
                              "x": "BASELINE configs[1]: x.rl_bwt index, %d synthetic %d-bp reads per GPU" % (n, args.read_len)}[args.workload],
                 "index": desc, "reads_per_gpu": n, "read_len": args.read_len, "min_len": args.min_len,
                 "min_occ": args.min_occ, "mode": args.mode, "tags": not args.no_tags,
@@ -397,7 +427,7 @@ def main():
                 "bwt_size": int(info.bwt_size), "bwt_runs": int(info.n_runs), "image_in_lds": bool(info.image_in_lds),
                 "rank_image": "%s, %.1f MB%s" % (image, info.image_bytes / 1e6, "" if info.image_in_lds else
                                                  (", global memory (fits the 256 MB memory-side cache)" if info.image_bytes < 240e6 else ", resident in HBM")),
-                "image_kind": int(info.image_kind), "image_pairs": int(info.image_pairs),
+                "image_kind": int(info.image_kind), "image_pairs": int(info.image_pairs), "image_wide": int(info.image_wide),
                 "tag_image_MB": info.tag_image_bytes / 1e6,
                 "index_build_host_s": round(build_s, 1), "prep_s": round(prep_s, 1),
             },

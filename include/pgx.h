@@ -136,6 +136,10 @@ pgx_status pgx_index_to_device(pgx_index *h, int device);
  * WIDE images: 22 superblock bases of the dense2 image (8 u64 each), 23 of the PAIRS image (24 u64 each). */
 pgx_status pgx_index_image_view(const pgx_index *h, int which, const void **ptr, uint64_t *bytes);
 
+/* The DEVICE copy of a view (tests: what the kernels read must be what the host built): which = 0 (rank blocks), 15 (exception runs),
+ * 20 (PAIRS blocks), 22 / 23 (superblock bases); copies min(bytes, size of the view) bytes into out. */
+pgx_status pgx_index_device_view(pgx_index *h, int device, int which, void *out, uint64_t bytes);
+
 /* ---- index construction (build side; CPU, run once) --------------------------------------- */
 /* Replaces build_rindex (src/build_rindex.cpp:13-21 -> FastLocate(std::string) src/r-index.cpp:778
  * + serialize_encoded :297-376).  encoded=0 writes the legacy layout (serialize, :266-294). */

@@ -9,7 +9,9 @@
 //                          src/tag_arrays.cpp:940-974, 622-654
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -24,6 +26,18 @@ using namespace pgx;
     catch (const pgx::Error &e) { pgx::set_last_error(e.what()); return e.code; }                   \
     catch (const std::bad_alloc &) { pgx::set_last_error("out of host memory"); return PGX_ERR_NOMEM; } \
     catch (const std::exception &e) { pgx::set_last_error(e.what()); return PGX_ERR_FORMAT; }
+
+// PGX_BUILD_TIMING=1: phase times of the builders on stderr
+struct BuildTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    bool on = std::getenv("PGX_BUILD_TIMING") != nullptr;
+    void lap(const char *what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[pgx build] %-28s %8.2f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 template <class T> static void put(std::vector<uint8_t> &out, T v) {
     const uint8_t *p = reinterpret_cast<const uint8_t *>(&v);
@@ -181,15 +195,20 @@ static bool suffix_less(const Chunk &A, uint64_t i, const Chunk &B, uint64_t j) 
     }
 }
 // the first 21 symbols of a suffix as one integer that orders like the suffix: 3 bits per symbol, nothing behind an endmarker
+struct KeyCodes {
+    uint8_t v[256];
+    KeyCodes() {
+        for (int c = 0; c < 256; c++) v[c] = c < 'A' ? 1 : 6; // (bytes the .ri builder rejects anyway: kept in byte order around the alphabet)
+        v[(uint8_t)'\n'] = 0; v[(uint8_t)'A'] = 1; v[(uint8_t)'C'] = 2; v[(uint8_t)'G'] = 3; v[(uint8_t)'N'] = 4; v[(uint8_t)'T'] = 5;
+    }
+};
 static inline uint64_t suffix_key(const Chunk &C, uint64_t i) {
+    static const KeyCodes kc;
     const uint8_t *p = C.text.data() + i;
     uint64_t k = 0;
-    int d = 0;
-    for (; d < 21; d++) {
-        const uint8_t ch = p[d];
-        if (ch == '\n') break;
-        // A C G N T -> 1 2 3 4 5 (byte order)
-        const uint64_t v = ch == 'A' ? 1u : ch == 'C' ? 2u : ch == 'G' ? 3u : ch == 'N' ? 4u : ch == 'T' ? 5u : (ch < 'A' ? 1u : 6u);
+    for (int d = 0; d < 21; d++) {
+        const uint64_t v = kc.v[p[d]];
+        if (!v) break;
         k |= v << (60 - 3 * d);
     }
     return k;
@@ -305,10 +324,11 @@ static void load_chunk(const char *path, Chunk &c) {
     c.seq_start.push_back(0);
     for (uint64_t i = 0; i + 1 < c.n; i++)
         if (c.text[i] == '\n') c.seq_start.push_back(i + 1);
-    c.text.resize(c.n + 8, 0); // the 8-byte loads of suffix_less stop at the final endmarker, inside the padding at the latest
+    c.text.resize(c.n + 32, 0); // the 8-byte loads of suffix_less and the 21-symbol keys stop at the final endmarker, inside the padding at the latest
 }
 
 static void build_texts_bwt(const char *const *text_paths, uint32_t n_texts, TextBwt &o) {
+    BuildTimer bt;
     std::vector<Chunk> ch(n_texts);
     std::vector<std::thread> th;
     std::exception_ptr err;
@@ -323,7 +343,9 @@ static void build_texts_bwt(const char *const *text_paths, uint32_t n_texts, Tex
         });
     for (auto &x : th) x.join();
     if (err) std::rethrow_exception(err);
+    bt.lap("suffix arrays (per text)");
     merge_chunks(ch, o);
+    bt.lap("k-way merge + runs");
 }
 
 static void build_text_bwt(const char *text_path, TextBwt &o) {
@@ -378,6 +400,7 @@ static std::vector<std::pair<uint8_t, uint64_t>> read_rlbwt(const std::string &p
 // straight from it: the sample of BWT position p is the (sequence, offset) of suffix SA[p] -- the same values, without
 // n binary searches over the run starts.
 static void build_rindex_core(const std::vector<std::pair<uint8_t, uint64_t>> &file_runs, const TextBwt *tb, const char *out_ri_path, int encoded) {
+    BuildTimer bt;
     // calculate_C, r-index.hpp:440-482: sym_map = rank among present byte values; C = exclusive sums
     uint64_t freq[256] = {0}, n = 0;
     for (auto &r : file_runs) { freq[r.first] += r.second; n += r.second; }
@@ -515,6 +538,7 @@ static void build_rindex_core(const std::vector<std::pair<uint8_t, uint64_t>> &f
         for (auto &t : th) t.join();
         if (bad.load()) throw Error(PGX_ERR_FORMAT, "rl_bwt is not the BWT of a newline-terminated collection (psi walk does not end)");
     }
+    bt.lap(".ri: blocks + SA samples");
     if (heads.size() < total_runs || tails.size() < total_runs)
         throw Error(PGX_ERR_FORMAT, "rl_bwt is not the BWT of a newline-terminated collection (sampling walk incomplete)");
     if (!tb) std::stable_sort(heads.begin(), heads.end(), [](const Sample &a, const Sample &b) { return a.run_id < b.run_id; }); // (already in run order otherwise)
@@ -546,6 +570,7 @@ static void build_rindex_core(const std::vector<std::pair<uint8_t, uint64_t>> &f
         IntVector::pack(sm, 8).write(out, false);
         IntVector::pack(C, 64).write(out, false);
     }
+    bt.lap(".ri: sort + pack samples");
     SdVector bsp;
     bsp.size = n;
     for (auto &b : blocks) bsp.ones.push_back(b.start);
@@ -587,7 +612,9 @@ static void build_rindex_core(const std::vector<std::pair<uint8_t, uint64_t>> &f
             }
         }
     }
+    bt.lap(".ri: blocks stream");
     write_whole_file(out_ri_path, out);
+    bt.lap(".ri: file written");
 }
 
 extern "C" pgx_status pgx_build_rindex(const char *rlbwt_path, const char *out_ri_path, int encoded) {

@@ -221,7 +221,7 @@ __device__ __forceinline__ void pgx_dense2_rank(const PgxDevImage &img, uint32_t
 // WIDE DENSE2 (pgx_image.h): the same blocks, header counts as deltas against the 64-bit bases of the block's superblock; positions
 // and counts in 64 bits.  `sb` = the base table (img.sbase2 or its LDS copy): 8 words per superblock {A, C, G, T, N, their sum}.
 __device__ __forceinline__ PgxDense2Blk pgx_dense2w_load(const PgxDevImage &img, uint64_t pos, uint32_t &rel, uint32_t &blk) {
-    blk = (uint32_t)(__umul64hi(pos, 0xAAAAAAAAAAAAAAABull) >> 8); // pos / 384
+    blk = (uint32_t)(((pos >> 7) * 0xAAAAAAABull) >> 33); // pos / 384 = (pos / 128) / 3, exact while pos / 128 < 2^32
     rel = (uint32_t)(pos - (uint64_t)blk * PGX_D2_SYMS);
     const uint4 *bp = img.blocks + (size_t)blk * 8;
     PgxDense2Blk b;
@@ -753,7 +753,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                 A0 = (pos_t)q0; A1 = (pos_t)q1; dB = (pos_t)dq;
                 fin = true;
                 c_blk = s != n;
-                c_blk2 = c_blk && (uint32_t)(__umul64hi(p0, 0xAAAAAAAAAAAAAAABull) >> 8) != (uint32_t)(__umul64hi(p1, 0xAAAAAAAAAAAAAAABull) >> 8);
+                c_blk2 = c_blk && (uint32_t)(((p0 >> 7) * 0xAAAAAAABull) >> 33) != (uint32_t)(((p1 >> 7) * 0xAAAAAAABull) >> 33);
             } else if (DENSE == 2) {
                 // dense2: header + one sub-block per probe, all within one 128-byte line (usually the same line for both probes)
                 uint64_t q0, q1, dq;
@@ -1441,15 +1441,16 @@ template __global__ void pgx_find_mems_heavy_kernel<true>(PgxDevImage, const uin
 // primitives for tests (mirror rank_at_cached_encoded / backward_extend_encoded / forward_...)
 __global__ void __launch_bounds__(256)
 pgx_rank_kernel(PgxDevImage img, const uint64_t *__restrict__ pos, uint64_t n, int true_codes, uint64_t *__restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    // one (position, slot) per thread
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 6 * n) return;
+    const uint64_t i = t / 6;
+    const uint32_t sl = (uint32_t)(t - 6 * i);
     const uint32_t sigma = img.consts->sigma;
-    for (uint32_t sl = 0; sl < 6; sl++) {
-        uint64_t A = 0, B;
-        if (true_codes) pgx_rank_ab<false>(img, nullptr, nullptr, nullptr, pos[i], sl, 0, A, B);
-        else if (sl < sigma) pgx_rank_ab<false>(img, nullptr, nullptr, nullptr, pos[i], img.consts->slot_code[sl], 0, A, B);
-        out[i * 6 + sl] = A;
-    }
+    uint64_t A = 0, B;
+    if (true_codes) pgx_rank_ab<false>(img, nullptr, nullptr, nullptr, pos[i], sl, 0, A, B);
+    else if (sl < sigma) pgx_rank_ab<false>(img, nullptr, nullptr, nullptr, pos[i], img.consts->slot_code[sl], 0, A, B);
+    out[t] = A;
 }
 
 template <bool LDS_IMAGE>

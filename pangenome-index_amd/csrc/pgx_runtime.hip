@@ -223,6 +223,27 @@ extern "C" pgx_status pgx_index_to_device(pgx_index *h, int device) {
     PGX_GUARD_END
 }
 
+extern "C" pgx_status pgx_index_device_view(pgx_index *h, int device, int which, void *out, uint64_t bytes) {
+    PGX_GUARD_BEGIN
+    if (!h || !out) throw Error(PGX_ERR_ARG, "pgx_index_device_view: null argument");
+    pgx_device_image *d = device_image(h, device);
+    const HostImage &m = h->img;
+    const void *src = nullptr;
+    uint64_t have = 0;
+    switch (which) {
+    case 0: src = d->blocks.p; have = m.blocks.size(); break;
+    case 15: src = d->exc.p; have = m.exc.size() * 4; break;
+    case 20: src = d->pairs.p; have = m.pairs.size(); break;
+    case 22: src = d->sbase2.p; have = m.sbase2.size() * 8; break;
+    case 23: src = d->pbase.p; have = m.pbase.size() * 8; break;
+    default: throw Error(PGX_ERR_ARG, "pgx_index_device_view: unknown view");
+    }
+    const uint64_t k = std::min(bytes, have);
+    if (k && src) HIPCHECK(hipMemcpy(out, src, k, hipMemcpyDeviceToHost));
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
 extern "C" pgx_status pgx_device_count(int *n) {
     PGX_GUARD_BEGIN
     if (!n) throw Error(PGX_ERR_ARG, "pgx_device_count: null argument");
@@ -1489,7 +1510,7 @@ extern "C" pgx_status pgx_rank_batch(pgx_index *h, int device, const uint64_t *p
         dout.ensure(n * 48);
         HIPCHECK(hipMemcpy(dp.p, pos, n * 8, hipMemcpyHostToDevice));
         HIPCHECK(hipMemset(dout.p, 0, n * 48));
-        hipLaunchKernelGGL(pgx_rank_kernel, dim3(grid_for(n, 256)), dim3(256), 0, 0, d->img, dp.as<uint64_t>(), n, true_codes, dout.as<uint64_t>());
+        hipLaunchKernelGGL(pgx_rank_kernel, dim3(grid_for(6 * n, 256)), dim3(256), 0, 0, d->img, dp.as<uint64_t>(), n, true_codes, dout.as<uint64_t>());
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipMemcpy(out, dout.p, n * 48, hipMemcpyDeviceToHost));
     } catch (...) { dp.release(); dout.release(); throw; }

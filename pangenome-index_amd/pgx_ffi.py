@@ -261,6 +261,13 @@ class Index:
         raw = C.string_at(ptr, nbytes.value)
         return np.frombuffer(raw, dtype=_VIEW_DTYPES[which]).copy()
 
+    def device_view(self, which, device=0):
+        """the device copy of image view `which` (0, 15, 20, 22, 23) as bytes"""
+        host = self.image_view(which)
+        out = np.zeros(host.nbytes, dtype=np.uint8)
+        _check(self.L.pgx_index_device_view(self.h, device, which, C.c_void_p(out.ctypes.data), u64(host.nbytes)))
+        return out.view(host.dtype)
+
     # ---- primitives -------------------------------------------------------------------------
     def rank_batch(self, pos, true_codes=False, device=0):
         pos = np.ascontiguousarray(pos, dtype=np.uint64)

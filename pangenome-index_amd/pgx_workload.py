@@ -68,6 +68,39 @@ def build_index_from_text(text_path, workdir, name, encoded=True, with_tags=True
     return ri, tags, rl
 
 
+def build_index_from_texts(text_paths, workdir, name, encoded=True, with_tags=True):
+    """the collection as several texts ("chromosomes"): pgx_build_index_from_texts (per-text suffix arrays + k-way merge; any total size)"""
+    os.makedirs(workdir, exist_ok=True)
+    rl = os.path.join(workdir, name + ".rl_bwt")
+    ri = os.path.join(workdir, name + (".ri" if encoded else ".legacy.ri"))
+    pgx_ffi.build_index_from_texts(list(text_paths), rl, ri, encoded)
+    tags = None
+    if with_tags:
+        tags = os.path.join(workdir, name + ".compact.tags")
+        synthetic_tags_from_runs(rl, tags)
+    return ri, tags, rl
+
+
+def _synth_one(args):
+    path, kw = args
+    return synth_pangenome_text(path, **kw)
+
+
+def synth_chromosome_texts(workdir, name, n_chrom, base_len, n_hap, seed=45, processes=8, **kw):
+    """n_chrom independent synthetic chromosomes (synth_pangenome_text each, its own seed), written side by side by worker processes"""
+    import multiprocessing as mp
+
+    paths = [os.path.join(workdir, "%s_chr%d.txt" % (name, c)) for c in range(n_chrom)]
+    jobs = [(paths[c], dict(base_len=base_len, n_hap=n_hap, seed=seed + 1000 * c, **kw)) for c in range(n_chrom)]
+    if processes > 1 and n_chrom > 1:
+        with mp.get_context("fork").Pool(min(processes, n_chrom)) as pool:
+            pool.map(_synth_one, jobs)
+    else:
+        for j in jobs:
+            _synth_one(j)
+    return paths
+
+
 def load_sequences(text_path):
     raw = open(text_path, "rb").read()
     return [np.frombuffer(s, dtype=np.uint8) for s in raw.split(b"\n") if len(s)]
