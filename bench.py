@@ -62,6 +62,8 @@ def parse(argv=None):
     ap.add_argument("--haps", type=int, default=None, help="chr22 / synth: haplotypes (each in both strands), default 8; wg: default 32")
     ap.add_argument("--mode", default="compat", choices=["compat", "strict"])
     ap.add_argument("--no-tags", action="store_true")
+    ap.add_argument("--n-read-frac", type=float, default=None,
+                    help="share of the reads that overlap an N run of the text (default: wherever uniform sampling falls, 0.4 %% on the chr22 workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="chr22: skip the nested x (configs[1]) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target core-seconds of the CPU sample")
@@ -176,7 +178,7 @@ def make_workload(args, workload, rank, wd, barrier, n_reads, base_len):
         desc = "synthetic pangenome: %d bp base x %d haplotypes x 2 strands, sigma=6" % (base_len, args.haps)
         if workload == "chr22":
             desc += " (chr22-scale, SURVEY 8d config 3 = BASELINE configs[2])"
-    cat, offs = W.sample_reads(seqs, n_reads, args.read_len, seed=seed + 1000 * rank)
+    cat, offs = W.sample_reads(seqs, n_reads, args.read_len, seed=seed + 1000 * rank, n_frac=args.n_read_frac if workload != "x" else None)
     return ri, tags, cat, offs, desc, build_s
 
 
@@ -422,7 +424,7 @@ def main():
                              "wg": desc + " (n = %d), %d reads per GPU" % (info.bwt_size, n),
                              "x": "BASELINE configs[1]: x.rl_bwt index, %d synthetic %d-bp reads per GPU" % (n, args.read_len)}[args.workload],
                 "index": desc, "reads_per_gpu": n, "read_len": args.read_len, "min_len": args.min_len,
-                "min_occ": args.min_occ, "mode": args.mode, "tags": not args.no_tags,
+                "min_occ": args.min_occ, "mode": args.mode, "tags": not args.no_tags, "n_read_frac": args.n_read_frac,
                 "sharding": "reads sharded by rank, index replicated, no collective",
                 "bwt_size": int(info.bwt_size), "bwt_runs": int(info.n_runs), "image_in_lds": bool(info.image_in_lds),
                 "rank_image": "%s, %.1f MB%s" % (image, info.image_bytes / 1e6, "" if info.image_in_lds else

@@ -39,6 +39,30 @@ struct BuildTimer {
     }
 };
 
+// sort with host threads: slices sorted side by side, then merged pairwise (std::inplace_merge), round by round
+template <class It, class Cmp> static void parallel_sort(It first, It last, Cmp cmp) {
+    const size_t n = (size_t)(last - first);
+    unsigned T = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 16u));
+    if (n < (1u << 20) || T < 2) { std::sort(first, last, cmp); return; }
+    unsigned P = 1;
+    while (P * 2 <= T) P *= 2; // a power of two slices
+    std::vector<size_t> cut(P + 1);
+    for (unsigned i = 0; i <= P; i++) cut[i] = n * i / P;
+    {
+        std::vector<std::thread> th;
+        for (unsigned i = 0; i < P; i++) th.emplace_back([&, i]() { std::sort(first + (std::ptrdiff_t)cut[i], first + (std::ptrdiff_t)cut[i + 1], cmp); });
+        for (auto &t : th) t.join();
+    }
+    for (unsigned w = 1; w < P; w *= 2) {
+        std::vector<std::thread> th;
+        for (unsigned i = 0; i + w < P; i += 2 * w)
+            th.emplace_back([&, i, w]() {
+                std::inplace_merge(first + (std::ptrdiff_t)cut[i], first + (std::ptrdiff_t)cut[i + w], first + (std::ptrdiff_t)cut[std::min(i + 2 * w, P)], cmp);
+            });
+        for (auto &t : th) t.join();
+    }
+}
+
 template <class T> static void put(std::vector<uint8_t> &out, T v) {
     const uint8_t *p = reinterpret_cast<const uint8_t *>(&v);
     out.insert(out.end(), p, p + sizeof(T));
@@ -542,7 +566,7 @@ static void build_rindex_core(const std::vector<std::pair<uint8_t, uint64_t>> &f
     if (heads.size() < total_runs || tails.size() < total_runs)
         throw Error(PGX_ERR_FORMAT, "rl_bwt is not the BWT of a newline-terminated collection (sampling walk incomplete)");
     if (!tb) std::stable_sort(heads.begin(), heads.end(), [](const Sample &a, const Sample &b) { return a.run_id < b.run_id; }); // (already in run order otherwise)
-    std::sort(tails.begin(), tails.end(), [](const Sample &a, const Sample &b) {
+    parallel_sort(tails.begin(), tails.end(), [](const Sample &a, const Sample &b) {
         return a.seq_id < b.seq_id || (a.seq_id == b.seq_id && a.seq_offset < b.seq_offset);
     });
     auto bits_length = [](uint64_t x) { return (uint8_t)(x ? hi_bit(x) + 1 : 0); }; // sdsl::bits::length

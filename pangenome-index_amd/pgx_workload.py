@@ -106,8 +106,10 @@ def load_sequences(text_path):
     return [np.frombuffer(s, dtype=np.uint8) for s in raw.split(b"\n") if len(s)]
 
 
-def sample_reads(seqs, n_reads, read_len=150, seed=42, sub_rate=0.01, rc_frac=0.5):
+def sample_reads(seqs, n_reads, read_len=150, seed=42, sub_rate=0.01, rc_frac=0.5, n_frac=None):
     """150-bp reads sampled from the indexed text, 1 % substitutions, 50 % reverse-complemented.
+    n_frac (None = wherever the uniform positions fall): the share of reads that overlap an N run of the text (their start is drawn
+    around a uniformly chosen N position); the others are drawn again until they hold no N.
 
     Returns (reads uint8[n_reads * read_len], offsets uint64[n_reads + 1])."""
     rng = np.random.default_rng(seed)
@@ -121,6 +123,29 @@ def sample_reads(seqs, n_reads, read_len=150, seed=42, sub_rate=0.01, rc_frac=0.
     room = lens - read_len + 1
     which = rng.choice(len(ok), size=n_reads, p=room / room.sum())
     start = base[which] + (rng.random(n_reads) * room[which]).astype(np.int64)
+    if n_frac is not None:
+        isn = cat == ord("N")
+        npos = np.flatnonzero(isn)
+        ncum = np.concatenate(([0], np.cumsum(isn, dtype=np.int64)))
+        ends = np.cumsum(lens)
+        has_n = lambda st: (ncum[st + read_len] - ncum[st]) > 0  # noqa: E731
+        want = rng.random(n_reads) < n_frac
+        if want.any() and len(npos) == 0:
+            raise ValueError("the text has no N to sample reads from")
+        # reads over an N run: a start within read_len before a uniformly chosen N position, clipped to its sequence
+        k = int(want.sum())
+        if k:
+            p = npos[rng.integers(0, len(npos), size=k)]
+            st = p - rng.integers(0, read_len, size=k)
+            sq = np.searchsorted(ends, p, side="right")
+            start[want] = np.clip(st, base[sq], ends[sq] - read_len)
+        # the others: drawn again while they hold an N (a few rounds)
+        for _ in range(50):
+            bad = ~want & has_n(start)
+            if not bad.any():
+                break
+            w2 = rng.choice(len(ok), size=int(bad.sum()), p=room / room.sum())
+            start[bad] = base[w2] + (rng.random(int(bad.sum())) * room[w2]).astype(np.int64)
     out = np.empty((n_reads, read_len), dtype=np.uint8)
     step = max(1, (1 << 24) // read_len)
     ar = np.arange(read_len, dtype=np.int64)

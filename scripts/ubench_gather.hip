@@ -10,6 +10,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
@@ -31,10 +32,12 @@ __global__ void __launch_bounds__(256) gather(const uint4 *__restrict__ tab, uin
     out[(uint64_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
-int main() {
+int main(int argc, char **argv) {
     int cus = 0;
     CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
-    const size_t sizes_mb[] = {4, 36, 300, 2048};
+    // default table sizes, or the ones named on the command line (MB): the whole-genome-scale PAIRS image is 5.8 GB, its seed table 16 GiB
+    std::vector<size_t> sizes_mb = {4, 36, 300, 2048};
+    if (argc > 1) { sizes_mb.clear(); for (int i = 1; i < argc; i++) sizes_mb.push_back((size_t)atoll(argv[i])); }
     const int iters = 400;
     for (size_t mb : sizes_mb) {
         const size_t bytes = mb << 20;
