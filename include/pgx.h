@@ -266,7 +266,7 @@ typedef struct {
     float ms_total;       /* first launch -> last launch, device time */
     uint32_t find_mems_launches;
     uint32_t heavy_reads; /* reads whose rest went through the heavy-read kernel (filled by every run, timed or not) */
-    uint32_t pairs_reads; /* 1 = the run used the two-step PAIRS kernel */
+    uint32_t pairs_reads; /* != 0: the run used the two-step PAIRS kernel (2: with the reads packed in LDS; 3: and cooperative line fetches) */
     uint32_t redo_reads;  /* reads the PAIRS kernel handed on to the dense2 kernel (they met \n or N in the BWT) */
     /* the first launch of the find_mems stage alone (the PAIRS kernel when pairs_reads, else pgx_find_mems_kernel): ms_find_mems
      * also covers the launches behind it (reads handed on, heavy reads) */
@@ -284,6 +284,11 @@ typedef struct {
  * find_mems.cpp:96-98, empty lines already skipped by the caller) to `device`. */
 pgx_status pgx_batch_create(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets,
                             uint64_t n_reads, pgx_batch **out);
+/* Pinned host memory for the read bytes handed to pgx_batch_create / pgx_batch_upload (and for anything else the caller streams to a
+ * device): uploads from it run at the speed of the link, uploads from ordinary pageable memory are staged by the runtime at a fraction of
+ * it (find_mems CLI, 16 M reads: 0.95 s of 1.9 s pipeline wall went into pageable uploads).  PGX_ERR_NO_DEVICE without a GPU. */
+pgx_status pgx_host_alloc(size_t bytes, void **out);
+void pgx_host_free(void *p);
 /* Replace the reads of an existing batch (its device and pinned host buffers only ever grow: a long-lived
  * batch costs no allocation per call).  Invalidates the results of the previous run. */
 pgx_status pgx_batch_upload(pgx_batch *b, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads);

@@ -985,7 +985,12 @@ __device__ __forceinline__ uint32_t pgx_window_byte(uint64_t w0, uint64_t w1, ui
 // into LDS when the lane takes it: the loop then reads its symbols (and whole seed windows, which ARE the seed index) from LDS instead of
 // re-fetching 16-byte windows of the read bytes through L2 -- a fifth of the kernel's memory requests at chr22 scale (941 M requests per step of
 // which 213 M were such windows: the ~300 k live reads do not stay in L2).  Only for launches that skip every read with a byte outside A C G T.
-template <bool SEED, bool WIDE, bool PACKED>
+// COOP (needs PACKED): the wave fetches the 64 block lines of its lanes TOGETHER -- eight load instructions in which lanes 8 q .. 8 q + 7 read the
+// eight 16-byte pieces of probe q's line (perfectly coalesced), through LDS -- instead of five loads per lane that each touch 64 different lines.
+// For images beyond the reach of the address-translation caches (~3 GB: profiles/r03_ubench_gather_loads_per_line.txt) a random line costs one
+// translation per load INSTRUCTION that touches it: 1 x 16 B of a line runs at 48 G lines/s, 5 x 16 B at 16-18 G/s, which is where the five-load
+// probe sat on the 5.8 GB image of the 4.35e9-symbol index (17 G lines/s).
+template <bool SEED, bool WIDE, bool PACKED, bool COOP>
 __global__ void __launch_bounds__(PGX_FM_THREADS, PGX_FM_WAVES_PER_SIMD) // (<= 96 VGPRs: five waves per SIMD fit and are what the launch uses; four are as fast -- 20.7 against 20.6-21.0 ms at chr22 scale --, three 21.8)
 pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                            uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
@@ -1001,8 +1006,11 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     __shared__ uint64_t s_pb[WIDE ? PGX_SB_MAX * 24 : 1]; // WIDE: per superblock the sixteen pair-count bases and their four row sums
     __shared__ uint4 s_fe[512]; // first_ext: [byte] the full interval extended by byte, [256 + byte] extended by 0 and then by byte (packed like a seed entry)
     extern __shared__ __align__(16) unsigned char pgx_dyn_lds[];
+    static_assert(!COOP || PACKED, "the cooperative loads come with the packed reads");
     uint32_t *s_rd = reinterpret_cast<uint32_t *>(pgx_dyn_lds); // PACKED: word w of this thread's read at s_rd[w * blockDim.x + threadIdx.x] (pk_words words per thread)
     const uint32_t rd_stride = blockDim.x;
+    // COOP: behind the packed reads, 8 KiB per wave: piece p of the line of lane q's probe at [q * 8 + (p ^ (q & 7))] (the swizzle spreads the banks)
+    uint4 *s_stage = reinterpret_cast<uint4 *>(pgx_dyn_lds + (size_t)pk_words * PGX_FM_THREADS * 4) + (size_t)(threadIdx.x >> 6) * 512;
     for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) s_ext[i] = img.consts->ext_tab[i];
     if (threadIdx.x < 8) s_C[threadIdx.x] = (pos_t)img.consts->C[threadIdx.x];
     if (threadIdx.x < 32) s_t2[threadIdx.x] = (pos_t)img.consts->pair_t2w[threadIdx.x];
@@ -1119,6 +1127,21 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         // (seed / end table entries: one per first trip -- an upper bound: a stage with fewer than K extensions to go reads the shared entry 0)
         ln_blk += (unsigned long long)__popcll(__ballot(ph > 0 && fresh == 0u));
         if (SEED) ln_seed += (unsigned long long)__popcll(__ballot(ph > 0 && fresh != 0u));
+        if (COOP) { // every lane names the block it is about to probe (idle lanes: block 0, like the first trip of a stage), the wave fetches all 64 lines
+            const pos_t kk_c = (ph == 2) ? kp : k;
+            const uint32_t myblk = ph > 0 ? (uint32_t)(((uint64_t)(kk_c >> 5) * 0xAAAAAAABull) >> 33) + pend : 0u;
+            // (global_load_lds_dwordx4: straight into LDS, no registers for the data; lane l of instruction i lands at [64 i + l] = slot l & 7 of
+            //  probe q = 8 i + (l >> 3), so the swizzle is applied to the piece it fetches)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t q = 8u * (uint32_t)i + ((uint32_t)lane >> 3), piece = ((uint32_t)lane & 7u) ^ (q & 7u);
+                const uint32_t blk = (uint32_t)__shfl((int)myblk, (int)q, 64);
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(img.pairs + ((size_t)blk * 8 + piece)),
+                                                 (void __attribute__((address_space(3))) *)(s_stage + 64 * i), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
         if (ph > 0) {
             const bool fr = fresh != 0u; // first extension of a backward stage: from first_ext / the seed table
             bool seed_lane = false;
@@ -1194,10 +1217,17 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             const uint32_t endrel = endrel_p > (pos_t)0xFFFFu ? 0xFFFFu : (uint32_t)endrel_p; // (anything beyond two blocks is "far")
             const uint32_t relA = pend ? 0u : p0 - bfirst * PGX_PAIRS_SYMS;
             const uint32_t relB = pend ? endrel - PGX_PAIRS_SYMS : (endrel < PGX_PAIRS_SYMS ? endrel : PGX_PAIRS_SYMS);
-            const uint4 *bp = img.pairs + (size_t)(bfirst + pend) * 8;
-            const uint4 row = bp[t1];                                                          // pairs (t1, A C G T) before the block
-            const uint4 hs = bp[4];                                                            // positions before the block with c2 special and c1 = A, C, G, T; bit 31 of .x: flag
-            const uint4 d0 = bp[5], d1 = bp[6], d2 = bp[7];                                    // planes: c1 bit 0, c1 bit 1, c2 bit 0, c2 bit 1, three dwords each
+            uint4 row, hs, d0, d1, d2;
+            if (COOP) { // the line of this lane's probe is in LDS (fetched by the whole wave above)
+                const uint4 *mine = s_stage + (uint32_t)lane * 8u;
+                const uint32_t sw = (uint32_t)lane & 7u;
+                row = mine[t1 ^ sw]; hs = mine[4u ^ sw]; d0 = mine[5u ^ sw]; d1 = mine[6u ^ sw]; d2 = mine[7u ^ sw];
+            } else {
+                const uint4 *bp = img.pairs + (size_t)(bfirst + pend) * 8;
+                row = bp[t1];                                                                  // pairs (t1, A C G T) before the block
+                hs = bp[4];                                                                    // positions before the block with c2 special and c1 = A, C, G, T; bit 31 of .x: flag
+                d0 = bp[5]; d1 = bp[6]; d2 = bp[7];                                            // planes: c1 bit 0, c1 bit 1, c2 bit 0, c2 bit 1, three dwords each
+            }
             const bool flagged = (hs.x >> 31) != 0u;
             const uint32_t pts = t1 == 0u ? (hs.x & 0x7FFFFFFFu) : (t1 == 1u ? hs.y : (t1 == 2u ? hs.z : hs.w));
             // masks that turn "code == t" / "code > t" into plane expressions: (x ^ i0) & (y ^ i1) and (y & ua) | (x & (y | va) & wa)
@@ -1315,10 +1345,12 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                                                                      pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t, uint32_t, \
                                                                      uint32_t, pgx_heavy_item *, unsigned long long *, pgx_heavy_item *, unsigned long long *,       \
                                                                      const uint8_t *, const uint32_t *, uint32_t);
-PGX_PAIRS_INSTANTIATE(true, false, false)
-PGX_PAIRS_INSTANTIATE(true, true, false)
-PGX_PAIRS_INSTANTIATE(true, false, true)
-PGX_PAIRS_INSTANTIATE(true, true, true)
+PGX_PAIRS_INSTANTIATE(true, false, false, false)
+PGX_PAIRS_INSTANTIATE(true, true, false, false)
+PGX_PAIRS_INSTANTIATE(true, false, true, false)
+PGX_PAIRS_INSTANTIATE(true, true, true, false)
+PGX_PAIRS_INSTANTIATE(true, false, true, true)
+PGX_PAIRS_INSTANTIATE(true, true, true, true)
 
 // first extension of every backward stage: the full interval extended by each byte value
 __global__ void __launch_bounds__(256) pgx_first_ext_kernel(PgxDevImage img, uint4 *__restrict__ out) { // out[512]

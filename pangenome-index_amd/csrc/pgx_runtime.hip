@@ -244,6 +244,22 @@ extern "C" pgx_status pgx_index_device_view(pgx_index *h, int device, int which,
     PGX_GUARD_END
 }
 
+extern "C" pgx_status pgx_host_alloc(size_t bytes, void **out) {
+    PGX_GUARD_BEGIN
+    if (!out) throw Error(PGX_ERR_ARG, "pgx_host_alloc: null argument");
+    *out = nullptr;
+    (void)checked_device_count();
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); throw Error(PGX_ERR_NOMEM, std::string("hipHostMalloc failed: ") + hipGetErrorString(e)); }
+    *out = p;
+    return PGX_OK;
+    PGX_GUARD_END
+}
+extern "C" void pgx_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 extern "C" pgx_status pgx_device_count(int *n) {
     PGX_GUARD_BEGIN
     if (!n) throw Error(PGX_ERR_ARG, "pgx_device_count: null argument");
@@ -1110,7 +1126,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         const char *pv = std::getenv("PGX_FM_PAIRS");
         // (only behind the seed table: the wide intervals at the start of an unseeded stage always have special positions between their ends)
         if (img.pairs && seeded && !(n >> 32) && b->read_bytes < (1ull << 35) && !(pv && pv[0] == '0'))
-            kfn_pairs = img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, false> : (const void *)pgx_find_mems_pairs_kernel<true, false, false>;
+            kfn_pairs = img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, false, false> : (const void *)pgx_find_mems_pairs_kernel<true, false, false, false>;
         pairs_lds = 0;
         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn_pairs ? kfn_pairs : kfn, PGX_FM_THREADS, kfn_pairs ? pairs_lds : b->dimg->lds_bytes));
         HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
@@ -1228,10 +1244,16 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                     const uint32_t pkw = (uint32_t)((15 + b->max_read_len + 15) >> 4) + 1u; // words of the longest read at the worst phase + one of padding
                     const char *pe = std::getenv("PGX_FM_PACKED");
                     if (a_skip && pkw <= 24 && !(pe && pe[0] == '0')) {
-                        kp = img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, true> : (const void *)pgx_find_mems_pairs_kernel<true, false, true>;
+                        // cooperative line fetches (one address translation per line instead of five) for PAIRS images beyond the reach of the
+                        // translation caches, ~3 GB (profiles/r03_ubench_gather_loads_per_line.txt); PGX_FM_COOP=0 / 1 overrides
+                        bool coop = b->h->img.pairs.size() > (3ull << 30);
+                        if (const char *ce = std::getenv("PGX_FM_COOP")) coop = ce[0] == '1';
+                        kp = coop ? (img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, true, true> : (const void *)pgx_find_mems_pairs_kernel<true, false, true, true>)
+                                  : (img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, true, false> : (const void *)pgx_find_mems_pairs_kernel<true, false, true, false>);
                         a_packed = b->packed.as<uint32_t>();
                         a_pkw = pkw;
-                        plds = (size_t)pkw * PGX_FM_THREADS * 4;
+                        plds = (size_t)pkw * PGX_FM_THREADS * 4 + (coop ? (size_t)(PGX_FM_THREADS / 64) * 8192 : 0);
+                        b->timing.pairs_reads = coop ? 3u : 2u;
                         int occ_p = 0;
                         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_p, kp, PGX_FM_THREADS, plds));
                         if (occ_p < 1) occ_p = 1;
@@ -1298,7 +1320,8 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         }
     }
     b->n_mems = mem_base;
-    b->timing.pairs_reads = kfn_pairs ? 1u : 0u;
+    if (!kfn_pairs) b->timing.pairs_reads = 0u;
+    else if (!b->timing.pairs_reads) b->timing.pairs_reads = 1u; // (2 / 3 when the launch used the packed reads / the cooperative fetches too)
     b->timing.seed_depth = (img.seed_k != 0 && min_len >= img.seed_k && img.dense) ? img.seed_k : 0u;
     if (chunks.size() != 1) { // global CSR offsets (a single chunk's local offsets already are global)
         if (chunks.empty()) { record(b, 1, s); record(b, 2, s); }

@@ -31,6 +31,12 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <atomic>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "../../include/pgx.h"
 
@@ -58,9 +64,35 @@ static inline char *put_str(char *p, const char *s) {
     return p + n;
 }
 
+// read bytes of a batch: pinned host memory from a small pool (pgx_host_alloc: uploads at link speed), ordinary memory when that fails
+struct ReadBuf {
+    char *p = nullptr;
+    size_t cap = 0, len = 0;
+    bool pinned = false;
+};
+class ReadBufPool {
+    std::mutex mu;
+    std::vector<ReadBuf> free_;
+public:
+    ReadBuf get(size_t bytes) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].cap >= bytes) { ReadBuf b = free_[i]; free_.erase(free_.begin() + (std::ptrdiff_t)i); b.len = 0; return b; }
+        }
+        ReadBuf b;
+        b.cap = bytes + bytes / 8 + 4096;
+        void *q = nullptr;
+        if (pgx_host_alloc(b.cap, &q) == PGX_OK) { b.p = static_cast<char *>(q); b.pinned = true; }
+        else { b.p = static_cast<char *>(std::malloc(b.cap)); if (!b.p) throw std::bad_alloc(); }
+        return b;
+    }
+    void put(ReadBuf b) { if (!b.p) return; std::lock_guard<std::mutex> lk(mu); free_.push_back(b); }
+    ~ReadBufPool() { for (auto &b : free_) { if (b.pinned) pgx_host_free(b.p); else std::free(b.p); } }
+};
 struct Job { // one batch of consecutive reads
     uint64_t id = 0, first_seq = 0; // batch number, reads before it in the file
-    std::string cat;
+    ReadBuf cat;
     std::vector<uint64_t> offs;
 };
 struct Done {
@@ -162,83 +194,120 @@ int main(int argc, char **argv) {
     auto time3 = std::chrono::high_resolution_clock::now();
     std::cerr << "Loading tag arrays took " << std::chrono::duration<double>(time3 - time2).count() << " seconds" << std::endl;
 
-    std::ifstream reads(reads_file, std::ios::binary);
-    if (!reads) { std::cerr << "Cannot open reads file: " << reads_file << std::endl; std::exit(EXIT_FAILURE); } // :91
+    // ---- the reads file, mapped: the reference reads it with std::getline (find_mems.cpp:96); here a planner cuts it into byte ranges that
+    //      end at a newline, PARSE threads turn ranges into batches side by side (line splitting was what bounded the single reader thread of
+    //      round 2 at ~1 GB/s), device workers take the batches in file order ----
+    struct MappedFile {
+        const char *p = nullptr;
+        size_t n = 0;
+        std::vector<char> own; // fallback when the file cannot be mapped (a pipe, a FIFO)
+        int fd = -1;
+        bool mapped = false;
+        ~MappedFile() { if (mapped) ::munmap(const_cast<char *>(p), n); if (fd >= 0) ::close(fd); }
+    } mf;
+    {
+        mf.fd = ::open(reads_file.c_str(), O_RDONLY);
+        if (mf.fd < 0) { std::cerr << "Cannot open reads file: " << reads_file << std::endl; std::exit(EXIT_FAILURE); } // :91
+        struct stat st;
+        if (::fstat(mf.fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            void *m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, mf.fd, 0);
+            if (m != MAP_FAILED) { mf.p = static_cast<const char *>(m); mf.n = (size_t)st.st_size; mf.mapped = true; (void)::madvise(m, mf.n, MADV_SEQUENTIAL); }
+        }
+        if (!mf.mapped) { // read it all (what the mapping would have paged in)
+            char buf[1 << 16];
+            for (;;) { const ssize_t k = ::read(mf.fd, buf, sizeof buf); if (k <= 0) break; mf.own.insert(mf.own.end(), buf, buf + k); }
+            mf.p = mf.own.data(); mf.n = mf.own.size();
+        }
+    }
 
     // ---- queues ----
     const unsigned n_workers = (unsigned)devices.size() * streams;
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const unsigned n_fmt = std::max(1u, std::min(16u, hw / n_workers)); // formatting threads per batch
+    unsigned n_parse = std::max(1u, std::min(8u, hw / 4));
+    if (const char *e = std::getenv("PGX_CLI_PARSE_THREADS")) n_parse = (unsigned)std::max(1, std::atoi(e));
     std::mutex mu;
     std::condition_variable cv_jobs, cv_done, cv_space;
-    std::deque<std::unique_ptr<Job>> jobs;
+    std::map<uint64_t, std::unique_ptr<Job>> parsed;     // by id, waiting for a device worker
     std::map<uint64_t, std::unique_ptr<Done>> finished;
     bool reader_done = false, failed = false;
-    uint64_t n_jobs = 0, next_write = 0;
-    const size_t max_ahead = 2 * n_workers + 2; // batches read or finished but not yet written (bounds memory)
+    uint64_t n_jobs = 0, next_write = 0, next_take = 0, next_seq_id = 0, seq_so_far = 0;
+    std::map<uint64_t, uint64_t> counts;                  // reads of parsed ranges whose first_seq is not known yet
+    const size_t max_ahead = 2 * n_workers + n_parse + 2; // ranges parsed or finished but not yet written (bounds memory)
 
-    // The reference reads with std::getline; here lines are split with memchr from 16 MiB chunks.
-    std::thread reader([&]() {
-        std::string carry;
-        std::vector<char> chunk(16u << 20);
-        size_t chunk_len = 0, chunk_pos = 0;
-        bool eof = false;
-        uint64_t seq_no = 0;
-        auto next_line = [&](std::string &cat, bool &empty) -> bool { // next line (without the newline) appended to cat
-            for (;;) {
-                if (chunk_pos < chunk_len) {
-                    const char *base = chunk.data() + chunk_pos;
-                    const char *nl = static_cast<const char *>(std::memchr(base, '\n', chunk_len - chunk_pos));
-                    if (nl) {
-                        const size_t len = (size_t)(nl - base);
-                        empty = carry.empty() && len == 0;
-                        if (!carry.empty()) { cat += carry; carry.clear(); }
-                        cat.append(base, len);
-                        chunk_pos += len + 1;
-                        return true;
-                    }
-                    carry.append(base, chunk_len - chunk_pos); // line continues in the next chunk
-                    chunk_pos = chunk_len;
-                }
-                if (eof) {
-                    if (carry.empty()) return false;
-                    empty = false; // std::getline returns a last line without a terminator
-                    cat += carry;
-                    carry.clear();
-                    return true;
-                }
-                reads.read(chunk.data(), (std::streamsize)chunk.size());
-                chunk_len = (size_t)reads.gcount();
-                chunk_pos = 0;
-                if (chunk_len == 0) eof = true;
+    // ranges: about batch_reads reads each, by the length of the first lines
+    std::vector<std::pair<size_t, size_t>> ranges;
+    {
+        size_t probe = std::min<size_t>(mf.n, 1u << 16), lines = 0;
+        for (size_t i = 0; i < probe; i++) lines += mf.p[i] == '\n';
+        const double per_line = lines ? (double)probe / (double)lines : 152.0;
+        const size_t want = (size_t)std::max(1.0, per_line * (double)batch_reads);
+        size_t at = 0;
+        while (at < mf.n) {
+            size_t end = std::min(mf.n, at + want);
+            if (end < mf.n) {
+                const char *nl = static_cast<const char *>(std::memchr(mf.p + end, '\n', mf.n - end));
+                end = nl ? (size_t)(nl - mf.p) + 1 : mf.n;
             }
-        };
-        bool done = false;
-        while (!done) {
-            std::unique_ptr<Job> j(new Job());
-            j->offs.assign(1, 0);
-            while (j->offs.size() <= batch_reads) {
-                bool empty = false;
-                if (!next_line(j->cat, empty)) { done = true; break; }
-                if (empty) continue; // :97
-                j->offs.push_back(j->cat.size());
-            }
-            const size_t n = j->offs.size() - 1;
-            if (n == 0) break;
-            j->first_seq = seq_no;
-            seq_no += n;
-            std::unique_lock<std::mutex> lk(mu);
-            cv_space.wait(lk, [&]() { return failed || n_jobs - next_write < max_ahead; });
-            if (failed) break;
-            j->id = n_jobs++;
-            jobs.push_back(std::move(j));
-            cv_jobs.notify_one();
+            ranges.emplace_back(at, end);
+            at = end;
         }
-        std::lock_guard<std::mutex> lk(mu);
-        reader_done = true;
-        cv_jobs.notify_all();
-        cv_done.notify_all();
-    });
+    }
+    n_jobs = ranges.size();
+    std::atomic<uint64_t> next_range{0};
+
+    // a range -> the reads it holds, concatenated, with offsets; empty lines are skipped (:97); a last line without a newline counts (std::getline)
+    ReadBufPool pool;
+    auto parse_range = [&](uint64_t id) {
+        std::unique_ptr<Job> j(new Job());
+        const char *q = mf.p + ranges[id].first, *end = mf.p + ranges[id].second;
+        j->id = id;
+        j->cat = pool.get((size_t)(end - q) + 1);
+        j->offs.reserve((size_t)(end - q) / 100 + 16);
+        j->offs.push_back(0);
+        char *dst = j->cat.p;
+        while (q < end) {
+            const char *nl = static_cast<const char *>(std::memchr(q, '\n', (size_t)(end - q)));
+            const size_t len = nl ? (size_t)(nl - q) : (size_t)(end - q);
+            if (len) { std::memcpy(dst, q, len); dst += len; j->offs.push_back((uint64_t)(dst - j->cat.p)); }
+            q += len + 1;
+        }
+        j->cat.len = (size_t)(dst - j->cat.p);
+        return j;
+    };
+    // PGX_CLI_STATS=1: busy seconds of every stage (summed over its threads) on stderr at the end
+    const bool cli_stats = std::getenv("PGX_CLI_STATS") != nullptr;
+    std::atomic<uint64_t> ns_parse{0}, ns_upload{0}, ns_run{0}, ns_download{0}, ns_format{0}, ns_write{0};
+    auto now_ns = []() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const uint64_t t_pipeline0 = now_ns();
+    std::vector<std::thread> parsers;
+    for (unsigned t = 0; t < n_parse; t++)
+        parsers.emplace_back([&]() {
+            for (;;) {
+                const uint64_t id = next_range.fetch_add(1);
+                if (id >= n_jobs) break;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv_space.wait(lk, [&]() { return failed || id < next_write + max_ahead; });
+                    if (failed) break;
+                }
+                const uint64_t tp0 = now_ns();
+                std::unique_ptr<Job> j = parse_range(id);
+                ns_parse += now_ns() - tp0;
+                std::lock_guard<std::mutex> lk(mu);
+                counts[id] = j->offs.size() - 1;
+                parsed[id] = std::move(j);
+                // sequence numbers: a range knows its first read's number once every range before it has been parsed
+                while (counts.count(next_seq_id)) {
+                    parsed[next_seq_id]->first_seq = seq_so_far;
+                    seq_so_far += counts[next_seq_id];
+                    counts.erase(next_seq_id);
+                    next_seq_id++;
+                }
+                cv_jobs.notify_all();
+            }
+        });
+    if (n_jobs == 0) reader_done = true;
 
     auto worker = [&](int device) {
         pgx_batch *b = nullptr; // long-lived: its device and pinned host buffers are reused by every batch of this worker
@@ -246,18 +315,35 @@ int main(int argc, char **argv) {
             std::unique_ptr<Job> j;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv_jobs.wait(lk, [&]() { return failed || !jobs.empty() || reader_done; });
-                if (failed || jobs.empty()) break;
-                j = std::move(jobs.front());
-                jobs.pop_front();
+                // the next range in file order, once it is parsed and numbered
+                cv_jobs.wait(lk, [&]() { return failed || next_take >= n_jobs || (parsed.count(next_take) && next_take < next_seq_id); });
+                if (failed || next_take >= n_jobs) break;
+                j = std::move(parsed[next_take]);
+                parsed.erase(next_take);
+                next_take++;
+                if (next_take >= n_jobs) { reader_done = true; cv_jobs.notify_all(); cv_done.notify_all(); }
             }
             std::unique_ptr<Done> d(new Done());
             const size_t n = j->offs.size() - 1;
+            if (n == 0) { // a range of empty lines only
+                pool.put(j->cat);
+                std::lock_guard<std::mutex> lk(mu);
+                finished[j->id] = std::move(d);
+                cv_done.notify_all();
+                continue;
+            }
             pgx_result r;
-            const uint8_t *rp = reinterpret_cast<const uint8_t *>(j->cat.data());
+            const uint8_t *rp = reinterpret_cast<const uint8_t *>(j->cat.p);
+            uint64_t t0 = now_ns();
             pgx_status st = b ? pgx_batch_upload(b, rp, j->offs.data(), n) : pgx_batch_create(h, device, rp, j->offs.data(), n, &b);
+            uint64_t t1 = now_ns();
             if (st == PGX_OK) st = pgx_batch_run(b, mem_length, min_occ, PGX_RUN_TAGS | PGX_RUN_TIMING, nullptr);
+            uint64_t t2 = now_ns();
             if (st == PGX_OK) st = pgx_batch_result(b, &r);
+            uint64_t t3 = now_ns();
+            ns_upload += t1 - t0; ns_run += t2 - t1; ns_download += t3 - t2;
+            pool.put(j->cat); // (the upload has completed: pgx_batch_upload synchronises its copies)
+            j->cat = ReadBuf();
             if (st != PGX_OK) d->error = pgx_last_error();
             else {
                 pgx_timing t;
@@ -275,6 +361,7 @@ int main(int argc, char **argv) {
                         pool.emplace_back([&, w]() { format_range(r, n * w / parts, n * (w + 1) / parts, j->first_seq, quiet, d->outs[w], d->errs[w]); });
                     for (auto &th : pool) th.join();
                 }
+                ns_format += now_ns() - t3;
             }
             std::lock_guard<std::mutex> lk(mu);
             if (!d->error.empty()) failed = true;
@@ -302,10 +389,12 @@ int main(int argc, char **argv) {
             cv_space.notify_all();
         }
         if (!d->error.empty()) { error = d->error; break; }
+        const uint64_t tw0 = now_ns();
         for (size_t w = 0; w < d->outs.size(); w++) {
             std::fwrite(d->outs[w].data(), 1, d->outs[w].size(), stdout);
             if (!d->errs[w].empty()) std::fwrite(d->errs[w].data(), 1, d->errs[w].size(), stderr);
         }
+        ns_write += now_ns() - tw0;
         total_mem_time += d->mem_s;
         total_tag_time += d->tag_s;
     }
@@ -315,7 +404,7 @@ int main(int argc, char **argv) {
         cv_jobs.notify_all();
         cv_space.notify_all();
     }
-    reader.join();
+    for (auto &th : parsers) th.join();
     for (auto &th : workers) th.join();
     if (error.empty()) // a batch that failed behind one still in flight when the writer stopped
         for (auto &kv : finished)
@@ -327,6 +416,10 @@ int main(int argc, char **argv) {
     }
     std::fflush(stdout);
     std::cout.flush();
+    if (cli_stats)
+        std::fprintf(stderr, "[find_mems] pipeline %.3f s wall; busy seconds: parse %.3f (%u threads), upload %.3f, run %.3f, download %.3f, format %.3f (wall of %u-thread pools), write %.3f; %u device workers\n",
+                     1e-9 * (double)(now_ns() - t_pipeline0), 1e-9 * (double)ns_parse.load(), n_parse, 1e-9 * (double)ns_upload.load(), 1e-9 * (double)ns_run.load(),
+                     1e-9 * (double)ns_download.load(), 1e-9 * (double)ns_format.load(), n_fmt, 1e-9 * (double)ns_write.load(), n_workers);
     std::cout << "\nTotal time for finding all MEMs: " << total_mem_time << " seconds" << std::endl; // :144
     std::cout << "Total time for all tag queries: " << total_tag_time << " seconds" << std::endl;   // :145
     pgx_index_close(h);

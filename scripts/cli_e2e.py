@@ -35,10 +35,11 @@ for extra in (["--streams", "1", "--batch", "1048576"], ["--streams", "1"], ["--
     for dest in ("/dev/null",):
         t0 = time.time()
         with open(dest, "wb") as out:
-            r = subprocess.run([exe, ri, tags, path, str(min_len), "1", "--quiet"] + extra, stdout=out, stderr=subprocess.PIPE)
+            r = subprocess.run([exe, ri, tags, path, str(min_len), "1", "--quiet"] + extra, stdout=out, stderr=subprocess.PIPE, env=dict(os.environ, PGX_CLI_STATS="1"))
         dt = time.time() - t0
         print("%s n=%d %s -> %s: %.2f s wall (%.2f M reads/s end to end), rc=%d" % (wl, n, " ".join(extra), dest, dt, n / dt / 1e6, r.returncode))
-        print("   stderr tail:", r.stderr.decode().strip().split("\n")[-2:], flush=True)
+        err = r.stderr.decode().strip().split("\n")
+        print("   ", [l for l in err if "took" in l or "[find_mems]" in l], flush=True)
 
 if len(sys.argv) > 3 and sys.argv[3] == "check":
     import hashlib

@@ -130,3 +130,34 @@ def test_wide_kernels_against_the_oracle(wide_case, monkeypatch, shift):
         assert b.timing().pairs_reads == (1 if force == P.MODE_IMAGE_PAIRS else 0) and b.timing().seed_depth > 0
         b.free()
         idx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wide", [0, 1])
+def test_cooperative_line_fetches_against_the_oracle(wide_case, monkeypatch, wide):
+    """pgx_find_mems_pairs_kernel<.., COOP>: the wave fetches the 64 block lines of its lanes together through LDS (global_load_lds), the variant
+    for PAIRS images beyond the reach of the address-translation caches -- forced here on a small index, narrow and wide, with reads that are
+    handed on, heavy reads and idle lanes in the mix"""
+    ri_path, tags_path, text = wide_case
+    monkeypatch.setenv("PGX_SB_SHIFT", "3")
+    monkeypatch.setenv("PGX_FM_COOP", "1")
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    seqs = W.load_sequences(text)
+    cat, offs = W.sample_reads(seqs, 60_000, 150, seed=9)
+    extra = [bytes(seqs[0][-150:]), bytes(seqs[1][:150]), bytes(seqs[2][-40:]), b"ACGT" * 30, b"", b"A"]
+    ecat, eoffs = O.pack_reads(extra)
+    cat = np.concatenate([cat, ecat]); offs = np.concatenate([offs, eoffs[1:] + offs[-1]])
+    idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | P.MODE_IMAGE_PAIRS | (P.MODE_IMAGE_WIDE if wide else 0))
+    for min_len, min_occ in ((20, 1), (12, 1), (25, 3), (31, 1)):
+        ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, threads=4)
+        b = idx.batch(cat, offs)
+        for _ in range(2):
+            b.run(min_len, min_occ, P.RUN_TAGS | P.RUN_TIMING)
+            assert b.timing().pairs_reads == 3  # the cooperative variant ran
+            res = b.result()
+            assert np.array_equal(res["mem_offsets"], ref["mem_offsets"]), (wide, min_len, min_occ)
+            assert res["mems"].tobytes() == ref["mems"].tobytes()
+            assert res["n_extensions"] == ref["n_extensions"]
+            assert np.array_equal(res["pos_offsets"], ref["pos_offsets"]) and np.array_equal(res["positions"], ref["positions"])
+        b.free()
+    idx.close()
