@@ -1003,19 +1003,23 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     __shared__ uint32_t s_ext[512];
     __shared__ pos_t s_C[8];
     __shared__ pos_t s_t2[32];
-    __shared__ uint64_t s_pb[WIDE ? PGX_SB_MAX * 24 : 1]; // WIDE: per superblock the sixteen pair-count bases and their four row sums
-    __shared__ uint4 s_fe[512]; // first_ext: [byte] the full interval extended by byte, [256 + byte] extended by 0 and then by byte (packed like a seed entry)
+    // first_ext: [byte] the full interval extended by byte, [256 + byte] extended by 0 and then by byte (packed like a seed entry); PACKED (every byte is
+    // one of A C G T): [code] by "ACTG"[code], [4] by 0, [5 + code] by 0 and then by "ACTG"[code]
+    __shared__ uint4 s_fe[PACKED ? 16 : 512];
     extern __shared__ __align__(16) unsigned char pgx_dyn_lds[];
     static_assert(!COOP || PACKED, "the cooperative loads come with the packed reads");
     uint32_t *s_rd = reinterpret_cast<uint32_t *>(pgx_dyn_lds); // PACKED: word w of this thread's read at s_rd[w * blockDim.x + threadIdx.x] (pk_words words per thread)
     const uint32_t rd_stride = blockDim.x;
     // COOP: behind the packed reads, 8 KiB per wave: piece p of the line of lane q's probe at [q * 8 + (p ^ (q & 7))] (the swizzle spreads the banks)
     uint4 *s_stage = reinterpret_cast<uint4 *>(pgx_dyn_lds + (size_t)pk_words * PGX_FM_THREADS * 4) + (size_t)(threadIdx.x >> 6) * 512;
+    // WIDE: behind those, per superblock the sixteen pair-count bases and their four row sums (24 words each, img.n_sbp superblocks)
+    uint64_t *s_pb = reinterpret_cast<uint64_t *>(pgx_dyn_lds + (size_t)pk_words * PGX_FM_THREADS * 4 + (COOP ? (size_t)(PGX_FM_THREADS / 64) * 8192 : 0));
     for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) s_ext[i] = img.consts->ext_tab[i];
     if (threadIdx.x < 8) s_C[threadIdx.x] = (pos_t)img.consts->C[threadIdx.x];
     if (threadIdx.x < 32) s_t2[threadIdx.x] = (pos_t)img.consts->pair_t2w[threadIdx.x];
     if (WIDE) for (uint32_t i = threadIdx.x; i < img.n_sbp * 24u; i += blockDim.x) s_pb[i] = img.pbase[i];
-    for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) s_fe[i] = img.first_ext[i];
+    if (PACKED) { if (threadIdx.x < 9) s_fe[threadIdx.x] = img.first_ext[threadIdx.x == 4 ? 0u : (threadIdx.x > 4 ? 256u : 0u) + ((0x47544341u >> (8u * ((threadIdx.x > 4 ? threadIdx.x - 5u : threadIdx.x) & 3u))) & 0xFFu)]; }
+    else for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) s_fe[i] = img.first_ext[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -1279,7 +1283,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 // first extension (src/r-index.cpp:713-764); a symbol that is not A C G T has no occurrence in a range free of special positions
                 pos_t s1 = reg1 ? (pos_t)c1 : (pos_t)0;
                 pos_t k1 = r1 + s_C[PGX_EXT_V(e1)], q1v = kq + (pos_t)w1;
-                if (fr) { const uint4 f = s_fe[byte]; k1 = ent_k(f); q1v = ent_q(f); s1 = ent_s(f); }
+                if (fr) { const uint4 f = s_fe[PACKED ? (at_end ? 4u : ((byte >> 1) & 3u)) : byte]; k1 = ent_k(f); q1v = ent_q(f); s1 = ent_s(f); }
                 const bool small1 = s1 == 0u || s1 < mo || mo_huge;
                 // a usable seed entry stands for the first extension and the ones after it
                 const uint32_t sdepth = se.w >> 24;
@@ -1288,7 +1292,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 const bool seed_dead = SEED && seed_lane && se_s == 0u && sdepth != PGX_SEED_UNUSABLE && min_occ <= 1;
                 const bool do2 = (fr ? (at_end && rem2 && have2 && !seed_alive && !seed_dead) : two) && !small1;
                 pos_t s2 = (pos_t)c2, k2 = r2 + s_C[PGX_EXT_V(e2)] + s_t2[8u * t1 + cv2], q2v = q1v + (pos_t)w2;
-                if (fr) { const uint4 f = s_fe[256u + byte2]; k2 = ent_k(f); q2v = ent_q(f); s2 = ent_s(f); }
+                if (fr) { const uint4 f = s_fe[PACKED ? 5u + ((byte2 >> 1) & 3u) : 256u + byte2]; k2 = ent_k(f); q2v = ent_q(f); s2 = ent_s(f); }
                 pos_t ns = do2 ? s2 : s1, nk = do2 ? k2 : k1, nq = do2 ? q2v : q1v;
                 if (ns == 0u) { nk = 0u; nq = 0u; }
                 if (do2) { // the first of the two: what a trip of its own would have left behind

@@ -1127,7 +1127,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         // (only behind the seed table: the wide intervals at the start of an unseeded stage always have special positions between their ends)
         if (img.pairs && seeded && !(n >> 32) && b->read_bytes < (1ull << 35) && !(pv && pv[0] == '0'))
             kfn_pairs = img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, false, false> : (const void *)pgx_find_mems_pairs_kernel<true, false, false, false>;
-        pairs_lds = 0;
+        pairs_lds = img.wide ? (size_t)img.n_sbp * 192 : 0; // (superblock bases of the wide form, behind the other dynamic LDS)
         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn_pairs ? kfn_pairs : kfn, PGX_FM_THREADS, kfn_pairs ? pairs_lds : b->dimg->lds_bytes));
         HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
         if (occ < 1) occ = 1;
@@ -1252,7 +1252,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                                   : (img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, true, false> : (const void *)pgx_find_mems_pairs_kernel<true, false, true, false>);
                         a_packed = b->packed.as<uint32_t>();
                         a_pkw = pkw;
-                        plds = (size_t)pkw * PGX_FM_THREADS * 4 + (coop ? (size_t)(PGX_FM_THREADS / 64) * 8192 : 0);
+                        plds = (size_t)pkw * PGX_FM_THREADS * 4 + (coop ? (size_t)(PGX_FM_THREADS / 64) * 8192 : 0) + (img.wide ? (size_t)img.n_sbp * 192 : 0);
                         b->timing.pairs_reads = coop ? 3u : 2u;
                         int occ_p = 0;
                         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_p, kp, PGX_FM_THREADS, plds));
