@@ -56,11 +56,34 @@ def build_index_from_rlbwt(rlbwt_path, workdir, name, encoded=True, with_tags=Tr
     return ri, tags
 
 
-def build_index_from_text(text_path, workdir, name, encoded=True, with_tags=True):
+def build_index_from_text(text_path, workdir, name, encoded=True, with_tags=True, parts=None):
+    """parts (None: by size): build through pgx_build_index_from_texts with the sequences of the text dealt into that many texts of consecutive
+    sequences -- the same bytes as the single suffix array gives (tests/test_formats.py), in a fraction of the time on a many-core host"""
     os.makedirs(workdir, exist_ok=True)
     rl = os.path.join(workdir, name + ".rl_bwt")
     ri = os.path.join(workdir, name + (".ri" if encoded else ".legacy.ri"))
-    pgx_ffi.build_index_from_text(text_path, rl, ri, encoded)  # one suffix array for the BWT and the SA samples
+    if parts is None:
+        parts = 4 if os.path.getsize(text_path) >= (64 << 20) else 1
+    pieces = []
+    if parts > 1:
+        raw = open(text_path, "rb").read()
+        ends = np.flatnonzero(np.frombuffer(raw, dtype=np.uint8) == 10) + 1  # one past every newline
+        if len(raw) and raw[-1] != 10:
+            ends = np.append(ends, len(raw))
+        if len(ends) >= parts:
+            cuts = [0] + [int(ends[len(ends) * (k + 1) // parts - 1]) for k in range(parts)]
+            for k in range(parts):
+                pth = os.path.join(workdir, "%s.part%d.txt" % (name, k))
+                with open(pth, "wb") as f:
+                    f.write(raw[cuts[k]:cuts[k + 1]])
+                pieces.append(pth)
+        del raw
+    if pieces:
+        pgx_ffi.build_index_from_texts(pieces, rl, ri, encoded)
+        for pth in pieces:
+            os.remove(pth)
+    else:
+        pgx_ffi.build_index_from_text(text_path, rl, ri, encoded)  # one suffix array for the BWT and the SA samples
     tags = None
     if with_tags:
         tags = os.path.join(workdir, name + ".compact.tags")
