@@ -19,6 +19,8 @@ enum PgxCounterSlot {
     PGX_CTR_REDO = 11,        // reads the pairs kernel handed on
     PGX_CTR_REDO_CURSOR = 12, // read cursor of the hand-on launch
     PGX_CTR_SIDE_CURSOR = 13, // read cursor of the side-stream launch (reads with a byte outside A C G T)
+    PGX_CTR_OVF_TOP = 14,     // slots handed out of the arena of fifth-and-later MEMs (pgx_slot_extent)
+    PGX_CTR_OVF_ABORT = 15,   // the arena was too small: the chunk is repeated in the worst-case slot layout
     PGX_CTR_TAG0 = 16,        // 16..24: tag stage (tag_pipeline)
     PGX_CTR_ABORT = 30,       // abort flag of a speculative run
     // what the kernels ask of the memory system (always on; bench.py's roofline): lane trips that fetch a rank-image line that is
@@ -31,8 +33,12 @@ enum PgxCounterSlot {
     // -DPGX_FM_STATS builds only (scripts/fm_stats.sh)
     PGX_CTR_ST_TRIPS = 40, PGX_CTR_ST_LIVE = 41, PGX_CTR_ST_LONGEST = 42,                  // pgx_find_mems_kernel: wave trips, live lane trips, longest wave
     PGX_CTR_ST_PAIR_TRIPS = 43, PGX_CTR_ST_PAIR_LIVE = 44, PGX_CTR_ST_PAIR_WAIT = 45, PGX_CTR_ST_PAIR_FRESH = 46,
-    PGX_CTR_SLOTS = 64
+    PGX_CTR_SLOTS = 64,  // (what the host reads back)
+    PGX_CTR_ARENA0 = 64, // counters of the PGX_ARENA_SUBS sub-arenas, 16 slots (one cache line) apart
+    PGX_CTR_ALL = 64 + 16 * 64
 };
+#define PGX_ARENA_SUBS 64u
+__global__ void pgx_arena_demand_kernel(unsigned long long *ctr);
 
 #define PGX_DENSE_LDS_U4 5 // uint4 slots per dense block in LDS (64 data bytes + 16 of padding)
 #define PGX_FM_THREADS 256
@@ -99,7 +105,7 @@ __global__ void pgx_find_mems_heavy_kernel(PgxDevImage img, const uint8_t *reads
                                            const uint64_t *slot_off, uint64_t slot_base, pgx_mem *slots, uint32_t *mem_count,
                                            unsigned long long *n_ext_total, const pgx_heavy_item *heavy_list,
                                            const unsigned long long *heavy_count, uint32_t heavy_cap, PgxHeavyResult *scratch, uint64_t chunk_first,
-                                           uint64_t chunk_reads);
+                                           uint64_t chunk_reads, uint32_t *ovf_base, uint64_t ovf_cap);
 
 __global__ void pgx_seed_build_kernel(PgxDevImage img, const uint4 *src, uint4 *dst, uint32_t level, uint64_t n_dst, uint64_t limit, int end_table);
 template <bool LDS_IMAGE, int DENSE, bool NARROW, bool SEED> // DENSE = image kind
@@ -107,14 +113,15 @@ __global__ void pgx_find_mems_kernel(PgxDevImage img, const uint8_t *reads, cons
                                      uint64_t min_len, uint64_t min_occ, const uint64_t *slot_off, pgx_mem *slots,
                                      uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor, uint64_t first_read,
                                      uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap, pgx_heavy_item *heavy_list, unsigned long long *heavy_count,
-                                     const pgx_heavy_item *rid_list, const unsigned long long *rid_count);
+                                     const pgx_heavy_item *rid_list, const unsigned long long *rid_count, uint32_t *ovf_base, uint64_t ovf_cap);
 // PAIRS image (pgx_image.h): two extensions per loop trip; reads that meet a special position go to redo_list (then served by the kernel above)
 template <bool SEED, bool WIDE, bool PACKED, bool COOP>
 __global__ void pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
                                            uint64_t min_len, uint64_t min_occ, const uint64_t *slot_off, pgx_mem *slots,
                                            uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor, uint64_t first_read,
                                            uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap, pgx_heavy_item *heavy_list, unsigned long long *heavy_count,
-                                           pgx_heavy_item *redo_list, unsigned long long *redo_count, const uint8_t *skip, const uint32_t *packed, uint32_t pk_words);
+                                           pgx_heavy_item *redo_list, unsigned long long *redo_count, const uint8_t *skip, const uint32_t *packed, uint32_t pk_words,
+                                           uint32_t *ovf_base, uint64_t ovf_cap);
 __global__ void pgx_bad_chunks_kernel(const uint8_t *reads, uint64_t n_bytes, uint64_t *chunks, unsigned long long *count, uint64_t cap, uint32_t *packed);
 __global__ void pgx_classify_reads_kernel(const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads, const uint64_t *chunks, const unsigned long long *n_chunks,
                                           uint64_t cap, uint32_t *flag_words, pgx_heavy_item *list, unsigned long long *count);
@@ -135,7 +142,7 @@ __global__ void pgx_scan_apply_kernel(int mode, const void *in, uint64_t n, uint
                                       uint64_t nb, uint64_t *out, uint64_t *total_out, int raw_sums, const uint64_t *n_dev);
 __global__ void pgx_compact_mems_kernel(uint64_t first_read, uint64_t n_reads, const uint64_t *slot_off, uint64_t slot_base,
                                         const pgx_mem *slots, const uint32_t *mem_count, const uint64_t *local_off,
-                                        uint64_t mem_base, pgx_mem *mems, uint64_t cap_mems, uint64_t *abort);
+                                        uint64_t mem_base, pgx_mem *mems, uint64_t cap_mems, uint64_t *abort, const uint32_t *ovf_base, uint64_t ovf_cap);
 __global__ void pgx_tag_pair_kernel(const uint64_t *tstart, const uint64_t *tvals, uint64_t n_runs, uint64_t n_items, ulonglong2 *out);
 #define PGX_TAG_LOCATE_THREADS 1024 // workgroup of pgx_tag_locate_kernel (one list atomic per workgroup)
 #define PGX_SORT_LDS_CAP 2048 // values per wave sorted in an LDS slice (pgx_tag_sort_unique_kernel)

@@ -532,6 +532,30 @@ pgx_seed_build_kernel(PgxDevImage img, const uint4 *__restrict__ src, uint4 *__r
 __device__ __forceinline__ uint64_t pgx_slot_index(uint64_t read_in_chunk, uint64_t chunk_reads, uint64_t slot, uint32_t nm) {
     return nm < PGX_FAST_SLOTS ? read_in_chunk * PGX_FAST_SLOTS + nm : chunk_reads * PGX_FAST_SLOTS + slot + nm;
 }
+// Where the fifth and later MEMs of a read go (`slot` of pgx_slot_index).  Worst-case layout (ovf_cap == 0): the read's offset in the scan of
+// min(len, len - min_len + 1), 131 slots per 150-bp read -- 42 GB for 10 M reads that write 0.6 GB.  ARENA (round 3): a read reserves its extent when it
+// emits its fifth MEM (2 % of the reads do) -- as many slots as it has start positions left, which bounds what it can still emit -- with one atomic,
+// and records it in ovf_base[rid] for its later MEMs, the kernels that continue the read, and the compaction.  The arena is PGX_ARENA_SUBS sub-arenas,
+// one per residue of the workgroup number, each with a counter on a cache line of its own (ctr + PGX_CTR_ARENA0 + 16 sub): one counter for everybody
+// serialised 48 k atomics into 0.7 ms on the x fixture (a 0.6 ms kernel).  A sub-arena that proves too small raises PGX_CTR_OVF_ABORT (the writes
+// then land at its start, in bounds) and the host repeats the chunk in the worst-case layout.
+__device__ __forceinline__ uint64_t pgx_slot_extent(const uint64_t *__restrict__ slot_off, uint64_t slot_base, uint32_t *__restrict__ ovf_base, uint64_t ovf_cap,
+                                                    unsigned long long *__restrict__ ctr, uint64_t rid, uint32_t nm, int32_t len, int32_t x, uint64_t min_len) {
+    if (!ovf_cap) return slot_off[rid] - slot_base;
+    if (nm == PGX_FAST_SLOTS) {
+        const int64_t ml = min_len ? (int64_t)min_len : 1;
+        const int64_t left = (int64_t)len - ml - (int64_t)x + 1; // start positions from x on (x itself has just produced a MEM)
+        const unsigned long long ext = left > 0 ? (unsigned long long)left : 1ull;
+        const uint32_t sub = blockIdx.x & (PGX_ARENA_SUBS - 1u);
+        const uint64_t sub_cap = ovf_cap / PGX_ARENA_SUBS;
+        unsigned long long at = atomicAdd(ctr + PGX_CTR_ARENA0 + 16u * sub, ext);
+        if (at + ext > sub_cap) { ctr[PGX_CTR_OVF_ABORT] = 1ull; at = 0ull; }
+        at += (unsigned long long)sub * sub_cap;
+        ovf_base[rid] = (uint32_t)at;
+        return at - PGX_FAST_SLOTS; // (pgx_slot_index adds nm)
+    }
+    return (uint64_t)ovf_base[rid] - PGX_FAST_SLOTS;
+}
 
 // ------------------------------------------------------------------------------------------
 // find_all_mems for a batch.  State machine of find_mems_function (algorithm.hpp:653-736):
@@ -563,7 +587,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                      pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
                      unsigned long long *__restrict__ cursor, uint64_t first_read, uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap,
                      pgx_heavy_item *__restrict__ heavy_list, unsigned long long *__restrict__ heavy_count,
-                     const pgx_heavy_item *__restrict__ rid_list, const unsigned long long *__restrict__ rid_count) {
+                     const pgx_heavy_item *__restrict__ rid_list, const unsigned long long *__restrict__ rid_count, uint32_t *__restrict__ ovf_base, uint64_t ovf_cap) {
     __shared__ uint32_t s_ext[512];
     __shared__ uint64_t s_C[8];
     __shared__ uint64_t s_sb[DENSE == 3 ? PGX_SB_MAX * 8 : 1]; // WIDE dense2: superblock bases
@@ -582,7 +606,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     typedef typename std::conditional<NARROW, uint32_t, uint64_t>::type pos_t;
     const int lane = threadIdx.x & 63;
     const pos_t n = (pos_t)img.n;
-    uint64_t rid = 0, base = 0, slot = 0;
+    uint64_t rid = 0, base = 0;
     int32_t len = 0, x = 0, j = 0;
     pos_t k = 0, kp = 0, s = 0, Jk = 0, Js = 0;
     uint32_t nm = 0, next = 0, next0 = 0; // next0: value of `next` when the current read was taken
@@ -629,6 +653,8 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     auto emit = [&]() __attribute__((always_inline)) {
         pgx_mem m;
         m.start = (uint64_t)x; m.end = (uint64_t)j; m.bwt_start = (uint64_t)Jk; m.size = (int64_t)(uint64_t)Js; // e == j at every emit
+        // (the extent of the read is looked up -- or, in an arena, reserved -- only by a fifth MEM: the first PGX_FAST_SLOTS have their own line)
+        const uint64_t slot = nm < PGX_FAST_SLOTS ? 0ull : pgx_slot_extent(slot_off, slot_base, ovf_base, ovf_cap, n_ext_total, rid, nm, len, x, min_len);
         slots[pgx_slot_index(rid - chunk_first, chunk_reads, slot, nm)] = m;
         nm++;
         k = 0; kp = 0; s = n;
@@ -664,7 +690,6 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                 if (rid_list) { const pgx_heavy_item it = rid_list[rid]; rid = it.rid; x = (int32_t)it.x; nm = it.nm; }
                 base = offsets[rid];
                 len = (int32_t)(offsets[rid + 1] - base);
-                slot = slot_off[rid] - slot_base; // slots are reused per chunk of reads (pgx_batch_run)
                 next0 = next;
                 begin(); // may leave the lane idle again (read shorter than min_len)
                 if (ph == 0) ph = -1; // served in this round; becomes idle again below
@@ -887,7 +912,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     template __global__ void pgx_find_mems_kernel<__VA_ARGS__>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t,     \
                                                                const uint64_t *, pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, \
                                                                uint64_t, uint64_t, uint32_t, uint32_t, pgx_heavy_item *, unsigned long long *,     \
-                                                               const pgx_heavy_item *, const unsigned long long *);
+                                                               const pgx_heavy_item *, const unsigned long long *, uint32_t *, uint64_t);
 PGX_FM_INSTANTIATE(false, 0, false, false)
 PGX_FM_INSTANTIATE(false, 1, false, false)
 PGX_FM_INSTANTIATE(true, 0, false, false)
@@ -904,6 +929,14 @@ PGX_FM_INSTANTIATE(false, 2, false, true)
 PGX_FM_INSTANTIATE(false, 2, true, true)
 PGX_FM_INSTANTIATE(false, 3, false, false)
 PGX_FM_INSTANTIATE(false, 3, false, true)
+
+// what the reads asked of the arena, for the host to size the next one: PGX_CTR_OVF_TOP = PGX_ARENA_SUBS x the fullest sub-arena's demand
+__global__ void pgx_arena_demand_kernel(unsigned long long *__restrict__ ctr) {
+    unsigned long long m = ctr[PGX_CTR_ARENA0 + 16u * threadIdx.x]; // (launched with PGX_ARENA_SUBS = 64 threads: one wave)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_down(m, off, 64); m = o > m ? o : m; }
+    if (threadIdx.x == 0) ctr[PGX_CTR_OVF_TOP] = m * PGX_ARENA_SUBS;
+}
 
 // ------------------------------------------------------------------------------------------
 // Reads with a byte outside A C G T (upper case): no seed applies to a window that holds one, so the two-step kernel could only hand
@@ -998,7 +1031,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                            unsigned long long *__restrict__ cursor, uint64_t first_read, uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap,
                            pgx_heavy_item *__restrict__ heavy_list, unsigned long long *__restrict__ heavy_count,
                            pgx_heavy_item *__restrict__ redo_list, unsigned long long *__restrict__ redo_count, const uint8_t *__restrict__ skip,
-                           const uint32_t *__restrict__ packed, uint32_t pk_words) {
+                           const uint32_t *__restrict__ packed, uint32_t pk_words, uint32_t *__restrict__ ovf_base, uint64_t ovf_cap) {
     typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type pos_t;
     __shared__ uint32_t s_ext[512];
     __shared__ pos_t s_C[8];
@@ -1069,7 +1102,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         pgx_mem m;
         m.start = (uint64_t)x; m.end = (uint64_t)j; m.bwt_start = (uint64_t)Jk; m.size = (int64_t)(uint64_t)Js;
         // (the worst-case offset of the read is looked up only by a fifth MEM: the first PGX_FAST_SLOTS have their own line)
-        const uint64_t slot = nm < PGX_FAST_SLOTS ? 0ull : slot_off[rid] - slot_base;
+        const uint64_t slot = nm < PGX_FAST_SLOTS ? 0ull : pgx_slot_extent(slot_off, slot_base, ovf_base, ovf_cap, n_ext_total, (uint64_t)rid, nm, len, x, min_len);
         slots[pgx_slot_index((uint64_t)rid - first_read, n_reads - first_read, slot, nm)] = m;
         nm++;
         k = 0; kp = 0; s = n;
@@ -1348,7 +1381,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     template __global__ void pgx_find_mems_pairs_kernel<__VA_ARGS__>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t, const uint64_t *, \
                                                                      pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t, uint32_t, \
                                                                      uint32_t, pgx_heavy_item *, unsigned long long *, pgx_heavy_item *, unsigned long long *,       \
-                                                                     const uint8_t *, const uint32_t *, uint32_t);
+                                                                     const uint8_t *, const uint32_t *, uint32_t, uint32_t *, uint64_t);
 PGX_PAIRS_INSTANTIATE(true, false, false, false)
 PGX_PAIRS_INSTANTIATE(true, true, false, false)
 PGX_PAIRS_INSTANTIATE(true, false, true, false)
@@ -1429,7 +1462,8 @@ pgx_find_mems_heavy_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                            uint64_t min_occ, const uint64_t *__restrict__ slot_off, uint64_t slot_base, pgx_mem *__restrict__ slots,
                            uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
                            const pgx_heavy_item *__restrict__ heavy_list, const unsigned long long *__restrict__ heavy_count,
-                           uint32_t heavy_cap, PgxHeavyResult *__restrict__ scratch, uint64_t chunk_first, uint64_t chunk_reads) {
+                           uint32_t heavy_cap, PgxHeavyResult *__restrict__ scratch, uint64_t chunk_first, uint64_t chunk_reads,
+                           uint32_t *__restrict__ ovf_base, uint64_t ovf_cap) {
     unsigned long long cnt = *heavy_count;
     if (cnt == 0) return; // the usual case: nothing was handed on (uniform exit before any staging)
     if (cnt > heavy_cap) cnt = heavy_cap;
@@ -1450,14 +1484,16 @@ pgx_find_mems_heavy_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         __threadfence_block();
         __syncthreads();
         if (threadIdx.x == 0) {
-            const uint64_t slot = slot_off[it.rid] - slot_base;
             uint32_t nm = it.nm;
             unsigned long long ne = 0;
             int32_t x = x0;
             while (x < len && (uint64_t)(len - x) >= min_len) {
                 const PgxHeavyResult r = res[x - x0];
                 ne += r.n_ext;
-                if (r.has_mem) { slots[pgx_slot_index(it.rid - chunk_first, chunk_reads, slot, nm)] = r.mem; nm++; }
+                if (r.has_mem) {
+                    const uint64_t slot = nm < PGX_FAST_SLOTS ? 0ull : pgx_slot_extent(slot_off, slot_base, ovf_base, ovf_cap, n_ext_total, it.rid, nm, len, x, min_len);
+                    slots[pgx_slot_index(it.rid - chunk_first, chunk_reads, slot, nm)] = r.mem; nm++;
+                }
                 x = (int32_t)r.next_x;
             }
             mem_count[it.rid] = nm;
@@ -1468,10 +1504,10 @@ pgx_find_mems_heavy_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
 }
 template __global__ void pgx_find_mems_heavy_kernel<false>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, const uint64_t *, uint64_t,
                                                            pgx_mem *, uint32_t *, unsigned long long *, const pgx_heavy_item *,
-                                                           const unsigned long long *, uint32_t, PgxHeavyResult *, uint64_t, uint64_t);
+                                                           const unsigned long long *, uint32_t, PgxHeavyResult *, uint64_t, uint64_t, uint32_t *, uint64_t);
 template __global__ void pgx_find_mems_heavy_kernel<true>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, const uint64_t *, uint64_t,
                                                           pgx_mem *, uint32_t *, unsigned long long *, const pgx_heavy_item *,
-                                                          const unsigned long long *, uint32_t, PgxHeavyResult *, uint64_t, uint64_t);
+                                                          const unsigned long long *, uint32_t, PgxHeavyResult *, uint64_t, uint64_t, uint32_t *, uint64_t);
 
 // ------------------------------------------------------------------------------------------
 // primitives for tests (mirror rank_at_cached_encoded / backward_extend_encoded / forward_...)
@@ -1630,12 +1666,12 @@ __global__ void __launch_bounds__(256)
 pgx_compact_mems_kernel(uint64_t first_read, uint64_t n_reads, const uint64_t *__restrict__ slot_off, uint64_t slot_base,
                         const pgx_mem *__restrict__ slots, const uint32_t *__restrict__ mem_count,
                         const uint64_t *__restrict__ local_off, uint64_t mem_base, pgx_mem *__restrict__ mems, uint64_t cap_mems,
-                        uint64_t *__restrict__ abort) {
+                        uint64_t *__restrict__ abort, const uint32_t *__restrict__ ovf_base, uint64_t ovf_cap) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // read first_read + t of this chunk
     if (t >= n_reads) return;
     const uint64_t i = first_read + t;
     const uint32_t c = mem_count[i];
-    const uint64_t src = slot_off[i] - slot_base, dst = mem_base + local_off[t];
+    const uint64_t src = c <= PGX_FAST_SLOTS ? 0ull : (ovf_cap ? (uint64_t)ovf_base[i] - PGX_FAST_SLOTS : slot_off[i] - slot_base), dst = mem_base + local_off[t];
     if (dst + c > cap_mems) { // speculative sizing: the MEM array was sized from an earlier run and this one has more
         if (c && abort) atomicOr((unsigned long long *)abort, 16ull);
         return;

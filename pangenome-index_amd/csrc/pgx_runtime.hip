@@ -918,7 +918,8 @@ struct pgx_batch {
     uint64_t plan_min_len = 0, plan_budget = 0;
     DevBuf reads, offsets;
     // run state
-    DevBuf slot_off, slots, mem_count, mem_off, mems, scan_tmp, counters, heavy_list, heavy_scratch, redo_list, read_flags, side_list, side_count, packed;
+    DevBuf slot_off, slots, mem_count, mem_off, mems, scan_tmp, counters, heavy_list, heavy_scratch, redo_list, read_flags, side_list, side_count, packed, ovf_base;
+    uint64_t last_ovf_used = 0; // arena slots the last run handed out (sizes the next arena)
     uint64_t max_read_len = 0; // longest read of the upload (sizes the LDS columns of the packed pairs kernel)
     TagWork tw;
     uint64_t n_mems = 0, n_positions = 0, n_ext = 0, n_tag_overflow = 0;
@@ -940,7 +941,7 @@ static void batch_release(pgx_batch *b) {
     if (!b) return;
     if (hipSetDevice(b->device) == hipSuccess) {
         DevBuf *all[] = {&b->reads, &b->offsets, &b->slot_off, &b->slots, &b->mem_count, &b->mem_off, &b->mems, &b->scan_tmp,
-                         &b->counters, &b->heavy_list, &b->heavy_scratch, &b->redo_list, &b->read_flags, &b->side_list, &b->side_count, &b->packed};
+                         &b->counters, &b->heavy_list, &b->heavy_scratch, &b->redo_list, &b->read_flags, &b->side_list, &b->side_count, &b->packed, &b->ovf_base};
         for (DevBuf *d : all) d->release();
         b->tw.release();
         HostBuf *hb[] = {&b->h_mem_off, &b->h_mems, &b->h_run_nums, &b->h_pos_off, &b->h_positions};
@@ -1045,11 +1046,12 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     // same shape (reads, min_len, min_occ, tags), the buffers and grids are sized from ITS totals (+ 25 %), all counts stay on the
     // device, capacity checks raise an abort flag there, and the host reads everything once at the end; if the flag came up (or the
     // 32-bit state overflowed) the run is repeated in exact mode.  PGX_SPEC=0 switches it off.
+    bool force_worst = false; // the arena of a speculative pass overflowed: the exact pass uses the worst-case slot layout
     for (int pass = 0;; pass++) {
     b->n_mems = b->n_positions = b->n_ext = b->n_tag_overflow = 0;
     std::memset(&b->timing, 0, sizeof b->timing);
-    b->counters.ensure(PGX_CTR_SLOTS * 8); // layout: PgxCounterSlot (pgx_device.h)
-    HIPCHECK(hipMemsetAsync(b->counters.p, 0, PGX_CTR_SLOTS * 8, s));
+    b->counters.ensure(PGX_CTR_ALL * 8); // layout: PgxCounterSlot (pgx_device.h)
+    HIPCHECK(hipMemsetAsync(b->counters.p, 0, PGX_CTR_ALL * 8, s));
     unsigned long long *d_next = b->counters.as<unsigned long long>();
     unsigned long long *d_nover = d_next + PGX_CTR_TAG_OVERFLOW;
 
@@ -1093,7 +1095,12 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     for (auto &c : chunks) max_slots = std::max(max_slots, c.slots);
     uint64_t max_chunk_reads = 1;
     for (auto &c : chunks) max_chunk_reads = std::max(max_chunk_reads, c.r1 - c.r0);
-    b->slots.ensure((max_slots + 4 * max_chunk_reads) * sizeof(pgx_mem)); // 4 = PGX_FAST_SLOTS (pgx_kernels.hip pgx_slot_index): dense array of the first MEMs + worst-case region
+    // The slot buffer: a dense array of the first four MEMs of every read (PGX_FAST_SLOTS, pgx_kernels.hip pgx_slot_index) + either an ARENA for the
+    // fifth and later MEMs, sized from the last run of this batch (or two slots per read), or -- PGX_SLOT_ARENA=0, tiny batches, and the repeat of a chunk
+    // whose arena proved too small -- the worst-case region (max_slots).  Sized per chunk below.
+    const char *arena_env = std::getenv("PGX_SLOT_ARENA");
+    const bool arena_on = !(arena_env && arena_env[0] == '0') && !force_worst;
+    b->ovf_base.ensure((max_chunk_reads ? max_chunk_reads : 1) * 4);
     // 2. the hot kernel, 3. CSR offsets + compaction (per chunk)
     float ms_fm = 0, ms_cp = 0, ms_main = 0;
     uint64_t mem_base = 0;
@@ -1168,9 +1175,25 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         uint64_t *local = b->mem_off.as<uint64_t>() + c.r0; // local CSR offsets of this chunk (scratch until the global scan below)
         uint64_t cm = 0;
         const void *kf = kfn;
+        // arena for the fifth and later MEMs of this chunk's reads (0 = worst-case layout)
+        uint64_t ovf_cap = 0;
+        if (arena_on) {
+            uint64_t want = b->shape_valid && b->shape_reads == n && b->shape_min_len == min_len && chunks.size() == 1 ? with_slack(b->last_ovf_used) + 4096 : 8 * cn + 4096; // (first run of a shape: eight slots per read; chr22 scale asks for 2.6, the x fixture for 6.7)
+            if (const char *e = std::getenv("PGX_SLOT_ARENA_CAP")) want = std::strtoull(e, nullptr, 10); // tests: an arena that overflows
+            want = std::max<uint64_t>(want, b->max_read_len + 1); // (an overflowing extent is parked at the start of the arena: it must fit)
+            want = std::max<uint64_t>(want, (uint64_t)PGX_ARENA_SUBS * (b->max_read_len + 1)); // (every sub-arena must hold a parked extent)
+            want = (want + PGX_ARENA_SUBS - 1) / PGX_ARENA_SUBS * PGX_ARENA_SUBS;
+            if (want < c.slots && want < (1ull << 32)) ovf_cap = want; // otherwise the worst case is no bigger
+        }
+        bool arena_failed = false;
         for (int attempt = 0;; attempt++) {
+            if (arena_failed) ovf_cap = 0;
+            b->slots.ensure(((ovf_cap ? ovf_cap : c.slots) + 4 * cn) * sizeof(pgx_mem));
             // per-chunk counters (slots below PGX_CTR_TAG0): extensions, cursors, heavy reads, 32-bit overflow flag, MEMs of the chunk
-            if (ci || attempt) HIPCHECK(hipMemsetAsync(d_next, 0, PGX_CTR_TAG0 * 8, s));
+            if (ci || attempt) {
+                HIPCHECK(hipMemsetAsync(d_next, 0, PGX_CTR_TAG0 * 8, s));
+                HIPCHECK(hipMemsetAsync(d_next + PGX_CTR_ARENA0, 0, (PGX_CTR_ALL - PGX_CTR_ARENA0) * 8, s));
+            }
             const uint8_t *a_reads = b->reads.as<uint8_t>();
             const uint64_t *a_off = b->offsets.as<uint64_t>(), *a_slot_off = b->slot_off.as<uint64_t>();
             uint64_t a_n = c.r1, a_min_len = min_len, a_min_occ = min_occ, a_base = c.slot_base, a_first = c.r0;
@@ -1179,6 +1202,8 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             unsigned long long *a_next = d_next, *a_cur = d_cursor;
             PgxDevImage a_img = img;
             uint32_t a_hext = heavy_ext, a_hcap = PGX_FM_HEAVY_CAP;
+            uint32_t *a_ovf = b->ovf_base.as<uint32_t>() - c.r0; // (indexed by read id; the buffer holds this chunk's reads)
+            uint64_t a_ovf_cap = ovf_cap;
             pgx_heavy_item *a_hlist = b->heavy_list.as<pgx_heavy_item>();
             unsigned long long *a_hcount = d_heavy_count;
             const pgx_heavy_item *a_rlist = nullptr;
@@ -1225,7 +1250,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                     const unsigned long long *s_count = b->side_count.as<unsigned long long>();
                     unsigned long long *s_cur = d_next + PGX_CTR_SIDE_CURSOR;
                     void *sargs[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &s_cur, &a_first, &a_base,
-                                     &a_hext, &a_hcap, &a_hlist, &a_hcount, &s_list, &s_count};
+                                     &a_hext, &a_hcap, &a_hlist, &a_hcount, &s_list, &s_count, &a_ovf, &a_ovf_cap};
                     HIPCHECK(hipLaunchKernel(kf, dim3(std::min<unsigned>(grid, (unsigned)cus)), dim3(PGX_FM_THREADS), sargs, b->dimg->lds_bytes, b->side));
                     HIPCHECK(hipEventRecord(b->ev_side[1], b->side));
                     side_running = true;
@@ -1263,7 +1288,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                     }
                 }
                 void *pargs[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_first, &a_base,
-                                 &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_redo, &a_redo_n, &a_skip, &a_packed, &a_pkw};
+                                 &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_redo, &a_redo_n, &a_skip, &a_packed, &a_pkw, &a_ovf, &a_ovf_cap};
                 HIPCHECK(hipLaunchKernel(kp, dim3(pgrid), dim3(PGX_FM_THREADS), pargs, plds, s));
                 record(b, 8, s);
                 a_rlist = a_redo; a_rcount = d_redo_count; a_cur = d_redo_cursor;
@@ -1274,7 +1299,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                 if (redo_hext && a_hext > redo_hext) a_hext = redo_hext;
             }
             void *args[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_first, &a_base,
-                            &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_rlist, &a_rcount};
+                            &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_rlist, &a_rcount, &a_ovf, &a_ovf_cap};
             HIPCHECK(hipLaunchKernel(kf, dim3(grid), dim3(PGX_FM_THREADS), args, b->dimg->lds_bytes, s)); // one of the variants
             if (!kfn_pairs) record(b, 8, s);
             if (side_running) HIPCHECK(hipStreamWaitEvent(s, b->ev_side[1], 0)); // the other stream's reads are done (they may have queued heavy reads)
@@ -1282,19 +1307,22 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                 if (b->dimg->lds_bytes)
                     hipLaunchKernelGGL(pgx_find_mems_heavy_kernel<true>, dim3(PGX_FM_HEAVY_GRID), dim3(256), b->dimg->lds_bytes, s, img, a_reads, a_off,
                                        min_len, min_occ, a_slot_off, c.slot_base, a_slots, a_cnt, d_next, (const pgx_heavy_item *)a_hlist,
-                                       (const unsigned long long *)d_heavy_count, (uint32_t)PGX_FM_HEAVY_CAP, b->heavy_scratch.as<PgxHeavyResult>(), c.r0, cn);
+                                       (const unsigned long long *)d_heavy_count, (uint32_t)PGX_FM_HEAVY_CAP, b->heavy_scratch.as<PgxHeavyResult>(), c.r0, cn, a_ovf, a_ovf_cap);
                 else
                     hipLaunchKernelGGL(pgx_find_mems_heavy_kernel<false>, dim3(PGX_FM_HEAVY_GRID), dim3(256), 0, s, img, a_reads, a_off, min_len, min_occ,
                                        a_slot_off, c.slot_base, a_slots, a_cnt, d_next, (const pgx_heavy_item *)a_hlist,
-                                       (const unsigned long long *)d_heavy_count, (uint32_t)PGX_FM_HEAVY_CAP, b->heavy_scratch.as<PgxHeavyResult>(), c.r0, cn);
+                                       (const unsigned long long *)d_heavy_count, (uint32_t)PGX_FM_HEAVY_CAP, b->heavy_scratch.as<PgxHeavyResult>(), c.r0, cn, a_ovf, a_ovf_cap);
             }
+            if (ovf_cap) hipLaunchKernelGGL(pgx_arena_demand_kernel, dim3(1), dim3(PGX_ARENA_SUBS), 0, s, d_next);
             HIPCHECK(hipGetLastError());
             b->timing.find_mems_launches++;
             record(b, 2, s);
             scan_excl(0, b->mem_count.as<uint32_t>() + c.r0, cn, 0, local, b->scan_tmp, s, reinterpret_cast<uint64_t *>(d_next + PGX_CTR_MEMS));
             if (spec) { cm = cm_cap; break; } // nothing is read back: the MEM total stays on the device
-            unsigned long long cc[12];
+            unsigned long long cc[16];
             read_scalars(cc, d_next, sizeof cc, s);
+            if (ovf_cap) b->last_ovf_used = cc[PGX_CTR_OVF_TOP]; // (what the reads asked for, whether or not it fitted: sizes the next arena)
+            if (ovf_cap && cc[PGX_CTR_OVF_ABORT]) { arena_failed = true; continue; } // the arena was too small: once more in the worst-case layout
             const bool forced = attempt == 0 && kf != kfn_wide && std::getenv("PGX_FM_NARROW_FORCE_REDO") != nullptr; // tests
             if ((cc[PGX_CTR_OVF32] || forced) && kf != kfn_wide) { kf = kfn_wide; continue; } // a coordinate left 32 bits: repeat the chunk in 64 bits
             n_ext_host += cc[PGX_CTR_EXT];
@@ -1306,7 +1334,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         b->mems.ensure_keep((mem_base + cm ? mem_base + cm : 1) * sizeof(pgx_mem), mem_base * sizeof(pgx_mem));
         hipLaunchKernelGGL(pgx_compact_mems_kernel, dim3(grid_for(cn, 256)), dim3(256), 0, s, c.r0, cn, b->slot_off.as<uint64_t>(),
                            c.slot_base, b->slots.as<pgx_mem>(), b->mem_count.as<uint32_t>(), (const uint64_t *)local, mem_base,
-                           b->mems.as<pgx_mem>(), spec ? cm_cap : ~0ull, d_abort);
+                           b->mems.as<pgx_mem>(), spec ? cm_cap : ~0ull, d_abort, (const uint32_t *)(b->ovf_base.as<uint32_t>() - c.r0), ovf_cap);
         HIPCHECK(hipGetLastError());
         record(b, 3, s);
         mem_base += cm;
@@ -1343,7 +1371,12 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     read_scalars(cnt, b->counters.p, sizeof cnt, s);
     if (spec) {
         b->spec_runs++;
-        if (cnt[PGX_CTR_ABORT] || cnt[PGX_CTR_OVF32] || cnt[PGX_CTR_MEMS] > cm_cap) { b->spec_fallbacks++; b->ran_tags = false; continue; } // a capacity was too small: once more, exactly
+        if (cnt[PGX_CTR_OVF_ABORT]) { force_worst = true; b->last_ovf_used = cnt[PGX_CTR_OVF_TOP]; } // (the arena sized from the last run overflowed: the next one is sized from this demand)
+        if (std::getenv("PGX_DEBUG_COUNTERS"))
+            std::fprintf(stderr, "[pgx] speculative run: abort flags %llu, 32-bit overflow %llu, arena overflow %llu (top %llu), MEMs %llu of capacity %llu\n", cnt[PGX_CTR_ABORT], cnt[PGX_CTR_OVF32],
+                         cnt[PGX_CTR_OVF_ABORT], cnt[PGX_CTR_OVF_TOP], cnt[PGX_CTR_MEMS], (unsigned long long)cm_cap);
+        if (cnt[PGX_CTR_ABORT] || cnt[PGX_CTR_OVF32] || cnt[PGX_CTR_OVF_ABORT] || cnt[PGX_CTR_MEMS] > cm_cap) { b->spec_fallbacks++; b->ran_tags = false; continue; } // a capacity was too small: once more, exactly
+        b->last_ovf_used = cnt[PGX_CTR_OVF_TOP];
         b->n_mems = cnt[PGX_CTR_MEMS];
         n_ext_host = cnt[PGX_CTR_EXT];
         b->timing.heavy_reads = (uint32_t)std::min<unsigned long long>(cnt[PGX_CTR_HEAVY], PGX_FM_HEAVY_CAP);

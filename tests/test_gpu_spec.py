@@ -119,3 +119,45 @@ def test_switched_off_and_chunked(pan, monkeypatch):
     assert b.spec_stats() == (0, 0)
     b.free()
     idx.close()
+
+
+def test_mem_slot_arena_and_its_fallback(monkeypatch, workdir):
+    """The fifth and later MEMs of a read go to an arena (an extent reserved when the fifth is emitted) instead of a worst-case region of 131 slots
+    per 150-bp read; an arena that proves too small makes the chunk run again in the worst-case layout.  Same bytes either way, also for reads the
+    pairs kernel hands on after their fifth MEM and for heavy reads."""
+    import pgx_workload as W
+
+    text = os.path.join(workdir, "arena.txt")
+    W.synth_pangenome_text(text, base_len=20_000, n_hap=3, seed=91, snp=0.02, indel=0.002, n_runs=2, n_run_len=(10, 100))
+    ri_path, tags_path = W.build_index_from_text(text, workdir, "arena")[:2]
+    seqs = W.load_sequences(text)
+    cat, offs = W.sample_reads(seqs, 30_000, 150, seed=4, sub_rate=0.06)  # many mismatches, min_len 8: most reads have more than four MEMs
+    extra = [bytes(seqs[0][-150:]), bytes(seqs[1][-150:]), b"N" * 150, b"ACGT" * 37]
+    ecat, eoffs = O.pack_reads(extra)
+    cat = np.concatenate([cat, ecat]); offs = np.concatenate([offs, eoffs[1:] + offs[-1]])
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    ref = O.find_mems_batch(ri, tags, cat, offs, 8, 1, threads=4)
+    per_read = np.diff(ref["mem_offsets"])
+    assert (per_read > 4).mean() > 0.5
+    for force in (0, P.MODE_IMAGE_PAIRS, P.MODE_IMAGE_RL):
+        idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | force)
+        # (default arena: eight slots per read at first, then what the last run asked for -- these reads ask for ~100 each, so the first run repeats)
+        for env, launches in (({}, None), ({"PGX_SLOT_ARENA": "0"}, 1), ({"PGX_SLOT_ARENA_CAP": "1000"}, 2), ({"PGX_SLOT_ARENA_CAP": "1000", "PGX_SPEC": "0"}, 2)):
+            for k in ("PGX_SLOT_ARENA", "PGX_SLOT_ARENA_CAP", "PGX_SPEC"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            b = idx.batch(cat, offs)
+            for rep in range(2):  # the second run is sized speculatively (arena from the first)
+                b.run(8, 1, P.RUN_TAGS | P.RUN_TIMING)
+                res = b.result()
+                assert np.array_equal(res["mem_offsets"], ref["mem_offsets"]), (force, env, rep)
+                assert res["mems"].tobytes() == ref["mems"].tobytes()
+                assert res["n_extensions"] == ref["n_extensions"]
+                assert np.array_equal(res["positions"], ref["positions"])
+                if launches is not None and (rep == 0 or "PGX_SPEC" in env):
+                    assert b.timing().find_mems_launches == launches, (force, env, rep, b.timing().find_mems_launches)
+                if launches is None and rep == 1:
+                    assert b.timing().find_mems_launches == 1 and b.spec_stats()[1] == 0  # sized from the first run's demand: one launch, nothing repeated
+            b.free()
+        idx.close()
