@@ -529,6 +529,9 @@ pgx_seed_build_kernel(PgxDevImage img, const uint4 *__restrict__ src, uint4 *__r
 // neighbouring lines instead of 4 KiB apart, and the compaction reads them as a stream --, further ones at the read's worst-case
 // offset (slot_off) behind that array
 #define PGX_FAST_SLOTS 4u
+#ifndef PGX_PAIRS_PACKED_WAVES
+#define PGX_PAIRS_PACKED_WAVES 6 // waves per SIMD the packed narrow pairs kernel is compiled for (80 VGPRs)
+#endif
 __device__ __forceinline__ uint64_t pgx_slot_index(uint64_t read_in_chunk, uint64_t chunk_reads, uint64_t slot, uint32_t nm) {
     return nm < PGX_FAST_SLOTS ? read_in_chunk * PGX_FAST_SLOTS + nm : chunk_reads * PGX_FAST_SLOTS + slot + nm;
 }
@@ -1024,7 +1027,7 @@ __device__ __forceinline__ uint32_t pgx_window_byte(uint64_t w0, uint64_t w1, ui
 // translation per load INSTRUCTION that touches it: 1 x 16 B of a line runs at 48 G lines/s, 5 x 16 B at 16-18 G/s, which is where the five-load
 // probe sat on the 5.8 GB image of the 4.35e9-symbol index (17 G lines/s).
 template <bool SEED, bool WIDE, bool PACKED, bool COOP>
-__global__ void __launch_bounds__(PGX_FM_THREADS, PGX_FM_WAVES_PER_SIMD) // (<= 96 VGPRs: five waves per SIMD fit and are what the launch uses; four are as fast -- 20.7 against 20.6-21.0 ms at chr22 scale --, three 21.8)
+__global__ void __launch_bounds__(PGX_FM_THREADS, (PACKED && !WIDE && !COOP) ? PGX_PAIRS_PACKED_WAVES : PGX_FM_WAVES_PER_SIMD) // (<= 96 VGPRs: five waves per SIMD fit and are what the launch uses; four are as fast -- 20.7 against 20.6-21.0 ms at chr22 scale --, three 21.8)
 pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                            uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
                            pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
@@ -1071,7 +1074,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     int ph = 0;
     uint64_t win = 0, win_hi = 0;
     uint32_t win_at = ~0u; // the cached 16 bytes of the reads buffer: their offset / 16 (16 rather than 32 bytes: four registers less, no difference in time)
-    uint32_t X0a = 0, X0b = 0, X0c = 0, X0d = 0; // sums over the first block of an interval that runs on into the next
+    uint32_t X0 = 0; // the four sums (each <= 96: one byte) over the first block of an interval that runs on into the next
     pos_t X0e = 0, X0f = 0;                                   // ... and the two absolute ranks at its start
     uint32_t pend = 0, fresh = 0, restart = 0;
     uint64_t rnext = 0, rend = 0;
@@ -1307,10 +1310,11 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 redo_list[atomicAdd(redo_count, 1ull)] = it;
                 ph = 0; next = nextb; pend = 0u;
             } else if (wait) {
-                X0a = e1r; X0b = g1r; X0c = e2r; X0d = g2r; X0e = a01; X0f = a02;
+                X0 = e1r | (g1r << 8) | (e2r << 16) | (g2r << 24); X0e = a01; X0f = a02;
                 pend = 1u;
             } else {
-                const uint32_t c1 = pend ? X0a + e1r : e1r, w1 = pend ? X0b + g1r : g1r, c2 = pend ? X0c + e2r : e2r, w2 = pend ? X0d + g2r : g2r;
+                const uint32_t Xp = pend ? X0 : 0u;
+                const uint32_t c1 = (Xp & 0xFFu) + e1r, w1 = ((Xp >> 8) & 0xFFu) + g1r, c2 = ((Xp >> 16) & 0xFFu) + e2r, w2 = (Xp >> 24) + g2r;
                 const pos_t r1 = pend ? X0e : a01, r2 = pend ? X0f : a02;
                 pend = 0u;
                 // first extension (src/r-index.cpp:713-764); a symbol that is not A C G T has no occurrence in a range free of special positions
