@@ -177,6 +177,16 @@ pgx_status pgx_convert_tags(const char *in_path, const char *out_path, int compa
  * positions of its sequences. */
 pgx_status pgx_merge_tags(const char *ri_path, const char *const *tag_paths, uint32_t n_files, const uint32_t *seq_to_file,
                           uint64_t n_seq, int device, const char *out_path);
+/* As pgx_merge_tags, with flags.  PGX_MERGE_REFERENCE_RUNS: the file byte for byte as the reference writes it.  The reference
+ * collects runs job by job (500 BWT runs each, src/merge_tags.cpp:600,733-823) in std::pair<pos_t, uint16_t> and joins the last
+ * run of one job to the first of the next when the tags are equal (:776-777, previous_last_run), so what it hands to
+ * append_compact_run_streamed is every MAXIMAL run with its length taken mod 65 536 -- a length that lands on 0 writes nothing
+ * (src/tag_arrays.cpp:959) and the positions of every later run shift down.  Without the flag (and in pgx_merge_tags) lengths are
+ * exact; the two outputs are the same bytes whenever no merged run reaches 65 536 positions (tests/test_merge_tags.py restates
+ * the reference's job loop and checks that rule). */
+#define PGX_MERGE_REFERENCE_RUNS 0x1u
+pgx_status pgx_merge_tags_ex(const char *ri_path, const char *const *tag_paths, uint32_t n_files, const uint32_t *seq_to_file,
+                             uint64_t n_seq, int device, const char *out_path, uint32_t flags);
 
 /* What merge_tags asks the graph (src/merge_tags.cpp:443-445,478-515; include/pangenome_index/algorithm.hpp:600-619): for every
  * GBWT sequence of the GBZ the graph node id of its first node (gbz.index.extract(i)[0]; 0 for an empty path) and that node's
@@ -189,6 +199,8 @@ pgx_status pgx_gbz_paths(const char *gbz_path, uint64_t *n_sequences, uint64_t *
  * of the output comes from the graph's largest node id (:627-638).  Otherwise as pgx_merge_tags. */
 pgx_status pgx_merge_tags_gbz(const char *gbz_path, const char *ri_path, const char *const *tag_paths, uint32_t n_files, int device,
                               const char *out_path);
+pgx_status pgx_merge_tags_gbz_ex(const char *gbz_path, const char *ri_path, const char *const *tag_paths, uint32_t n_files, int device,
+                                 const char *out_path, uint32_t flags); /* flags as pgx_merge_tags_ex */
 
 /* ---- primitives (tests; mirror the public FastLocate / TagArray query API) ----------------- */
 /* FastLocate::rank_at_cached_encoded (src/r-index.cpp:619-641): out[i*6 .. i*6+sigma) per position;

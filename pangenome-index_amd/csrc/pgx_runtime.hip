@@ -11,6 +11,7 @@
 //   scan ; tag_compact -> positions CSR
 // The only host synchronisations are the scalar read-backs that size the next buffer.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -26,6 +27,39 @@
 #include "pgx_device.h"
 #include "pgx_host.hpp"
 #include "pgx_runtime.hpp"
+
+// roctx ranges and stage marks for rocprofv3 --marker-trace (the reference's TIME stopwatches, src/find_mems.cpp:20-24,100-136).
+// Off unless PGX_ROCTX=1: the library is looked up at run time so that nothing links against the profiler.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    void (*mark)(const char *) = nullptr;
+    bool on = false;
+};
+static const Roctx &roctx() {
+    static const Roctx r = [] {
+        Roctx x;
+        const char *e = std::getenv("PGX_ROCTX");
+        if (!e || !std::atoi(e)) return x;
+        void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return x;
+        x.push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+        x.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        x.mark = reinterpret_cast<void (*)(const char *)>(dlsym(h, "roctxMarkA"));
+        x.on = x.push && x.pop && x.mark;
+        return x;
+    }();
+    return r;
+}
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char *name) : on(roctx().on) { if (on) roctx().push(name); }
+    ~RoctxRange() { if (on) roctx().pop(); }
+    RoctxRange(const RoctxRange &) = delete;
+    RoctxRange &operator=(const RoctxRange &) = delete;
+};
+
 
 using namespace pgx;
 
@@ -723,8 +757,9 @@ extern "C" pgx_status pgx_decompress_sa(pgx_index *h, int device, uint32_t flags
 // ------------------------------------------------------------------------------------------
 // merge_tags (pgx_merge_kernels.hip)
 static void merge_tags_core(const char *ri_path, const char *const *tag_paths, uint32_t n_files, const uint32_t *seq_to_file, uint64_t n_seq,
-                            int device, const char *out_path, uint64_t max_node_floor) {
+                            int device, const char *out_path, uint64_t max_node_floor, uint32_t opts) {
     if (!ri_path || !tag_paths || !seq_to_file || !out_path) throw Error(PGX_ERR_ARG, "pgx_merge_tags: null argument");
+    if (opts & ~PGX_MERGE_REFERENCE_RUNS) throw Error(PGX_ERR_ARG, "pgx_merge_tags: unknown flag");
     if (n_files == 0 || n_files > 250) throw Error(PGX_ERR_ARG, "pgx_merge_tags: between 1 and 250 tag files");
     // only the locate side of the index is needed: parse the file, no rank image
     std::unique_ptr<pgx_index, void (*)(pgx_index *)> guard(new pgx_index(), pgx_index_close);
@@ -836,6 +871,18 @@ static void merge_tags_core(const char *ri_path, const char *const *tag_paths, u
             h_start[n_out] = n;
         }
         for (uint64_t i = 0; i < n_out; i++) h_start[i] = h_start[i + 1] - h_start[i]; // lengths
+        if (opts & PGX_MERGE_REFERENCE_RUNS) {
+            // the reference counts a merged run in a uint16_t (std::pair<pos_t, uint16_t>, src/merge_tags.cpp:282,346,394-398,625) and
+            // adds the pieces of a run that crosses a 500-run job in the same type (:776-777): what reaches
+            // append_compact_run_streamed is the maximal run's length mod 65 536, and a length of 0 writes nothing (tag_arrays.cpp:959)
+            uint64_t w = 0;
+            for (uint64_t i = 0; i < n_out; i++) {
+                const uint64_t l16 = h_start[i] & 0xFFFFull;
+                if (!l16) continue;
+                h_val[w] = h_val[i]; h_start[w++] = l16;
+            }
+            h_val.resize(w); h_start.resize(w + 1);
+        }
     } catch (...) {
         for (DevBuf *b : all) b->release();
         throw;
@@ -847,7 +894,15 @@ static void merge_tags_core(const char *ri_path, const char *const *tag_paths, u
 extern "C" pgx_status pgx_merge_tags(const char *ri_path, const char *const *tag_paths, uint32_t n_files, const uint32_t *seq_to_file,
                                      uint64_t n_seq, int device, const char *out_path) {
     PGX_GUARD_BEGIN
-    merge_tags_core(ri_path, tag_paths, n_files, seq_to_file, n_seq, device, out_path, 0);
+    merge_tags_core(ri_path, tag_paths, n_files, seq_to_file, n_seq, device, out_path, 0, 0);
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_merge_tags_ex(const char *ri_path, const char *const *tag_paths, uint32_t n_files, const uint32_t *seq_to_file,
+                                        uint64_t n_seq, int device, const char *out_path, uint32_t flags) {
+    PGX_GUARD_BEGIN
+    merge_tags_core(ri_path, tag_paths, n_files, seq_to_file, n_seq, device, out_path, 0, flags);
     return PGX_OK;
     PGX_GUARD_END
 }
@@ -866,9 +921,8 @@ static uint64_t first_tag_node(const char *path) {
     return v >> 20; // offset:10 | rev:1 | len:9 | node << 20 (encode_run_length, src/tag_arrays.cpp:28-36)
 }
 
-extern "C" pgx_status pgx_merge_tags_gbz(const char *gbz_path, const char *ri_path, const char *const *tag_paths, uint32_t n_files, int device,
-                                         const char *out_path) {
-    PGX_GUARD_BEGIN
+static void merge_tags_gbz_core(const char *gbz_path, const char *ri_path, const char *const *tag_paths, uint32_t n_files, int device,
+                                const char *out_path, uint32_t flags) {
     if (!gbz_path || !ri_path || !tag_paths || !out_path || !n_files) throw Error(PGX_ERR_ARG, "pgx_merge_tags_gbz: null argument");
     GbzPaths g;
     try { parse_gbz_paths(gbz_path, g); }
@@ -893,7 +947,21 @@ extern "C" pgx_status pgx_merge_tags_gbz(const char *gbz_path, const char *ri_pa
             throw Error(PGX_ERR_FORMAT, "path " + std::to_string(sq) + " of the graph starts in a component without a tag file");
         s2f[sq] = comp_to_file[c];
     }
-    merge_tags_core(ri_path, tag_paths, n_files, s2f.data(), s2f.size(), device, out_path, g.max_node_id);
+    merge_tags_core(ri_path, tag_paths, n_files, s2f.data(), s2f.size(), device, out_path, g.max_node_id, flags);
+}
+
+extern "C" pgx_status pgx_merge_tags_gbz(const char *gbz_path, const char *ri_path, const char *const *tag_paths, uint32_t n_files, int device,
+                                         const char *out_path) {
+    PGX_GUARD_BEGIN
+    merge_tags_gbz_core(gbz_path, ri_path, tag_paths, n_files, device, out_path, 0);
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
+extern "C" pgx_status pgx_merge_tags_gbz_ex(const char *gbz_path, const char *ri_path, const char *const *tag_paths, uint32_t n_files, int device,
+                                            const char *out_path, uint32_t flags) {
+    PGX_GUARD_BEGIN
+    merge_tags_gbz_core(gbz_path, ri_path, tag_paths, n_files, device, out_path, flags);
     return PGX_OK;
     PGX_GUARD_END
 }
@@ -1007,6 +1075,7 @@ extern "C" pgx_status pgx_batch_create(pgx_index *h, int device, const uint8_t *
 
 extern "C" pgx_status pgx_batch_upload(pgx_batch *b, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads) {
     PGX_GUARD_BEGIN
+    RoctxRange range("pgx_batch_upload");
     if (!b || !offsets || (!reads && n_reads && offsets[n_reads] != offsets[0])) throw Error(PGX_ERR_ARG, "pgx_batch_upload: null argument");
     for (uint64_t i = 0; i < n_reads; i++) {
         if (offsets[i + 1] < offsets[i]) throw Error(PGX_ERR_ARG, "pgx_batch_upload: offsets must be non-decreasing");
@@ -1019,6 +1088,9 @@ extern "C" pgx_status pgx_batch_upload(pgx_batch *b, const uint8_t *reads, const
 }
 
 static void record(pgx_batch *b, int i, hipStream_t s) {
+    static const char *const stage[9] = {"pgx: run begins (classify, sizing)", "pgx: find_mems launches follow", "pgx: find_mems enqueued", "pgx: compaction enqueued",
+                                         "pgx: tag locate enqueued", "pgx: tag gather enqueued", "pgx: tag sort/unique enqueued", "pgx: run enqueued", "pgx: main find_mems kernel enqueued"};
+    if (roctx().on) roctx().mark(stage[i]);
     if (!b->timed) return;
     if (!b->ev[i]) HIPCHECK(hipEventCreate(&b->ev[i]));
     HIPCHECK(hipEventRecord(b->ev[i], s));
@@ -1026,6 +1098,7 @@ static void record(pgx_batch *b, int i, hipStream_t s) {
 
 extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min_occ, uint32_t flags, void *stream) {
     PGX_GUARD_BEGIN
+    RoctxRange range("pgx_batch_run");
     if (!b) throw Error(PGX_ERR_ARG, "pgx_batch_run: null batch");
     use_device(b->device);
     hipStream_t s = stream ? (hipStream_t)stream : b->own;
@@ -1477,6 +1550,7 @@ extern "C" pgx_status pgx_batch_timing(pgx_batch *b, pgx_timing *out) {
 
 extern "C" pgx_status pgx_batch_result(pgx_batch *b, pgx_result *out) {
     PGX_GUARD_BEGIN
+    RoctxRange range("pgx_batch_result");
     if (!b || !out || !b->ran) throw Error(PGX_ERR_ARG, "pgx_batch_result: batch has not been run");
     use_device(b->device);
     const uint64_t n = b->n_reads, m = b->n_mems;

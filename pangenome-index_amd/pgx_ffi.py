@@ -118,6 +118,8 @@ def lib():
     L.pgx_merge_tags.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), u32, p, u64, C.c_int, C.c_char_p]
     L.pgx_gbz_paths.argtypes = [C.c_char_p, C.POINTER(u64), p, p, u64, C.POINTER(u64), C.POINTER(u32)]
     L.pgx_merge_tags_gbz.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, C.c_int, C.c_char_p]
+    L.pgx_merge_tags_ex.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), u32, p, u64, C.c_int, C.c_char_p, u32]
+    L.pgx_merge_tags_gbz_ex.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u32, C.c_int, C.c_char_p, u32]
     L.pgx_rank_batch.argtypes = [p, C.c_int, p, u64, C.c_int, p]
     L.pgx_extend_batch.argtypes = [p, C.c_int, p, p, p, u64, p]
     L.pgx_count_batch.argtypes = [p, C.c_int, p, p, u64, p]
@@ -205,12 +207,16 @@ LOCATE_SEQ_IDS, LOCATE_UNIQUE = 1, 2
 NO_POSITION = 0xFFFFFFFFFFFFFFFF
 
 
-def merge_tags(ri_path, tag_paths, seq_to_file, out_path, device=0):
+MERGE_REFERENCE_RUNS = 0x1
+
+
+def merge_tags(ri_path, tag_paths, seq_to_file, out_path, device=0, flags=0):
     """merge_tags: per-chromosome tag streams (algorithm format) -> whole-genome sdsl-compact tag array; seq_to_file[s] =
-    index into tag_paths of the file that holds the tags of sequence s of the whole-genome r-index"""
+    index into tag_paths of the file that holds the tags of sequence s of the whole-genome r-index.  flags: MERGE_REFERENCE_RUNS
+    writes run lengths as the reference does (mod 65 536)"""
     s2f = np.ascontiguousarray(seq_to_file, dtype=np.uint32)
     arr = (C.c_char_p * len(tag_paths))(*[t.encode() for t in tag_paths])
-    _check(lib().pgx_merge_tags(ri_path.encode(), arr, len(tag_paths), s2f.ctypes.data, len(s2f), device, out_path.encode()))
+    _check(lib().pgx_merge_tags_ex(ri_path.encode(), arr, len(tag_paths), s2f.ctypes.data, len(s2f), device, out_path.encode(), flags))
 
 
 def gbz_paths(gbz_path):
@@ -223,10 +229,10 @@ def gbz_paths(gbz_path):
     return first, comp, mx.value, nc.value
 
 
-def merge_tags_gbz(gbz_path, ri_path, tag_paths, out_path, device=0):
+def merge_tags_gbz(gbz_path, ri_path, tag_paths, out_path, device=0, flags=0):
     """merge_tags with the reference's inputs: the sequence -> tag file map comes from the graph"""
     arr = (C.c_char_p * len(tag_paths))(*[t.encode() for t in tag_paths])
-    _check(lib().pgx_merge_tags_gbz(gbz_path.encode(), ri_path.encode(), arr, len(tag_paths), device, out_path.encode()))
+    _check(lib().pgx_merge_tags_gbz_ex(gbz_path.encode(), ri_path.encode(), arr, len(tag_paths), device, out_path.encode(), flags))
 
 
 class Index:

@@ -27,7 +27,7 @@
 
 int main(int argc, char **argv) {
     if (argc < 4) {
-        std::cerr << "usage: merge_tags <graph.gbz | seq_map.txt | --counts f0:n0,f1:n1,...> <whole_genome.ri> <tag_dir> [--out FILE] [--device N]" << std::endl;
+        std::cerr << "usage: merge_tags <graph.gbz | seq_map.txt | --counts f0:n0,f1:n1,...> <whole_genome.ri> <tag_dir> [--out FILE] [--device N] [--reference-runs]" << std::endl;
         return EXIT_FAILURE;
     }
     {   // the reference's argv: <graph.gbz> <r_index> <tag_dir>
@@ -37,10 +37,12 @@ int main(int argc, char **argv) {
             const std::string ri = argv[2], dir = argv[3];
             std::string out = "whole_genome_tag_array_compressed.tags"; // written into the working directory (:538)
             int device = 0;
+            uint32_t flags = 0;
             for (int i = 4; i < argc; i++) {
                 const std::string o = argv[i];
                 if (o == "--out" && i + 1 < argc) out = argv[++i];
                 else if (o == "--device" && i + 1 < argc) device = std::stoi(argv[++i]);
+                else if (o == "--reference-runs") flags |= PGX_MERGE_REFERENCE_RUNS;
                 else { std::cerr << "unknown option " << o << std::endl; return EXIT_FAILURE; }
             }
             std::cerr << "Loading the graph file" << std::endl;            // :449
@@ -60,7 +62,7 @@ int main(int argc, char **argv) {
             for (auto &p : files) { std::cerr << p << std::endl; cp.push_back(p.c_str()); }
             std::cerr << "Reading the whole genome r-index file (encoded)" << std::endl; // :465
             std::cerr << "Finding the node to component mapping" << std::endl;           // :477
-            if (pgx_merge_tags_gbz(argv[1], ri.c_str(), cp.data(), (uint32_t)cp.size(), device, out.c_str()) != PGX_OK) {
+            if (pgx_merge_tags_gbz_ex(argv[1], ri.c_str(), cp.data(), (uint32_t)cp.size(), device, out.c_str(), flags) != PGX_OK) {
                 std::cerr << pgx_last_error() << std::endl;
                 return EXIT_FAILURE;
             }
@@ -97,10 +99,12 @@ int main(int argc, char **argv) {
     const std::string ri = argv[a], dir = argv[a + 1];
     std::string out = "whole_genome_tag_array_compressed.tags";
     int device = 0;
+    uint32_t flags = 0;
     for (int i = a + 2; i < argc; i++) {
         const std::string o = argv[i];
         if (o == "--out" && i + 1 < argc) out = argv[++i];
         else if (o == "--device" && i + 1 < argc) device = std::stoi(argv[++i]);
+        else if (o == "--reference-runs") flags |= PGX_MERGE_REFERENCE_RUNS;
         else { std::cerr << "unknown option " << o << std::endl; return EXIT_FAILURE; }
     }
     std::map<std::string, uint32_t> id;
@@ -118,7 +122,7 @@ int main(int argc, char **argv) {
     std::vector<const char *> cp;
     for (auto &p : paths) { std::cerr << p << std::endl; cp.push_back(p.c_str()); }
     std::cerr << "Merging tags and creating the whole genome tag array indexing" << std::endl; // :735
-    if (pgx_merge_tags(ri.c_str(), cp.data(), (uint32_t)cp.size(), s2f.data(), s2f.size(), device, out.c_str()) != PGX_OK) {
+    if (pgx_merge_tags_ex(ri.c_str(), cp.data(), (uint32_t)cp.size(), s2f.data(), s2f.size(), device, out.c_str(), flags) != PGX_OK) {
         std::cerr << pgx_last_error() << std::endl;
         return EXIT_FAILURE;
     }
