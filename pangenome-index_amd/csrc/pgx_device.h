@@ -33,6 +33,7 @@ enum PgxCounterSlot {
     // -DPGX_FM_STATS builds only (scripts/fm_stats.sh)
     PGX_CTR_ST_TRIPS = 40, PGX_CTR_ST_LIVE = 41, PGX_CTR_ST_LONGEST = 42,                  // pgx_find_mems_kernel: wave trips, live lane trips, longest wave
     PGX_CTR_ST_PAIR_TRIPS = 43, PGX_CTR_ST_PAIR_LIVE = 44, PGX_CTR_ST_PAIR_WAIT = 45, PGX_CTR_ST_PAIR_FRESH = 46,
+    PGX_CTR_ST_PAIR_T_REFILL = 47, PGX_CTR_ST_PAIR_T_TOTAL = 48, PGX_CTR_ST_PAIR_REFILLS = 49, PGX_CTR_ST_PAIR_T_SEED = 50, PGX_CTR_ST_PAIR_T_LINE = 51, // clock ticks (s_memtime) of the waves in the refill loop / in all, refill rounds, ticks waiting for the seed entry / for the block line
     PGX_CTR_SLOTS = 64,  // (what the host reads back)
     PGX_CTR_ARENA0 = 64, // counters of the PGX_ARENA_SUBS sub-arenas, 16 slots (one cache line) apart
     PGX_CTR_ALL = 64 + 16 * 64
@@ -82,6 +83,7 @@ struct PgxDevImage {
     const uint64_t *sbase2, *pbase;
     uint32_t d2_sb_shift, pairs_sb_shift, n_sb2, n_sbp;
     uint32_t wide;
+    uint32_t pairs_syms; // positions per PAIRS block: PGX_PAIRS_SYMS or PGX_PAIRS_SYMS64 (pgx_image.h)
 };
 #define PGX_SEED_UNUSABLE 255u // depth value of entries the kernels must not use (a coordinate does not fit the entry)
 #define PGX_SEED_MAX_K 16
@@ -115,7 +117,7 @@ __global__ void pgx_find_mems_kernel(PgxDevImage img, const uint8_t *reads, cons
                                      uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap, pgx_heavy_item *heavy_list, unsigned long long *heavy_count,
                                      const pgx_heavy_item *rid_list, const unsigned long long *rid_count, uint32_t *ovf_base, uint64_t ovf_cap);
 // PAIRS image (pgx_image.h): two extensions per loop trip; reads that meet a special position go to redo_list (then served by the kernel above)
-template <bool SEED, bool WIDE, bool PACKED, bool COOP>
+template <bool SEED, bool WIDE, bool PACKED, bool COOP, bool B64>
 __global__ void pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
                                            uint64_t min_len, uint64_t min_occ, const uint64_t *slot_off, pgx_mem *slots,
                                            uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor, uint64_t first_read,

@@ -187,6 +187,7 @@ __device__ __forceinline__ void pgx_dense2_pair(const PgxDevImage &img, uint32_t
                                                 uint64_t &dB) {
     uint32_t r0, r1;
     const PgxDense2Blk k0 = pgx_dense2_load(img, p0, r0), k1 = pgx_dense2_load(img, p1, r1);
+    __builtin_amdgcn_s_setprio(0); // (the find_mems kernels raise their priority on the way to the loads: see pgx_find_mems_pairs_kernel)
     uint32_t c0[6], c1[6];
     pgx_dense2_counts(img, k0, p0, r0, c0);
     pgx_dense2_counts(img, k1, p1, r1, c1);
@@ -246,6 +247,7 @@ __device__ __forceinline__ void pgx_dense2w_pair(const PgxDevImage &img, const u
                                                  uint64_t &A0, uint64_t &A1, uint64_t &dB) {
     uint32_t r0, r1, b0, b1;
     const PgxDense2Blk k0 = pgx_dense2w_load(img, p0, r0, b0), k1 = pgx_dense2w_load(img, p1, r1, b1);
+    __builtin_amdgcn_s_setprio(0);
     uint64_t c0[6], c1[6];
     pgx_dense2w_counts(img, sb, k0, p0, r0, b0, c0);
     pgx_dense2w_counts(img, sb, k1, p1, r1, b1, c1);
@@ -532,6 +534,7 @@ pgx_seed_build_kernel(PgxDevImage img, const uint4 *__restrict__ src, uint4 *__r
 #ifndef PGX_PAIRS_PACKED_WAVES
 #define PGX_PAIRS_PACKED_WAVES 6 // waves per SIMD the packed narrow pairs kernel is compiled for (80 VGPRs)
 #endif
+#define PGX_PK_GROUP 12u // packed words of a read fetched per round of loads when a lane takes the read
 __device__ __forceinline__ uint64_t pgx_slot_index(uint64_t read_in_chunk, uint64_t chunk_reads, uint64_t slot, uint32_t nm) {
     return nm < PGX_FAST_SLOTS ? read_in_chunk * PGX_FAST_SLOTS + nm : chunk_reads * PGX_FAST_SLOTS + slot + nm;
 }
@@ -671,6 +674,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     };
 
     for (;;) {
+        if (DENSE >= 2) __builtin_amdgcn_s_setprio(3); // up until the probes' loads are out (pgx_dense2_pair lowers it again): see pgx_find_mems_pairs_kernel
         // ---- refill idle lanes ----
         unsigned long long idle = __ballot(ph == 0);
         while (idle) {
@@ -1026,7 +1030,10 @@ __device__ __forceinline__ uint32_t pgx_window_byte(uint64_t w0, uint64_t w1, ui
 // For images beyond the reach of the address-translation caches (~3 GB: profiles/r03_ubench_gather_loads_per_line.txt) a random line costs one
 // translation per load INSTRUCTION that touches it: 1 x 16 B of a line runs at 48 G lines/s, 5 x 16 B at 16-18 G/s, which is where the five-load
 // probe sat on the 5.8 GB image of the 4.35e9-symbol index (17 G lines/s).
-template <bool SEED, bool WIDE, bool PACKED, bool COOP>
+// B64 (narrow, no COOP): the image with 64 positions per block (pgx_image.h): a probe reads piece t1 (rank of its first symbol with the flag, pairs
+// (t1, 0..2)), the two plane pieces, and piece 5 (pairs (., 3)) only where its second symbol has code 3 -- three or four 16-byte requests per lane
+// instead of five, two plane words instead of three.
+template <bool SEED, bool WIDE, bool PACKED, bool COOP, bool B64>
 __global__ void __launch_bounds__(PGX_FM_THREADS, (PACKED && !WIDE && !COOP) ? PGX_PAIRS_PACKED_WAVES : PGX_FM_WAVES_PER_SIMD) // (<= 96 VGPRs: five waves per SIMD fit and are what the launch uses; four are as fast -- 20.7 against 20.6-21.0 ms at chr22 scale --, three 21.8)
 pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                            uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
@@ -1044,6 +1051,8 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     __shared__ uint4 s_fe[PACKED ? 16 : 512];
     extern __shared__ __align__(16) unsigned char pgx_dyn_lds[];
     static_assert(!COOP || PACKED, "the cooperative loads come with the packed reads");
+    static_assert(!B64 || (!WIDE && !COOP), "the 64-position image is narrow and within the reach of the translation caches");
+    constexpr uint32_t SYMS = B64 ? PGX_PAIRS_SYMS64 : PGX_PAIRS_SYMS;
     uint32_t *s_rd = reinterpret_cast<uint32_t *>(pgx_dyn_lds); // PACKED: word w of this thread's read at s_rd[w * blockDim.x + threadIdx.x] (pk_words words per thread)
     const uint32_t rd_stride = blockDim.x;
     // COOP: behind the packed reads, 8 KiB per wave: piece p of the line of lane q's probe at [q * 8 + (p ^ (q & 7))] (the swizzle spreads the banks)
@@ -1082,6 +1091,8 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     unsigned long long ln_blk = 0, ln_seed = 0; // wave-uniform (scalar registers): block lines / seed entries the wave asked for (PGX_CTR_PAIRS_*)
 #ifdef PGX_FM_STATS
     unsigned long long st_trips = 0, st_live = 0, st_wait = 0, st_fresh = 0; // diagnostics build only (scripts/fm_stats.sh)
+    unsigned long long st_t_refill = 0, st_refills = 0, st_t_seed = 0, st_t_line = 0;
+    const unsigned long long st_t0 = __builtin_readcyclecounter();
 #endif
 
     auto begin = [&]() __attribute__((always_inline)) {
@@ -1117,7 +1128,16 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     };
 
     for (;;) {
+        // Wave priority: up from here until the trip's loads are out, down for the arithmetic on what they return.  The waves of a SIMD take turns
+        // issuing; with equal priority they drift into step -- all computing, then all waiting -- and the memory pipeline idles in between.  A wave
+        // that is about to ask for its lines now overtakes the ones that are counting bits: 17.3 -> 16.0-16.5 ms at chr22 scale
+        // (profiles/r03_wave_priority.txt; the same priority for every wave, or the opposite order, is slower).
+        __builtin_amdgcn_s_setprio(3);
         unsigned long long idle = __ballot(ph == 0);
+#ifdef PGX_FM_STATS
+        const unsigned long long st_r0 = __builtin_readcyclecounter();
+        if (idle) st_refills++;
+#endif
         while (idle) {
             if (rnext == rend) {
                 if (exhausted) break;
@@ -1133,14 +1153,27 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             if (ph == 0 && (uint64_t)rank < avail) {
                 rid = (uint32_t)(rnext + rank);
-                if (skip && skip[rid]) ph = -1; // served by the dense2 kernel on the other stream (pgx_classify_reads_kernel)
+                // (the three loads go out together, and so do the packed words below: a refill round is two memory latencies, not one per word --
+                //  word by word, 58 % of the waves' time at chr22 scale went by in this loop: profiles/r03_refill_share.txt)
+                const uint8_t *skp = skip ? skip + rid : reinterpret_cast<const uint8_t *>(offsets); // (always a load, never a branch with a wait of its own)
+                const uint32_t skv = (uint32_t)*skp;
+                const uint64_t o0 = offsets[rid], o1 = offsets[rid + 1];
+                const uint32_t sk = skip ? skv : 0u;
+                base = o0; // (assigned on both paths, so that the offsets are not fetched behind the branch on sk)
+                len = (int32_t)(o1 - o0);
+                if (sk) ph = -1; // served by the dense2 kernel on the other stream (pgx_classify_reads_kernel)
                 else {
-                    base = offsets[rid];
-                    len = (int32_t)(offsets[rid + 1] - base);
                     if (PACKED) { // the read's packed words into this thread's LDS column (the host sized pk_words for the longest read of the launch)
                         const uint32_t *src = packed + (base >> 4);
                         const uint32_t nw = ((uint32_t)(base & 15ull) + (uint32_t)len + 15u) >> 4;
-                        for (uint32_t w = 0; w < nw; w++) s_rd[w * rd_stride + threadIdx.x] = src[w];
+#pragma unroll 1
+                        for (uint32_t w0 = 0; w0 < nw; w0 += PGX_PK_GROUP) { // (a read of 150 symbols: ten or eleven words, one group)
+                            uint32_t t[PGX_PK_GROUP];
+#pragma unroll
+                            for (uint32_t i = 0; i < PGX_PK_GROUP; i++) t[i] = src[w0 + i < nw ? w0 + i : nw - 1u];
+#pragma unroll
+                            for (uint32_t i = 0; i < PGX_PK_GROUP; i++) if (w0 + i < nw) s_rd[(w0 + i) * rd_stride + threadIdx.x] = t[i];
+                        }
                     }
                     x = 0; nm = 0;
                     next0 = next;
@@ -1152,6 +1185,10 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             rnext += (uint64_t)want < avail ? (uint64_t)want : avail;
             idle = __ballot(ph == 0);
         }
+#ifdef PGX_FM_STATS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        st_t_refill += __builtin_readcyclecounter() - st_r0;
+#endif
         if (ph == -1) ph = 0;
         if (!__any(ph > 0)) {
             if (exhausted && rnext == rend) break;
@@ -1179,6 +1216,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(img.pairs + ((size_t)blk * 8 + piece)),
                                                  (void __attribute__((address_space(3))) *)(s_stage + 64 * i), 16, 0, 0);
             }
+            __builtin_amdgcn_s_setprio(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
@@ -1210,7 +1248,14 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                         }
                     }
                 }
+#ifdef PGX_FM_STATS
+                const unsigned long long st_s0 = __builtin_readcyclecounter();
+#endif
                 se = *sp;
+#ifdef PGX_FM_STATS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                st_t_seed += __builtin_readcyclecounter() - st_s0;
+#endif
             }
             fresh = 0u;
             const bool fwd = (ph == 2);
@@ -1252,33 +1297,55 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             const pos_t kk = fwd ? kp : k, kq = fwd ? k : kp;
             const pos_t p0 = kk, p1 = kk + s;
             // the block of p0 (96 positions); a second trip (pend) reads the block after it
-            const uint32_t bfirst = (uint32_t)(((uint64_t)(p0 >> 5) * 0xAAAAAAABull) >> 33); // p0 / 96 (p0 < 2^37)
-            const pos_t endrel_p = p1 - (pos_t)bfirst * PGX_PAIRS_SYMS;                       // p1 relative to the first block
+            const uint32_t bfirst = B64 ? (uint32_t)(p0 >> 6) : (uint32_t)(((uint64_t)(p0 >> 5) * 0xAAAAAAABull) >> 33); // p0 / 96 (p0 < 2^37)
+            const pos_t endrel_p = p1 - (pos_t)bfirst * SYMS;                                 // p1 relative to the first block
             const uint32_t endrel = endrel_p > (pos_t)0xFFFFu ? 0xFFFFu : (uint32_t)endrel_p; // (anything beyond two blocks is "far")
-            const uint32_t relA = pend ? 0u : p0 - bfirst * PGX_PAIRS_SYMS;
-            const uint32_t relB = pend ? endrel - PGX_PAIRS_SYMS : (endrel < PGX_PAIRS_SYMS ? endrel : PGX_PAIRS_SYMS);
+            const uint32_t relA = pend ? 0u : p0 - bfirst * SYMS;
+            const uint32_t relB = pend ? endrel - SYMS : (endrel < SYMS ? endrel : SYMS);
             uint4 row, hs, d0, d1, d2;
-            if (COOP) { // the line of this lane's probe is in LDS (fetched by the whole wave above)
+            if (B64) { // three pieces of the line, a fourth for a second symbol of code 3
+                const uint4 *bp = img.pairs + (size_t)(bfirst + pend) * 8;
+                row = bp[t1];                                                                  // rank of t1 before the block | flag << 31, pairs (t1, 0), (t1, 1), (t1, 2)
+                d0 = bp[6]; d1 = bp[7];                                                        // planes: c1 bit 0, c1 bit 1 | c2 bit 0, c2 bit 1, two dwords each
+                hs = make_uint4(0u, 0u, 0u, 0u);
+                if (t2 == 3u) hs = bp[5];                                                      // pairs (0..3, 3)
+                d2 = make_uint4(0u, 0u, 0u, 0u);
+                __builtin_amdgcn_s_setprio(0);
+            } else if (COOP) { // the line of this lane's probe is in LDS (fetched by the whole wave above)
                 const uint4 *mine = s_stage + (uint32_t)lane * 8u;
                 const uint32_t sw = (uint32_t)lane & 7u;
                 row = mine[t1 ^ sw]; hs = mine[4u ^ sw]; d0 = mine[5u ^ sw]; d1 = mine[6u ^ sw]; d2 = mine[7u ^ sw];
             } else {
+#ifdef PGX_FM_STATS
+                const unsigned long long st_l0 = __builtin_readcyclecounter();
+#endif
                 const uint4 *bp = img.pairs + (size_t)(bfirst + pend) * 8;
                 row = bp[t1];                                                                  // pairs (t1, A C G T) before the block
                 hs = bp[4];                                                                    // positions before the block with c2 special and c1 = A, C, G, T; bit 31 of .x: flag
                 d0 = bp[5]; d1 = bp[6]; d2 = bp[7];                                            // planes: c1 bit 0, c1 bit 1, c2 bit 0, c2 bit 1, three dwords each
+#ifdef PGX_EXP_LOAD6 // sensitivity experiment (scripts/exp_dup.sh): a sixth piece of the same line, thrown away
+                { const uint4 xx = bp[(t1 + 1u) & 3u]; asm volatile("" ::"v"(xx.x), "v"(xx.y), "v"(xx.z), "v"(xx.w)); }
+#endif
+#ifdef PGX_EXP_LOAD4 // ... and one piece less (wrong results: timing only)
+#endif
+                __builtin_amdgcn_s_setprio(0);
+#ifdef PGX_FM_STATS
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(row.x), "+v"(hs.x), "+v"(d0.x), "+v"(d1.x), "+v"(d2.x) :: "memory");
+                st_t_line += __builtin_readcyclecounter() - st_l0;
+#endif
             }
-            const bool flagged = (hs.x >> 31) != 0u;
-            const uint32_t pts = t1 == 0u ? (hs.x & 0x7FFFFFFFu) : (t1 == 1u ? hs.y : (t1 == 2u ? hs.z : hs.w));
+            const bool flagged = ((B64 ? row.x : hs.x) >> 31) != 0u;
+            const uint32_t pts = t1 == 0u ? (hs.x & 0x7FFFFFFFu) : (t1 == 1u ? hs.y : (t1 == 2u ? hs.z : hs.w)); // (B64: the pair count (t1, 3) where t2 = 3)
             // masks that turn "code == t" / "code > t" into plane expressions: (x ^ i0) & (y ^ i1) and (y & ua) | (x & (y | va) & wa)
             const uint32_t i0 = (t1 & 1u) ? 0u : 0xFFFFFFFFu, i1 = (t1 & 2u) ? 0u : 0xFFFFFFFFu, j0 = (t2 & 1u) ? 0u : 0xFFFFFFFFu, j1 = (t2 & 2u) ? 0u : 0xFFFFFFFFu;
             const uint32_t ua = t1 < 2u ? 0xFFFFFFFFu : 0u, va = t1 == 0u ? 0xFFFFFFFFu : 0u, wa = (t1 & 1u) ? 0u : 0xFFFFFFFFu;
             const uint32_t ub = t2 < 2u ? 0xFFFFFFFFu : 0u, vb = t2 == 0u ? 0xFFFFFFFFu : 0u, wb = (t2 & 1u) ? 0u : 0xFFFFFFFFu;
-            const uint32_t PX[3] = {d0.x, d0.y, d0.z}, PY[3] = {d0.w, d1.x, d1.y}, PU[3] = {d1.z, d1.w, d2.x}, PV[3] = {d2.y, d2.z, d2.w};
+            const uint32_t PX[3] = {d0.x, d0.y, B64 ? 0u : d0.z}, PY[3] = {B64 ? d0.z : d0.w, B64 ? d0.w : d1.x, B64 ? 0u : d1.y},
+                           PU[3] = {B64 ? d1.x : d1.z, B64 ? d1.y : d1.w, B64 ? 0u : d2.x}, PV[3] = {B64 ? d1.z : d2.y, B64 ? d1.w : d2.z, B64 ? 0u : d2.w};
             // counts below relA (absolute ranks need them) and in [relA, relB) (sizes and the other coordinate are differences)
             uint32_t e1p = 0, e2p = 0, e1r = 0, g1r = 0, e2r = 0, g2r = 0;
 #pragma unroll
-            for (int h = 0; h < 3; h++) {
+            for (int h = 0; h < (B64 ? 2 : 3); h++) {
                 const int32_t ta = (int32_t)relA - 32 * h, tb = (int32_t)relB - 32 * h;
                 const uint32_t mP = ta >= 32 ? 0xFFFFFFFFu : (ta > 0 ? ((1u << ta) - 1u) : 0u);
                 const uint32_t mR = (tb >= 32 ? 0xFFFFFFFFu : (tb > 0 ? ((1u << tb) - 1u) : 0u)) & ~mP;
@@ -1290,14 +1357,34 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 e1p += __popc(m1 & mP); e2p += __popc(q2 & mP);
                 e1r += __popc(m1 & mR); g1r += __popc(g1 & mR); e2r += __popc(q2 & mR); g2r += __popc(g2 & mR);
             }
-            pos_t a01 = (pos_t)(row.x + row.y + row.z + row.w + pts + e1p);                       // rank of the first symbol at p0
-            pos_t a02 = (pos_t)((t2 == 0u ? row.x : (t2 == 1u ? row.y : (t2 == 2u ? row.z : row.w))) + e2p); // rank of the pair at p0
+#ifdef PGX_EXP_DUP // sensitivity experiment (scripts/exp_dup.sh): the popcount section once more on the same planes, results thrown away
+            {
+                uint32_t dsum = 0;
+#pragma unroll
+                for (int h = 0; h < 3; h++) {
+                    uint32_t x = PX[h], y = PY[h], u = PU[h], v = PV[h];
+                    asm volatile("" : "+v"(x), "+v"(y), "+v"(u), "+v"(v));
+                    const int32_t ta = (int32_t)relA - 32 * h, tb = (int32_t)relB - 32 * h;
+                    const uint32_t mP = ta >= 32 ? 0xFFFFFFFFu : (ta > 0 ? ((1u << ta) - 1u) : 0u);
+                    const uint32_t mR = (tb >= 32 ? 0xFFFFFFFFu : (tb > 0 ? ((1u << tb) - 1u) : 0u)) & ~mP;
+                    const uint32_t m1 = (x ^ i0) & (y ^ i1);
+                    const uint32_t g1 = (y & ua) | (x & (y | va) & wa);
+                    const uint32_t q2 = m1 & (u ^ j0) & (v ^ j1);
+                    const uint32_t g2 = m1 & ((v & ub) | (u & (v | vb) & wb));
+                    dsum += __popc(m1 & mP) + __popc(q2 & mP) + __popc(m1 & mR) + __popc(g1 & mR) + __popc(q2 & mR) + __popc(g2 & mR);
+                }
+                asm volatile("" ::"v"(dsum));
+            }
+#endif
+            pos_t a01 = B64 ? (pos_t)((row.x & 0x7FFFFFFFu) + e1p) : (pos_t)(row.x + row.y + row.z + row.w + pts + e1p);                       // rank of the first symbol at p0
+            pos_t a02 = B64 ? (pos_t)((t2 == 0u ? row.y : (t2 == 1u ? row.z : (t2 == 2u ? row.w : pts))) + e2p)
+                            : (pos_t)((t2 == 0u ? row.x : (t2 == 1u ? row.y : (t2 == 2u ? row.z : row.w))) + e2p); // rank of the pair at p0
             if (WIDE) { // the counts of a block are deltas against its superblock
                 const uint64_t *pb = s_pb + (size_t)((bfirst + pend) >> img.pairs_sb_shift) * 24u;
                 a01 += (pos_t)pb[16u + t1];
                 a02 += (pos_t)pb[4u * t1 + t2];
             }
-            const bool straddle = endrel > PGX_PAIRS_SYMS, far = endrel > 2u * PGX_PAIRS_SYMS;
+            const bool straddle = endrel > SYMS, far = endrel > 2u * SYMS;
             const bool bail = !fr && (flagged || far); // (a second block is used only when it is not flagged either: nothing special between the two ends)
             const bool wait = !fr && !pend && straddle && !bail; // the interval runs on into the next block: next trip
 #ifdef PGX_FM_STATS
@@ -1378,6 +1465,8 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
 #ifdef PGX_FM_STATS // wave trips / live lane-trips, lane-trips waiting for the second block / fresh
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) st_wait += __shfl_down(st_wait, off, 64);
+    if (lane == 0) { atomicAdd(n_ext_total + PGX_CTR_ST_PAIR_T_REFILL, st_t_refill); atomicAdd(n_ext_total + PGX_CTR_ST_PAIR_T_TOTAL, __builtin_readcyclecounter() - st_t0); atomicAdd(n_ext_total + PGX_CTR_ST_PAIR_REFILLS, st_refills);
+                     atomicAdd(n_ext_total + PGX_CTR_ST_PAIR_T_SEED, st_t_seed); atomicAdd(n_ext_total + PGX_CTR_ST_PAIR_T_LINE, st_t_line); }
     if (lane == 0) { atomicAdd(n_ext_total + PGX_CTR_ST_PAIR_TRIPS, st_trips); atomicAdd(n_ext_total + PGX_CTR_ST_PAIR_LIVE, st_live); atomicAdd(n_ext_total + PGX_CTR_ST_PAIR_WAIT, st_wait); atomicAdd(n_ext_total + PGX_CTR_ST_PAIR_FRESH, st_fresh); }
 #endif
 }
@@ -1386,12 +1475,14 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                                                                      pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t, uint32_t, \
                                                                      uint32_t, pgx_heavy_item *, unsigned long long *, pgx_heavy_item *, unsigned long long *,       \
                                                                      const uint8_t *, const uint32_t *, uint32_t, uint32_t *, uint64_t);
-PGX_PAIRS_INSTANTIATE(true, false, false, false)
-PGX_PAIRS_INSTANTIATE(true, true, false, false)
-PGX_PAIRS_INSTANTIATE(true, false, true, false)
-PGX_PAIRS_INSTANTIATE(true, true, true, false)
-PGX_PAIRS_INSTANTIATE(true, false, true, true)
-PGX_PAIRS_INSTANTIATE(true, true, true, true)
+PGX_PAIRS_INSTANTIATE(true, false, false, false, false)
+PGX_PAIRS_INSTANTIATE(true, true, false, false, false)
+PGX_PAIRS_INSTANTIATE(true, false, true, false, false)
+PGX_PAIRS_INSTANTIATE(true, true, true, false, false)
+PGX_PAIRS_INSTANTIATE(true, false, true, true, false)
+PGX_PAIRS_INSTANTIATE(true, true, true, true, false)
+PGX_PAIRS_INSTANTIATE(true, false, false, false, true)
+PGX_PAIRS_INSTANTIATE(true, false, true, false, true)
 
 // first extension of every backward stage: the full interval extended by each byte value
 __global__ void __launch_bounds__(256) pgx_first_ext_kernel(PgxDevImage img, uint4 *__restrict__ out) { // out[512]

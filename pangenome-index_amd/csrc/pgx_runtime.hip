@@ -216,7 +216,7 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
     upload(d->sbase2, m.sbase2.data(), m.sbase2.size() * 8);
     g.sbase2 = d->sbase2.as<uint64_t>();
     g.d2_sb_shift = m.consts.d2_sb_shift; g.n_sb2 = m.consts.n_sb2;
-    g.pbase = nullptr; g.pairs_sb_shift = 0; g.n_sbp = 0;
+    g.pbase = nullptr; g.pairs_sb_shift = 0; g.n_sbp = 0; g.pairs_syms = 0;
     g.exc = d->exc.as<uint32_t>();
     size_t img_bytes = m.blocks.size() + m.dir.size() * 8 + m.blow.size() * 2;
     if (g.dense == 1) img_bytes = (size_t)m.consts.n_blocks * 16 * PGX_DENSE_LDS_U4 + 16; // padded blocks, no directory (pgx_dense_load)
@@ -234,6 +234,7 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
         upload(d->pbase, m.pbase.data(), m.pbase.size() * 8);
         g.pbase = d->pbase.as<uint64_t>();
         g.pairs_sb_shift = m.consts.pairs_sb_shift; g.n_sbp = m.consts.n_sbp;
+        g.pairs_syms = m.consts.pairs_syms;
         d->first_ext.ensure(512 * sizeof(uint4));
         hipLaunchKernelGGL(pgx_first_ext_kernel, dim3(1), dim3(256), 0, nullptr, g, d->first_ext.as<uint4>());
         HIPCHECK(hipGetLastError());
@@ -1206,7 +1207,8 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         const char *pv = std::getenv("PGX_FM_PAIRS");
         // (only behind the seed table: the wide intervals at the start of an unseeded stage always have special positions between their ends)
         if (img.pairs && seeded && !(n >> 32) && b->read_bytes < (1ull << 35) && !(pv && pv[0] == '0'))
-            kfn_pairs = img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, false, false> : (const void *)pgx_find_mems_pairs_kernel<true, false, false, false>;
+            kfn_pairs = img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, false, false, false>
+                                 : (img.pairs_syms == PGX_PAIRS_SYMS64 ? (const void *)pgx_find_mems_pairs_kernel<true, false, false, false, true> : (const void *)pgx_find_mems_pairs_kernel<true, false, false, false, false>);
         pairs_lds = img.wide ? (size_t)img.n_sbp * 192 : 0; // (superblock bases of the wide form, behind the other dynamic LDS)
         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn_pairs ? kfn_pairs : kfn, PGX_FM_THREADS, kfn_pairs ? pairs_lds : b->dimg->lds_bytes));
         HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
@@ -1344,10 +1346,12 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                     if (a_skip && pkw <= 24 && !(pe && pe[0] == '0')) {
                         // cooperative line fetches (one address translation per line instead of five) for PAIRS images beyond the reach of the
                         // translation caches, ~3 GB (profiles/r03_ubench_gather_loads_per_line.txt); PGX_FM_COOP=0 / 1 overrides
-                        bool coop = b->h->img.pairs.size() > (3ull << 30);
-                        if (const char *ce = std::getenv("PGX_FM_COOP")) coop = ce[0] == '1';
-                        kp = coop ? (img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, true, true> : (const void *)pgx_find_mems_pairs_kernel<true, false, true, true>)
-                                  : (img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, true, false> : (const void *)pgx_find_mems_pairs_kernel<true, false, true, false>);
+                        const bool b64 = img.pairs_syms == PGX_PAIRS_SYMS64; // (three pieces of the line per probe: nothing to gain from fetching whole lines together)
+                        bool coop = !b64 && b->h->img.pairs.size() > (3ull << 30);
+                        if (const char *ce = std::getenv("PGX_FM_COOP")) coop = !b64 && ce[0] == '1';
+                        kp = b64    ? (const void *)pgx_find_mems_pairs_kernel<true, false, true, false, true>
+                             : coop ? (img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, true, true, false> : (const void *)pgx_find_mems_pairs_kernel<true, false, true, true, false>)
+                                    : (img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, true, false, false> : (const void *)pgx_find_mems_pairs_kernel<true, false, true, false, false>);
                         a_packed = b->packed.as<uint32_t>();
                         a_pkw = pkw;
                         plds = (size_t)pkw * PGX_FM_THREADS * 4 + (coop ? (size_t)(PGX_FM_THREADS / 64) * 8192 : 0) + (img.wide ? (size_t)img.n_sbp * 192 : 0);
@@ -1478,6 +1482,10 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         std::fprintf(stderr, "[pgx] pairs kernel wave trips %llu, live lane-trips %llu (%.1f%%), with two extensions %llu, waiting for a second block %llu, fresh %llu, reads handed on %llu\n",
                      cnt[PGX_CTR_ST_PAIR_TRIPS], cnt[PGX_CTR_ST_PAIR_LIVE], 100.0 * (double)cnt[PGX_CTR_ST_PAIR_LIVE] / (64.0 * (double)cnt[PGX_CTR_ST_PAIR_TRIPS]),
                      cnt[PGX_CTR_PAIRS_TWO], cnt[PGX_CTR_ST_PAIR_WAIT], cnt[PGX_CTR_ST_PAIR_FRESH], cnt[PGX_CTR_REDO]);
+    if (cnt[PGX_CTR_ST_PAIR_T_TOTAL] && std::getenv("PGX_FM_STATS"))
+        std::fprintf(stderr, "[pgx] pairs kernel clock ticks: %.1f%% of the waves' time in the refill loop (%llu of %llu), %llu trips with a refill round; waiting for the seed entry %.1f%%, then for the block line %.1f%%\n",
+                     100.0 * (double)cnt[PGX_CTR_ST_PAIR_T_REFILL] / (double)cnt[PGX_CTR_ST_PAIR_T_TOTAL], cnt[PGX_CTR_ST_PAIR_T_REFILL], cnt[PGX_CTR_ST_PAIR_T_TOTAL], cnt[PGX_CTR_ST_PAIR_REFILLS],
+                     100.0 * (double)cnt[PGX_CTR_ST_PAIR_T_SEED] / (double)cnt[PGX_CTR_ST_PAIR_T_TOTAL], 100.0 * (double)cnt[PGX_CTR_ST_PAIR_T_LINE] / (double)cnt[PGX_CTR_ST_PAIR_T_TOTAL]);
     if (std::getenv("PGX_DEBUG_COUNTERS"))
         std::fprintf(stderr, "[pgx] counters: extensions %llu tag overflows %llu heavy %llu redo %llu lines %llu + %llu seeds %llu + %llu\n", cnt[PGX_CTR_EXT], cnt[PGX_CTR_TAG_OVERFLOW],
                      cnt[PGX_CTR_HEAVY], cnt[PGX_CTR_REDO], cnt[PGX_CTR_PAIRS_LINES], cnt[PGX_CTR_FM_LINES], cnt[PGX_CTR_PAIRS_SEEDS], cnt[PGX_CTR_FM_SEEDS]);

@@ -8,5 +8,5 @@ cp -r pangenome-index_amd include oracle bench.py __graft_entry__.py tests $D/ 2
 cd $D/pangenome-index_amd && rm -rf build libpgx.so && make -s -j8 CXXFLAGS="-O3 -std=c++17 -fPIC -DPGX_FM_STATS" libpgx.so
 cd $D
 for wl in ${WLS:-x synth}; do
-  echo "$wl $*"; PGX_FM_STATS=1 python3 bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --no-tags "$@" 2>&1 | grep -E "pgx\]" | tail -2
+  echo "$wl $*"; PGX_FM_STATS=1 python3 bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --no-tags "$@" 2>&1 | grep -E "pgx\]" | tail -3
 done

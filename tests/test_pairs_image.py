@@ -7,11 +7,18 @@ import pytest
 
 import pgx_ffi as P
 import pgx_workload as W
-from image_emu import Consts
+from image_emu import Consts, PairsLayout
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 NUC = {10: 0, ord("A"): 1, ord("C"): 2, ord("G"): 3, ord("N"): 4, ord("T"): 5}
 TWO = np.array([-1, 0, 1, 2, -1, 3])
+
+
+@pytest.fixture(params=["96", "64"])
+def psyms(request, monkeypatch):
+    """both block sizes of the PAIRS image (pgx_image.h): the host builder takes PGX_PAIRS_SYMS"""
+    monkeypatch.setenv("PGX_PAIRS_SYMS", request.param)
+    return int(request.param)
 
 
 def _bwt_codes(rl_path):
@@ -19,7 +26,7 @@ def _bwt_codes(rl_path):
     return np.repeat(np.array([NUC[int(s)] for s in sym], dtype=np.int64), ln.astype(np.int64))
 
 
-def _check(idx, bw):
+def _check(idx, bw, syms=None):
     c = Consts(idx.image_view(6))
     assert c.has_pairs == 1 and idx.info().image_pairs == 1 and idx.info().image_kind == P.IMAGE_DENSE2
     n = len(bw)
@@ -36,7 +43,10 @@ def _check(idx, bw):
     special = (y < 0) | (x < 0)
     pair = np.where(special, -1, 4 * y + x)
     blocks = idx.image_view(20).reshape(-1, 32)
-    nb = n // 96 + 1
+    L = PairsLayout(c)
+    B = L.syms
+    assert idx.info().pairs_syms == B and (syms is None or B == syms)
+    nb = n // B + 1
     assert len(blocks) == nb
     # special runs (statistics) and, per first symbol, the positions whose second symbol is special: what the pair counts do not see of it
     starts = np.flatnonzero(special & ~np.concatenate([[False], special[:-1]]))
@@ -45,25 +55,28 @@ def _check(idx, bw):
     n_special = np.concatenate([[0], np.cumsum(special)])
     cum = np.zeros(16, dtype=np.int64)
     for b in range(nb):
-        s0, s1 = 96 * b, min(96 * b + 96, n)
+        s0, s1 = B * b, min(B * b + B, n)
         h = blocks[b]
-        assert [int(v) for v in h[:16]] == list(cum), b
+        assert [L.pair_before(h, i >> 2, i & 3) for i in range(16)] == list(cum), b
         flag = bool(special[s0:s1].any())
-        assert int(h[16]) >> 31 == (1 if flag else 0), (b, hex(int(h[16])), flag)
-        assert [int(h[16]) & 0x7FFFFFFF] + [int(v) for v in h[17:20]] == [int(half[yy][s0]) for yy in range(4)], b
+        assert L.flag(h) == int(h[16]) >> 31 == (1 if flag else 0), (b, hex(int(h[16])), flag)
+        if B == 64:
+            assert all(int(h[4 * yy]) >> 31 == (1 if flag else 0) for yy in range(4))
+        assert [L.half_before(h, yy) for yy in range(4)] == [int(half[yy][s0]) for yy in range(4)], b
+        assert [L.rank_before(h, yy) for yy in range(4)] == [int((y[:s0] == yy).sum()) for yy in range(4)], b
         # every position before a block is a regular pair or a special position; rank of symbol y = its row sum + its half-special count
         assert s0 - int(cum.sum()) == int(n_special[s0])
         for yy in range(4):
             assert int(cum[4 * yy:4 * yy + 4].sum()) + int(half[yy][s0]) == int((y[:s0] == yy).sum())
         for i in range(s1 - s0):
             pv = int(pair[s0 + i])
-            bits = [(int(h[20 + 3 * pl + (i >> 5)]) >> (i & 31)) & 1 for pl in range(4)]
+            bits = [(L.plane_word(h, pl, i >> 5) >> (i & 31)) & 1 for pl in range(4)]
             if pv >= 0:
                 assert bits == [(pv >> 2) & 1, (pv >> 3) & 1, pv & 1, (pv >> 1) & 1], (b, i)
             else:
                 assert bits == [0, 0, 0, 0]
-        for i in range(s1 - s0, 96):
-            assert all(((int(h[20 + 3 * pl + (i >> 5)]) >> (i & 31)) & 1) == 0 for pl in range(4))
+        for i in range(s1 - s0, B):
+            assert all(((L.plane_word(h, pl, i >> 5) >> (i & 31)) & 1) == 0 for pl in range(4))
         cum += np.bincount(pair[s0:s1][pair[s0:s1] >= 0], minlength=16)
     for yy, code in enumerate((1, 2, 3, 5)):
         exp = np.bincount(bw[:trueC[code]], minlength=6)
@@ -71,7 +84,7 @@ def _check(idx, bw):
 
 
 @pytest.mark.parametrize("mode", [P.MODE_COMPAT, P.MODE_STRICT])
-def test_pairs_image_of_a_text_with_N_runs(workdir, mode):
+def test_pairs_image_of_a_text_with_N_runs(workdir, mode, psyms):
     rng = np.random.default_rng(5)
     seqs = []
     base = "".join("ACGT"[i] for i in rng.integers(0, 4, 3000))
@@ -91,14 +104,14 @@ def test_pairs_image_of_a_text_with_N_runs(workdir, mode):
     ri, _, rl = (W.build_index_from_text(text, workdir, "pairs_n", with_tags=False) + (None,))[:3]
     rl = os.path.join(workdir, "pairs_n.rl_bwt")
     idx = P.Index(ri, mode=mode | P.MODE_IMAGE_PAIRS)
-    _check(idx, _bwt_codes(rl))
+    _check(idx, _bwt_codes(rl), psyms)
 
 
-def test_pairs_image_of_the_reference_fixtures(workdir):
+def test_pairs_image_of_the_reference_fixtures(workdir, psyms):
     for name in ("x.rl_bwt", "med_test.rl_bwt"):
         ri, _ = W.build_index_from_rlbwt(os.path.join(G, name), workdir, "pairs_" + name, with_tags=False)
         idx = P.Index(ri, mode=P.MODE_STRICT | P.MODE_IMAGE_PAIRS)
-        _check(idx, _bwt_codes(os.path.join(G, name)))
+        _check(idx, _bwt_codes(os.path.join(G, name)), psyms)
 
 
 def test_pairs_image_refused_where_the_tables_are_not_the_textbook_ones(workdir, built):
@@ -123,10 +136,11 @@ class PairsEmu:
     def __init__(self, idx):
         self.c = Consts(idx.image_view(6))
         self.blocks = idx.image_view(20).reshape(-1, 32)
+        self.L = PairsLayout(self.c)
 
     def _counts(self, b, rel_a, rel_b, t1, t2):
         h = self.blocks[b]
-        pl = [[int(h[20 + 3 * p + w]) for w in range(3)] for p in range(4)]
+        pl = [[self.L.plane_word(h, p, w) for w in range(self.L.words)] for p in range(4)]
         bits = lambda p, i: (pl[p][i >> 5] >> (i & 31)) & 1
         c1 = lambda i: bits(0, i) | (bits(1, i) << 1)
         c2 = lambda i: bits(2, i) | (bits(3, i) << 1)
@@ -149,21 +163,22 @@ class PairsEmu:
         t1, t2 = cv1 - 1 - (cv1 >> 2), cv2 - 1 - (cv2 >> 2)
         kk, kq = (kp, k) if fwd else (k, kp)
         p0, p1 = kk, kk + s
-        bf = p0 // 96
-        endrel = p1 - 96 * bf
-        if endrel > 192:
+        B, L = self.L.syms, self.L
+        bf = p0 // B
+        endrel = p1 - B * bf
+        if endrel > 2 * B:
             return None
         h = self.blocks[bf]
-        if int(h[16]) >> 31:
+        if L.flag(h):
             return None
-        e1p, e2p, e1r, g1r, e2r, g2r = self._counts(bf, p0 - 96 * bf, min(endrel, 96), t1, t2)
-        a01 = sum(int(h[4 * t1 + x]) for x in range(4)) + (int(h[16 + t1]) & 0x7FFFFFFF) + e1p
-        a02 = int(h[4 * t1 + t2]) + e2p
-        if endrel > 96:
+        e1p, e2p, e1r, g1r, e2r, g2r = self._counts(bf, p0 - B * bf, min(endrel, B), t1, t2)
+        a01 = L.rank_before(h, t1) + e1p
+        a02 = L.pair_before(h, t1, t2) + e2p
+        if endrel > B:
             h2 = self.blocks[bf + 1]
-            if int(h2[16]) >> 31:
+            if L.flag(h2):
                 return None
-            _, _, a, b, c, d = self._counts(bf + 1, 0, endrel - 96, t1, t2)
+            _, _, a, b, c, d = self._counts(bf + 1, 0, endrel - B, t1, t2)
             e1r, g1r, e2r, g2r = e1r + a, g1r + b, e2r + c, g2r + d
         s1, k1, q1 = e1r, a01 + self.c.C[(e1 >> 3) & 7], kq + g1r
         s2, k2, q2 = e2r, a02 + self.c.C[(e2 >> 3) & 7] + self.c.pair_t2[8 * t1 + cv2], q1 + g2r
@@ -173,7 +188,7 @@ class PairsEmu:
 
 
 @pytest.mark.parametrize("mode,omode", [(P.MODE_COMPAT, 0), (P.MODE_STRICT, 1)])
-def test_two_step_arithmetic_equals_two_oracle_extensions(workdir, mode, omode):
+def test_two_step_arithmetic_equals_two_oracle_extensions(workdir, mode, omode, psyms):
     """walks of random reads through the oracle, every interval narrower than two blocks extended by the next two symbols through the PAIRS
     image: the first result and the result of both equal the oracle's stepwise bi-intervals, backward and forward"""
     import oracle_ffi as O
@@ -224,7 +239,7 @@ def test_two_step_arithmetic_equals_two_oracle_extensions(workdir, mode, omode):
     assert checked > 5000 and handed_on < checked // 5, (checked, handed_on)
 
 
-def test_pairs_image_does_not_depend_on_the_builder_threads(workdir, monkeypatch):
+def test_pairs_image_does_not_depend_on_the_builder_threads(workdir, monkeypatch, psyms):
     """the builder splits the BWT into chunks of blocks, one thread each (LF offsets, pair counts and special runs are stitched at the
     chunk borders): 1, 3 and 16 threads give the same bytes, and they are the brute-force image"""
     rng = np.random.default_rng(23)
@@ -249,7 +264,7 @@ def test_pairs_image_does_not_depend_on_the_builder_threads(workdir, monkeypatch
         idx = P.Index(ri, mode=P.MODE_STRICT | P.MODE_IMAGE_PAIRS)
         images.append((idx.image_view(20).tobytes(), bytes(idx.image_view(6))))
         if threads == "16":
-            _check(idx, _bwt_codes(os.path.join(workdir, "pairs_thr.rl_bwt")))
+            _check(idx, _bwt_codes(os.path.join(workdir, "pairs_thr.rl_bwt")), psyms)
     assert images[0] == images[1] == images[2]
 
 
@@ -389,7 +404,7 @@ class PairsKernelEmu(PairsEmu):
 
 
 @pytest.mark.parametrize("mode,omode", [(P.MODE_COMPAT, 0), (P.MODE_STRICT, 1)])
-def test_pairs_kernel_state_machine_emulated(workdir, mode, omode):
+def test_pairs_kernel_state_machine_emulated(workdir, mode, omode, psyms):
     """the whole two-step search of reads, emulated from the image views, against the oracle's find_all_mems: MEMs and extension counts"""
     import oracle_ffi as O
     rng = np.random.default_rng(29)

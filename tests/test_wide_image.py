@@ -25,6 +25,7 @@ def wide_case(workdir):
 @pytest.mark.parametrize("shift", ["2", "4", "7"])
 def test_wide_images_are_the_narrow_ones_rebased(wide_case, monkeypatch, shift):
     ri, _, _ = wide_case
+    monkeypatch.setenv("PGX_PAIRS_SYMS", "96")  # the wide form keeps the 96-position blocks: compare with the narrow image of that layout
     narrow = P.Index(ri, None, mode=P.MODE_COMPAT | P.MODE_IMAGE_PAIRS)
     monkeypatch.setenv("PGX_SB_SHIFT", shift)
     wide = P.Index(ri, None, mode=P.MODE_COMPAT | P.MODE_IMAGE_PAIRS | P.MODE_IMAGE_WIDE)
