@@ -439,7 +439,7 @@ def main():
             "mems_per_step": tot[0], "positions_per_step": tot[1], "extensions_per_step": tot[2],
             "kernel_ms_per_step": k_ms,
             "speculative_runs": dict(zip(("sized_from_the_previous_run", "repeated_with_exact_sizes"), batch.spec_stats())),
-            "pairs_kernel": {"used": bool(batch.timing().pairs_reads), "reads_handed_to_the_dense2_kernel": int(batch.timing().redo_reads)},
+            "pairs_kernel": {"used": bool(batch.timing().pairs_reads), "extensions_through_the_dense2_image": int(batch.timing().pairs_other_steps)},
             "roofline": roofline_record(info, len(cat), n, counts, k_ms, batch.timing(), args.workload, args.min_len, not args.no_tags),
         }
         if args.pcie:

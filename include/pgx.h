@@ -279,7 +279,8 @@ typedef struct {
     uint32_t find_mems_launches;
     uint32_t heavy_reads; /* reads whose rest went through the heavy-read kernel (filled by every run, timed or not) */
     uint32_t pairs_reads; /* != 0: the run used the two-step PAIRS kernel (2: with the reads packed in LDS; 3: and cooperative line fetches) */
-    uint32_t redo_reads;  /* reads the PAIRS kernel handed on to the dense2 kernel (they met \n or N in the BWT) */
+    uint32_t pairs_other_steps; /* extensions the PAIRS kernel took through the image it accompanies: its own block held \n or N, or the interval was wider
+                                 * than two blocks (until ABI 3's last revision: redo_reads, reads handed on to the dense2 kernel) */
     /* the first launch of the find_mems stage alone (the PAIRS kernel when pairs_reads, else pgx_find_mems_kernel): ms_find_mems
      * also covers the launches behind it (reads handed on, heavy reads) */
     float ms_find_mems_main;

@@ -16,8 +16,8 @@ enum PgxCounterSlot {
     PGX_CTR_HEAVY = 8,        // reads handed to pgx_find_mems_heavy_kernel
     PGX_CTR_OVF32 = 9,        // a coordinate left 32 bits (NARROW kernels): the chunk is repeated in 64 bits
     PGX_CTR_MEMS = 10,        // MEMs of the chunk (scan total)
-    PGX_CTR_REDO = 11,        // reads the pairs kernel handed on
-    PGX_CTR_REDO_CURSOR = 12, // read cursor of the hand-on launch
+    PGX_CTR_REDO = 11,        // extensions the pairs kernel took through the image it accompanies (flagged blocks, wide intervals)
+    PGX_CTR_REDO_CURSOR = 12, // (unused since the pairs kernel no longer hands reads on)
     PGX_CTR_SIDE_CURSOR = 13, // read cursor of the side-stream launch (reads with a byte outside A C G T)
     PGX_CTR_OVF_TOP = 14,     // slots handed out of the arena of fifth-and-later MEMs (pgx_slot_extent)
     PGX_CTR_OVF_ABORT = 15,   // the arena was too small: the chunk is repeated in the worst-case slot layout
@@ -116,13 +116,13 @@ __global__ void pgx_find_mems_kernel(PgxDevImage img, const uint8_t *reads, cons
                                      uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor, uint64_t first_read,
                                      uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap, pgx_heavy_item *heavy_list, unsigned long long *heavy_count,
                                      const pgx_heavy_item *rid_list, const unsigned long long *rid_count, uint32_t *ovf_base, uint64_t ovf_cap);
-// PAIRS image (pgx_image.h): two extensions per loop trip; reads that meet a special position go to redo_list (then served by the kernel above)
+// PAIRS image (pgx_image.h): two extensions per loop trip; an extension its blocks cannot answer (special positions) goes through the other image
 template <bool SEED, bool WIDE, bool PACKED, bool COOP, bool B64>
 __global__ void pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
                                            uint64_t min_len, uint64_t min_occ, const uint64_t *slot_off, pgx_mem *slots,
                                            uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor, uint64_t first_read,
                                            uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap, pgx_heavy_item *heavy_list, unsigned long long *heavy_count,
-                                           pgx_heavy_item *redo_list, unsigned long long *redo_count, const uint8_t *skip, const uint32_t *packed, uint32_t pk_words,
+                                           const uint8_t *skip, const uint32_t *packed, uint32_t pk_words,
                                            uint32_t *ovf_base, uint64_t ovf_cap);
 __global__ void pgx_bad_chunks_kernel(const uint8_t *reads, uint64_t n_bytes, uint64_t *chunks, unsigned long long *count, uint64_t cap, uint32_t *packed);
 __global__ void pgx_classify_reads_kernel(const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads, const uint64_t *chunks, const unsigned long long *n_chunks,

@@ -532,7 +532,7 @@ pgx_seed_build_kernel(PgxDevImage img, const uint4 *__restrict__ src, uint4 *__r
 // offset (slot_off) behind that array
 #define PGX_FAST_SLOTS 4u
 #ifndef PGX_PAIRS_PACKED_WAVES
-#define PGX_PAIRS_PACKED_WAVES 6 // waves per SIMD the packed narrow pairs kernel is compiled for (80 VGPRs)
+#define PGX_PAIRS_PACKED_WAVES 5 // waves per SIMD the packed narrow pairs kernel is compiled for (95 VGPRs with the inline dense2 step; 79 and six waves without it were no faster)
 #endif
 #define PGX_PK_GROUP 12u // packed words of a read fetched per round of loads when a lane takes the read
 __device__ __forceinline__ uint64_t pgx_slot_index(uint64_t read_in_chunk, uint64_t chunk_reads, uint64_t slot, uint32_t nm) {
@@ -600,8 +600,8 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     PGX_LDS_CARVE(img);
     if (DENSE == 3) for (uint32_t i = threadIdx.x; i < img.n_sb2 * 8u; i += blockDim.x) s_sb[i] = img.sbase2[i];
     pgx_stage_tables<LDS_IMAGE>(img, s_ext, s_C, lds_blocks, lds_dir, lds_blow);
-    // rid_list (may be NULL): the launch serves the reads listed there (handed on by pgx_find_mems_pairs_kernel), *rid_count of them, each from
-    // the start position it was handed on at, keeping the MEMs written before
+    // rid_list (may be NULL): the launch serves the reads listed there (the reads with a byte outside A C G T, which the pairs kernel skips: the launch
+    // on the second stream), *rid_count of them, each from the start position listed, keeping the MEMs written before
     const uint64_t chunk_first = first_read, chunk_reads = n_reads - first_read; // (n_reads is the END of the chunk)
     if (rid_list) { first_read = 0; n_reads = *rid_count; }
 
@@ -1013,9 +1013,9 @@ pgx_classify_reads_kernel(const uint8_t *__restrict__ reads, const uint64_t *__r
 // one at its own j.  MEMs, restart positions and n_extensions are those of pgx_find_mems_kernel.  Positions, counts and C are below
 // 2^32 (the image exists for such indexes only), so the state is 32-bit.  A stage that starts from the full interval takes its first
 // extension from img.first_ext (or the seed tables): the image is never probed with the full interval.
-// A lane that meets a flagged block, two blocks with different run counts, or an interval wider than two blocks gives its read up:
-// the read goes to redo_list with its current start position and pgx_find_mems_kernel (on the dense / dense2 image the PAIRS image accompanies)
-// carries on from there.
+// A lane that meets a flagged block or an interval wider than two blocks takes THAT extension through the image the PAIRS image accompanies
+// (one rank probe after the other in a rolled loop, exact for every symbol) and carries on with pairs; until the end of round 3 it gave its read
+// up to a list that pgx_find_mems_kernel served behind this kernel.
 __device__ __forceinline__ uint32_t pgx_window_byte(uint64_t w0, uint64_t w1, uint64_t a) { // byte a of the 16-byte window
     return (uint32_t)(((a & 8ull) ? w1 : w0) >> (8u * (uint32_t)(a & 7ull))) & 0xFFu;
 }
@@ -1039,8 +1039,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                            uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
                            pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
                            unsigned long long *__restrict__ cursor, uint64_t first_read, uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap,
-                           pgx_heavy_item *__restrict__ heavy_list, unsigned long long *__restrict__ heavy_count,
-                           pgx_heavy_item *__restrict__ redo_list, unsigned long long *__restrict__ redo_count, const uint8_t *__restrict__ skip,
+                           pgx_heavy_item *__restrict__ heavy_list, unsigned long long *__restrict__ heavy_count, const uint8_t *__restrict__ skip,
                            const uint32_t *__restrict__ packed, uint32_t pk_words, uint32_t *__restrict__ ovf_base, uint64_t ovf_cap) {
     typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type pos_t;
     __shared__ uint32_t s_ext[512];
@@ -1079,7 +1078,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     uint64_t base = 0;
     int32_t len = 0, x = 0, j = 0;
     pos_t k = 0, kp = 0, s = 0, Jk = 0, Js = 0;
-    uint32_t nm = 0, next = 0, next0 = 0, nextb = 0; // nextb: value of `next` when the current start position was begun
+    uint32_t nm = 0, next = 0, next0 = 0;
     int ph = 0;
     uint64_t win = 0, win_hi = 0;
     uint32_t win_at = ~0u; // the cached 16 bytes of the reads buffer: their offset / 16 (16 rather than 32 bytes: four registers less, no difference in time)
@@ -1108,7 +1107,6 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             }
         }
         k = 0; kp = 0; s = n;
-        nextb = next;
         if (min_len == 0) { Jk = 0; Js = n; j = x; ph = 2; }
         else { j = x + (int32_t)min_len - 1; ph = 1; fresh = 1u; }
     };
@@ -1390,13 +1388,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
 #ifdef PGX_FM_STATS
             st_wait += wait ? 1ull : 0ull;
 #endif
-            if (bail) { // special positions in the way (or an interval wider than two blocks): the dense2 kernel searches this read
-                // from this start position on; step 3 means the MEM of this start position has been written: the other kernel writes it again
-                pgx_heavy_item it;
-                it.rid = (uint64_t)rid; it.x = (uint32_t)x; it.nm = nm - (ph == 3 ? 1u : 0u);
-                redo_list[atomicAdd(redo_count, 1ull)] = it;
-                ph = 0; next = nextb; pend = 0u;
-            } else if (wait) {
+            if (wait) {
                 X0 = e1r | (g1r << 8) | (e2r << 16) | (g2r << 24); X0e = a01; X0f = a02;
                 pend = 1u;
             } else {
@@ -1407,6 +1399,37 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 // first extension (src/r-index.cpp:713-764); a symbol that is not A C G T has no occurrence in a range free of special positions
                 pos_t s1 = reg1 ? (pos_t)c1 : (pos_t)0;
                 pos_t k1 = r1 + s_C[PGX_EXT_V(e1)], q1v = kq + (pos_t)w1;
+                if (bail) { // special positions in the way (or an interval wider than two blocks): THIS extension alone through the dense2 image the
+                    // PAIRS image accompanies (two more lines, exact for every symbol), then on with pairs.  (Until round 3 the read went to a list
+                    // and pgx_find_mems_kernel searched the rest of it behind this kernel: 0.8 ms of a 20 ms step for 0.1 % of the reads.)
+                    // (one probe after the other in a rolled loop: this path is rare and must not cost the common one its registers)
+                    const uint64_t q0 = (uint64_t)p0 > (uint64_t)n ? (uint64_t)n : (uint64_t)p0, q1 = (uint64_t)p1 > (uint64_t)n ? (uint64_t)n : (uint64_t)p1;
+                    uint64_t A0 = 0, A1 = 0, B0 = 0, B1 = 0;
+#pragma unroll 1
+                    for (int it = 0; it < 2; it++) {
+                        const uint64_t q = it ? q1 : q0;
+                        uint64_t a, bq;
+                        if (WIDE) pgx_dense2w_rank(img, q, PGX_EXT_CV(e1), PGX_EXT_M(e1), a, bq);
+                        else if (img.dense == 1) { // (a small index: the 64-byte dense image)
+                            const PgxDenseBlk db = pgx_dense_load<false>(img, nullptr, q);
+                            pgx_dense_rank(db, q, PGX_EXT_CV(e1), PGX_EXT_M(e1), a, bq);
+                        } else pgx_dense2_rank(img, (uint32_t)q, PGX_EXT_CV(e1), PGX_EXT_M(e1), a, bq);
+                        A1 = a; B1 = bq;
+                        if (!it) { A0 = a; B0 = bq; }
+                    }
+                    const uint64_t dB = B1 - B0;
+                    { // (rare, and inside diverged control flow: counted with one atomic by the first lane that is here, not in the wave-uniform sums)
+                        const unsigned long long here = __ballot(true);
+                        if (lane == (int)__ffsll((long long)here) - 1) {
+                            atomicAdd(n_ext_total + PGX_CTR_REDO, (unsigned long long)__popcll(here));
+                            atomicAdd(n_ext_total + PGX_CTR_PAIRS_LINES, 2ull * (unsigned long long)__popcll(here)); // the two lines of the other image
+                        }
+                    }
+                    const bool none = PGX_EXT_KILL(e1) || A0 >= A1; // rank_k >= rank_ks -> bi_interval(0,0,0), src/r-index.cpp:751
+                    s1 = none ? (pos_t)0 : (pos_t)(A1 - A0);
+                    k1 = (pos_t)A0 + s_C[PGX_EXT_V(e1)];
+                    q1v = kq + (pos_t)dB;
+                }
                 if (fr) { const uint4 f = s_fe[PACKED ? (at_end ? 4u : ((byte >> 1) & 3u)) : byte]; k1 = ent_k(f); q1v = ent_q(f); s1 = ent_s(f); }
                 const bool small1 = s1 == 0u || s1 < mo || mo_huge;
                 // a usable seed entry stands for the first extension and the ones after it
@@ -1414,7 +1437,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 const pos_t se_s = ent_s(se);
                 const bool seed_alive = SEED && seed_lane && se_s != 0u && se_s >= mo && !mo_huge;
                 const bool seed_dead = SEED && seed_lane && se_s == 0u && sdepth != PGX_SEED_UNUSABLE && min_occ <= 1;
-                const bool do2 = (fr ? (at_end && rem2 && have2 && !seed_alive && !seed_dead) : two) && !small1;
+                const bool do2 = (fr ? (at_end && rem2 && have2 && !seed_alive && !seed_dead) : (two && !bail)) && !small1;
                 pos_t s2 = (pos_t)c2, k2 = r2 + s_C[PGX_EXT_V(e2)] + s_t2[8u * t1 + cv2], q2v = q1v + (pos_t)w2;
                 if (fr) { const uint4 f = s_fe[PACKED ? 5u + ((byte2 >> 1) & 3u) : 256u + byte2]; k2 = ent_k(f); q2v = ent_q(f); s2 = ent_s(f); }
                 pos_t ns = do2 ? s2 : s1, nk = do2 ? k2 : k1, nq = do2 ? q2v : q1v;
@@ -1473,8 +1496,8 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
 #define PGX_PAIRS_INSTANTIATE(...)                                                                                                                \
     template __global__ void pgx_find_mems_pairs_kernel<__VA_ARGS__>(PgxDevImage, const uint8_t *, const uint64_t *, uint64_t, uint64_t, uint64_t, const uint64_t *, \
                                                                      pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t, uint32_t, \
-                                                                     uint32_t, pgx_heavy_item *, unsigned long long *, pgx_heavy_item *, unsigned long long *,       \
-                                                                     const uint8_t *, const uint32_t *, uint32_t, uint32_t *, uint64_t);
+                                                                     uint32_t, pgx_heavy_item *, unsigned long long *, const uint8_t *, const uint32_t *, uint32_t,  \
+                                                                     uint32_t *, uint64_t);
 PGX_PAIRS_INSTANTIATE(true, false, false, false, false)
 PGX_PAIRS_INSTANTIATE(true, true, false, false, false)
 PGX_PAIRS_INSTANTIATE(true, false, true, false, false)

@@ -987,7 +987,7 @@ struct pgx_batch {
     uint64_t plan_min_len = 0, plan_budget = 0;
     DevBuf reads, offsets;
     // run state
-    DevBuf slot_off, slots, mem_count, mem_off, mems, scan_tmp, counters, heavy_list, heavy_scratch, redo_list, read_flags, side_list, side_count, packed, ovf_base;
+    DevBuf slot_off, slots, mem_count, mem_off, mems, scan_tmp, counters, heavy_list, heavy_scratch, read_flags, side_list, side_count, packed, ovf_base;
     uint64_t last_ovf_used = 0; // arena slots the last run handed out (sizes the next arena)
     uint64_t max_read_len = 0; // longest read of the upload (sizes the LDS columns of the packed pairs kernel)
     TagWork tw;
@@ -1010,7 +1010,7 @@ static void batch_release(pgx_batch *b) {
     if (!b) return;
     if (hipSetDevice(b->device) == hipSuccess) {
         DevBuf *all[] = {&b->reads, &b->offsets, &b->slot_off, &b->slots, &b->mem_count, &b->mem_off, &b->mems, &b->scan_tmp,
-                         &b->counters, &b->heavy_list, &b->heavy_scratch, &b->redo_list, &b->read_flags, &b->side_list, &b->side_count, &b->packed, &b->ovf_base};
+                         &b->counters, &b->heavy_list, &b->heavy_scratch, &b->read_flags, &b->side_list, &b->side_count, &b->packed, &b->ovf_base};
         for (DevBuf *d : all) d->release();
         b->tw.release();
         HostBuf *hb[] = {&b->h_mem_off, &b->h_mems, &b->h_run_nums, &b->h_pos_off, &b->h_positions};
@@ -1203,7 +1203,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                   : d2   ? (seeded ? (const void *)pgx_find_mems_kernel<false, 2, true, true> : (const void *)pgx_find_mems_kernel<false, 2, true, false>)
                          : (seeded ? (const void *)pgx_find_mems_kernel<false, 1, true, true> : (const void *)pgx_find_mems_kernel<false, 1, true, false>);
         // two extensions per cache line where the index has a PAIRS image (PGX_FM_PAIRS=0: the dense2 kernel alone); the kernel chosen
-        // above then serves the reads the pairs kernel hands on
+        // above then serves the reads the pairs kernel skips (a byte outside A C G T), on the second stream
         const char *pv = std::getenv("PGX_FM_PAIRS");
         // (only behind the seed table: the wide intervals at the start of an unseeded stage always have special positions between their ends)
         if (img.pairs && seeded && !(n >> 32) && b->read_bytes < (1ull << 35) && !(pv && pv[0] == '0'))
@@ -1226,8 +1226,6 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         b->heavy_scratch.ensure((size_t)PGX_FM_HEAVY_GRID * PGX_FM_HEAVY_MAXLEN * sizeof(PgxHeavyResult));
     }
     unsigned long long *d_cursor = d_next + PGX_CTR_CURSOR;
-    unsigned long long *d_redo_count = d_next + PGX_CTR_REDO, *d_redo_cursor = d_next + PGX_CTR_REDO_CURSOR;
-    if (kfn_pairs) b->redo_list.ensure((n ? n : 1) * sizeof(pgx_heavy_item));
     const char *spec_env = std::getenv("PGX_SPEC");
     const bool spec = pass == 0 && chunks.size() == 1 && b->shape_valid && b->shape_reads == n && b->shape_min_len == min_len && b->shape_min_occ == min_occ &&
                       b->shape_tags == want_tags && (!want_tags || (b->tw.have_last && b->tw.last_largest <= PGX_SORT_WG_LDS_CAP)) &&
@@ -1284,7 +1282,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             const pgx_heavy_item *a_rlist = nullptr;
             const unsigned long long *a_rcount = nullptr;
             bool side_running = false;
-            if (kfn_pairs) { // the pairs kernel first; what it hands on (reads that met \n or N in the BWT) goes through the kernel chosen above
+            if (kfn_pairs) { // the pairs kernel; the kernel chosen above serves the reads it skips
                 // reads with a byte outside A C G T cannot be seeded: they go to the dense2 kernel at once, on a second stream next to the pairs
                 // kernel, which skips them (a read cut from an N run is a chain of thousands of extensions: behind the pairs kernel it was 1.5 ms of tail)
                 const uint8_t *a_skip = nullptr;
@@ -1331,8 +1329,6 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                     side_running = true;
                   }
                 }
-                pgx_heavy_item *a_redo = b->redo_list.as<pgx_heavy_item>();
-                unsigned long long *a_redo_n = d_redo_count;
                 // the reads from LDS, two bits per symbol, when every read the launch serves is pure A C G T (the others are skipped) and a
                 // thread's column stays small enough for four workgroups per CU (reads up to ~350 bp); PGX_FM_PACKED=0 switches it off
                 const void *kp = kfn_pairs;
@@ -1365,20 +1361,15 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                     }
                 }
                 void *pargs[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_first, &a_base,
-                                 &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_redo, &a_redo_n, &a_skip, &a_packed, &a_pkw, &a_ovf, &a_ovf_cap};
+                                 &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_skip, &a_packed, &a_pkw, &a_ovf, &a_ovf_cap};
                 HIPCHECK(hipLaunchKernel(kp, dim3(pgrid), dim3(PGX_FM_THREADS), pargs, plds, s));
                 record(b, 8, s);
-                a_rlist = a_redo; a_rcount = d_redo_count; a_cur = d_redo_cursor;
-                // the few reads handed on have the device to themselves: the launch lasts as long as its longest read, and a read that ends a
-                // sequence (the usual reason to be here) runs until the heavy-read threshold: a quarter of it (chr22 scale: 21.2 -> 20.7 ms)
-                uint32_t redo_hext = 512u;
-                if (const char *e = std::getenv("PGX_FM_REDO_HEAVY_EXT")) redo_hext = (uint32_t)std::strtoul(e, nullptr, 10);
-                if (redo_hext && a_hext > redo_hext) a_hext = redo_hext;
+            } else { // (the pairs kernel serves every read of the launch itself: where its image cannot answer, it takes that extension through the other one)
+                void *args[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_first, &a_base,
+                                &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_rlist, &a_rcount, &a_ovf, &a_ovf_cap};
+                HIPCHECK(hipLaunchKernel(kf, dim3(grid), dim3(PGX_FM_THREADS), args, b->dimg->lds_bytes, s)); // one of the variants
+                record(b, 8, s);
             }
-            void *args[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_first, &a_base,
-                            &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_rlist, &a_rcount, &a_ovf, &a_ovf_cap};
-            HIPCHECK(hipLaunchKernel(kf, dim3(grid), dim3(PGX_FM_THREADS), args, b->dimg->lds_bytes, s)); // one of the variants
-            if (!kfn_pairs) record(b, 8, s);
             if (side_running) HIPCHECK(hipStreamWaitEvent(s, b->ev_side[1], 0)); // the other stream's reads are done (they may have queued heavy reads)
             if (heavy_ext) { // the rest of reads that spent heavy_ext extensions (usually none: the launch then costs a few microseconds)
                 if (b->dimg->lds_bytes)
@@ -1404,7 +1395,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             if ((cc[PGX_CTR_OVF32] || forced) && kf != kfn_wide) { kf = kfn_wide; continue; } // a coordinate left 32 bits: repeat the chunk in 64 bits
             n_ext_host += cc[PGX_CTR_EXT];
             b->timing.heavy_reads += (uint32_t)std::min<unsigned long long>(cc[PGX_CTR_HEAVY], PGX_FM_HEAVY_CAP);
-            b->timing.redo_reads += (uint32_t)cc[PGX_CTR_REDO];
+            b->timing.pairs_other_steps += (uint32_t)cc[PGX_CTR_REDO];
             cm = cc[PGX_CTR_MEMS];
             break;
         }
@@ -1457,7 +1448,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         b->n_mems = cnt[PGX_CTR_MEMS];
         n_ext_host = cnt[PGX_CTR_EXT];
         b->timing.heavy_reads = (uint32_t)std::min<unsigned long long>(cnt[PGX_CTR_HEAVY], PGX_FM_HEAVY_CAP);
-        b->timing.redo_reads = (uint32_t)cnt[PGX_CTR_REDO];
+        b->timing.pairs_other_steps = (uint32_t)cnt[PGX_CTR_REDO];
         if (want_tags) {
             TagWork &w = b->tw;
             const unsigned long long *tc = cnt + PGX_CTR_TAG0; // (scalars of tag_pipeline)
@@ -1479,7 +1470,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         std::fprintf(stderr, "[pgx] find_mems wave trips %llu, live lane-trips %llu (%.1f%% of lanes), longest wave %llu trips, extensions %llu\n", cnt[PGX_CTR_ST_TRIPS],
                      cnt[PGX_CTR_ST_LIVE], 100.0 * (double)cnt[PGX_CTR_ST_LIVE] / (64.0 * (double)cnt[PGX_CTR_ST_TRIPS]), cnt[PGX_CTR_ST_LONGEST], cnt[PGX_CTR_EXT]);
     if (cnt[PGX_CTR_ST_PAIR_TRIPS] && std::getenv("PGX_FM_STATS"))
-        std::fprintf(stderr, "[pgx] pairs kernel wave trips %llu, live lane-trips %llu (%.1f%%), with two extensions %llu, waiting for a second block %llu, fresh %llu, reads handed on %llu\n",
+        std::fprintf(stderr, "[pgx] pairs kernel wave trips %llu, live lane-trips %llu (%.1f%%), with two extensions %llu, waiting for a second block %llu, fresh %llu, extensions through the other image %llu\n",
                      cnt[PGX_CTR_ST_PAIR_TRIPS], cnt[PGX_CTR_ST_PAIR_LIVE], 100.0 * (double)cnt[PGX_CTR_ST_PAIR_LIVE] / (64.0 * (double)cnt[PGX_CTR_ST_PAIR_TRIPS]),
                      cnt[PGX_CTR_PAIRS_TWO], cnt[PGX_CTR_ST_PAIR_WAIT], cnt[PGX_CTR_ST_PAIR_FRESH], cnt[PGX_CTR_REDO]);
     if (cnt[PGX_CTR_ST_PAIR_T_TOTAL] && std::getenv("PGX_FM_STATS"))
@@ -1487,7 +1478,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                      100.0 * (double)cnt[PGX_CTR_ST_PAIR_T_REFILL] / (double)cnt[PGX_CTR_ST_PAIR_T_TOTAL], cnt[PGX_CTR_ST_PAIR_T_REFILL], cnt[PGX_CTR_ST_PAIR_T_TOTAL], cnt[PGX_CTR_ST_PAIR_REFILLS],
                      100.0 * (double)cnt[PGX_CTR_ST_PAIR_T_SEED] / (double)cnt[PGX_CTR_ST_PAIR_T_TOTAL], 100.0 * (double)cnt[PGX_CTR_ST_PAIR_T_LINE] / (double)cnt[PGX_CTR_ST_PAIR_T_TOTAL]);
     if (std::getenv("PGX_DEBUG_COUNTERS"))
-        std::fprintf(stderr, "[pgx] counters: extensions %llu tag overflows %llu heavy %llu redo %llu lines %llu + %llu seeds %llu + %llu\n", cnt[PGX_CTR_EXT], cnt[PGX_CTR_TAG_OVERFLOW],
+        std::fprintf(stderr, "[pgx] counters: extensions %llu tag overflows %llu heavy %llu other-image steps %llu lines %llu + %llu seeds %llu + %llu\n", cnt[PGX_CTR_EXT], cnt[PGX_CTR_TAG_OVERFLOW],
                      cnt[PGX_CTR_HEAVY], cnt[PGX_CTR_REDO], cnt[PGX_CTR_PAIRS_LINES], cnt[PGX_CTR_FM_LINES], cnt[PGX_CTR_PAIRS_SEEDS], cnt[PGX_CTR_FM_SEEDS]);
     b->n_ext = n_ext_host;
     b->n_tag_overflow = cnt[PGX_CTR_TAG_OVERFLOW];

@@ -68,7 +68,7 @@ class Timing(C.Structure):
     _fields_ = [
         ("ms_find_mems", C.c_float), ("ms_compact", C.c_float), ("ms_tag_locate", C.c_float),
         ("ms_tag_gather", C.c_float), ("ms_tag_sort", C.c_float), ("ms_total", C.c_float),
-        ("find_mems_launches", u32), ("heavy_reads", u32), ("pairs_reads", u32), ("redo_reads", u32),
+        ("find_mems_launches", u32), ("heavy_reads", u32), ("pairs_reads", u32), ("pairs_other_steps", u32),
         ("ms_find_mems_main", C.c_float), ("seed_depth", u32),
         ("main_lines", u64), ("main_seed_loads", u64), ("other_lines", u64), ("other_seed_loads", u64), ("two_step_trips", u64),
     ]

@@ -26,7 +26,7 @@ def _run(idx, cat, offs, min_len, min_occ):
     b = idx.batch(cat, offs)
     b.run(min_len, min_occ, flags=P.RUN_TAGS | P.RUN_TIMING)
     res, t = b.result(), b.timing()
-    stats = (1 if t.pairs_reads else 0, int(t.redo_reads))  # (pairs_reads also says which variant ran: 1 byte windows, 2 packed reads, 3 cooperative fetches)
+    stats = (1 if t.pairs_reads else 0, int(t.pairs_other_steps))  # (pairs_reads also says which variant ran: 1 byte windows, 2 packed reads, 3 cooperative fetches)
     b.free()
     return res, stats
 
@@ -80,7 +80,7 @@ def test_pairs_kernel_equals_the_oracle(pan, monkeypatch, seed_k, psyms):
             seeded = seed_k != "0" and min_len >= idx_seed_k
             assert used == (1 if seeded else 0)  # the kernel runs behind the seed table only
             if seeded and seed_k is None and min_occ <= 1:  # (a larger min_occ lets fewer seeds apply: unseeded stages start wide and are handed on)
-                assert redo < n_reads // 3, (min_len, redo)  # the two-step path does the work, not the fallback (a small index: ~0.2 % of its blocks are flagged)
+                assert redo < 2 * n_reads, (min_len, redo)  # extensions taken through the dense2 image: the two-step path does the work (of ~200 extensions per read)
         idx.close()
 
 
