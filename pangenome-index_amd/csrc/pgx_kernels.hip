@@ -542,7 +542,7 @@ __device__ __forceinline__ uint64_t pgx_slot_index(uint64_t read_in_chunk, uint6
 // min(len, len - min_len + 1), 131 slots per 150-bp read -- 42 GB for 10 M reads that write 0.6 GB.  ARENA (round 3): a read reserves its extent when it
 // emits its fifth MEM (2 % of the reads do) -- as many slots as it has start positions left, which bounds what it can still emit -- with one atomic,
 // and records it in ovf_base[rid] for its later MEMs, the kernels that continue the read, and the compaction.  The arena is PGX_ARENA_SUBS sub-arenas,
-// one per residue of the workgroup number, each with a counter on a cache line of its own (ctr + PGX_CTR_ARENA0 + 16 sub): one counter for everybody
+// one per residue of the read number, each with a counter on a cache line of its own (ctr + PGX_CTR_ARENA0 + 16 sub): one counter for everybody
 // serialised 48 k atomics into 0.7 ms on the x fixture (a 0.6 ms kernel).  A sub-arena that proves too small raises PGX_CTR_OVF_ABORT (the writes
 // then land at its start, in bounds) and the host repeats the chunk in the worst-case layout.
 __device__ __forceinline__ uint64_t pgx_slot_extent(const uint64_t *__restrict__ slot_off, uint64_t slot_base, uint32_t *__restrict__ ovf_base, uint64_t ovf_cap,
@@ -552,7 +552,9 @@ __device__ __forceinline__ uint64_t pgx_slot_extent(const uint64_t *__restrict__
         const int64_t ml = min_len ? (int64_t)min_len : 1;
         const int64_t left = (int64_t)len - ml - (int64_t)x + 1; // start positions from x on (x itself has just produced a MEM)
         const unsigned long long ext = left > 0 ? (unsigned long long)left : 1ull;
-        const uint32_t sub = blockIdx.x & (PGX_ARENA_SUBS - 1u);
+        // (by read id, not by workgroup: what a sub-arena is asked for then does not depend on which workgroup took which reads, so a run sized from
+        //  the one before fits -- reads that need many slots come in clusters, e.g. the reads cut from an N run, and landed in a few sub-arenas)
+        const uint32_t sub = (uint32_t)rid & (PGX_ARENA_SUBS - 1u);
         const uint64_t sub_cap = ovf_cap / PGX_ARENA_SUBS;
         unsigned long long at = atomicAdd(ctr + PGX_CTR_ARENA0 + 16u * sub, ext);
         if (at + ext > sub_cap) { ctr[PGX_CTR_OVF_ABORT] = 1ull; at = 0ull; }
@@ -1775,6 +1777,98 @@ pgx_scan_apply_kernel(int mode, const void *in, uint64_t n_cap, uint64_t min_len
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         out[n] = grand;
         if (total_out) *total_out = grand; // a second copy next to other scalars the host reads back together
+    }
+}
+
+// The same scan in ONE launch (decoupled look-back): tiles of 4096 items take their numbers from a counter in the order they start, publish their
+// total, look back over the tiles before them until one has published its inclusive prefix, and publish their own.  A tile word is
+// epoch (18 bits) | state (2: 1 = total, 2 = inclusive prefix) | value (44 bits) in one 64-bit store, so a word of an earlier scan over the same
+// buffer reads as "nothing yet" and nothing has to be cleared between scans.  Loads and stores are coalesced (a wave scans 64 consecutive items per
+// round with lane shifts, sixteen rounds), which the three-launch form above was not: 10 M counts take 177 us there.
+// state[0]: tile counter (the last tile sets it back to 0), state[1 + t]: word of tile t.
+#define PGX_SCAN1_ROUNDS 16
+__global__ void __launch_bounds__(256)
+pgx_scan_onepass_kernel(int mode, const void *in, uint64_t n_cap, uint64_t min_len, uint64_t *__restrict__ out, uint64_t *__restrict__ total_out,
+                        const uint64_t *__restrict__ n_dev, unsigned long long *__restrict__ state, uint32_t epoch) {
+    __shared__ uint64_t s_wave[4];
+    __shared__ uint64_t s_prefix;
+    __shared__ uint32_t s_tile;
+    const uint64_t n = n_dev ? (*n_dev < n_cap ? *n_dev : n_cap) : n_cap;
+    if (threadIdx.x == 0) s_tile = atomicAdd(reinterpret_cast<uint32_t *>(state), 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t b0 = (uint64_t)tile * (256u * PGX_SCAN1_ROUNDS) + (uint64_t)w * (64u * PGX_SCAN1_ROUNDS);
+    uint64_t x[PGX_SCAN1_ROUNDS], carry = 0;
+#pragma unroll
+    for (int r = 0; r < PGX_SCAN1_ROUNDS; r++) {
+        const uint64_t i = b0 + (uint64_t)(r * 64 + lane);
+        const uint64_t v = i < n ? pgx_scan_load(mode, in, i, min_len) : 0;
+        uint64_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint64_t t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        x[r] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) s_wave[w] = carry;
+    __syncthreads();
+    uint64_t wbase = 0, tile_total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { if (i < w) wbase += s_wave[i]; tile_total += s_wave[i]; }
+    const unsigned long long ep = (unsigned long long)(epoch & 0x3FFFFu) << 46;
+    const unsigned long long vmask = (1ull << 44) - 1ull;
+    if (w == 0) {
+        uint64_t prefix = 0;
+        if (tile != 0) {
+            if (lane == 0) __hip_atomic_store(state + 1 + tile, ep | (1ull << 44) | (tile_total & vmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t j = (int64_t)tile - 1;
+            for (;;) { // 64 predecessors at a time, nearest first (lane 0 = tile j)
+                const int64_t idx = j - lane;
+                unsigned long long word = ep | (2ull << 44); // (before tile 0: an inclusive prefix of 0)
+                if (idx >= 0) word = __hip_atomic_load(state + 1 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t st = (word >> 46) == (ep >> 46) ? (uint32_t)(word >> 44) & 3u : 0u;
+                const unsigned long long ready = __ballot(st != 0u), full = __ballot(st == 2u);
+                // the run of published words that starts at lane 0 and ends at the first inclusive prefix (or at lane 63)
+                const unsigned long long gap = ~ready;
+                const int stop_gap = gap ? (int)__ffsll((long long)gap) - 1 : 64, stop_full = full ? (int)__ffsll((long long)full) - 1 : 64;
+                if (stop_full < stop_gap) { // an inclusive prefix before any unpublished tile: sum up to it and stop
+                    uint64_t v = lane <= stop_full ? (uint64_t)(word & vmask) : 0;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                    prefix += __shfl(v, 0, 64);
+                    break;
+                }
+                if (stop_gap == 64) { // 64 totals, no prefix among them: take them all and look further back
+                    uint64_t v = (uint64_t)(word & vmask);
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                    prefix += __shfl(v, 0, 64);
+                    j -= 64;
+                    continue;
+                }
+                __builtin_amdgcn_s_sleep(2); // a tile in the window has not published yet
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(state + 1 + tile, ep | (2ull << 44) | ((prefix + tile_total) & vmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_prefix = prefix;
+        }
+    }
+    __syncthreads();
+    const uint64_t P = s_prefix + wbase;
+#pragma unroll
+    for (int r = 0; r < PGX_SCAN1_ROUNDS; r++) {
+        const uint64_t i = b0 + (uint64_t)(r * 64 + lane);
+        if (i < n) out[i] = P + x[r];
+    }
+    if (tile == gridDim.x - 1 && threadIdx.x == 0) { // (every tile has its number by now)
+        const uint64_t grand = s_prefix + tile_total;
+        out[n] = grand;
+        if (total_out) *total_out = grand;
+        __hip_atomic_store(reinterpret_cast<uint32_t *>(state), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

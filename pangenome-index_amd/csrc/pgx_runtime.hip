@@ -324,8 +324,25 @@ static void scan_excl(int mode, const void *in, uint64_t n, uint64_t min_len, ui
         if (total_out) HIPCHECK(hipMemsetAsync(total_out, 0, 8, s));
         return;
     }
+    // one launch (decoupled look-back, pgx_scan_onepass_kernel); the tile words carry an epoch, so the buffer is cleared only when it is new or
+    // the 18-bit epoch comes round.  PGX_SCAN_THREE=1: the three-launch form (partial sums, their scan, apply)
+    static const bool three = [] { const char *e = std::getenv("PGX_SCAN_THREE"); return e && e[0] == '1'; }();
+    if (!three) {
+        const uint64_t nt = (n + PGX_SCAN1_TILE_ITEMS - 1) / PGX_SCAN1_TILE_ITEMS;
+        tmp.ensure((nt + 2) * 8);
+        if (tmp.scan_epoch == 0 || tmp.scan_epoch >= 0x3FFFFu) {
+            HIPCHECK(hipMemsetAsync(tmp.p, 0, tmp.cap, s));
+            tmp.scan_epoch = 0;
+        }
+        tmp.scan_epoch++;
+        hipLaunchKernelGGL(pgx_scan_onepass_kernel, dim3((unsigned)nt), dim3(256), 0, s, mode, in, n, min_len, out, total_out, n_dev, tmp.as<unsigned long long>(),
+                           tmp.scan_epoch);
+        HIPCHECK(hipGetLastError());
+        return;
+    }
     const uint64_t nb = (n + PGX_SCAN_BLOCK_ITEMS - 1) / PGX_SCAN_BLOCK_ITEMS;
     tmp.ensure((nb + 1) * 8);
+    tmp.scan_epoch = 0; // (the tile words are overwritten)
     uint64_t *sums = tmp.as<uint64_t>();
     hipLaunchKernelGGL(pgx_scan_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, mode, in, n, min_len, sums, n_dev);
     const int raw = nb <= 2048; // up to 4 M items: no separate scan of the block totals
@@ -1297,6 +1314,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                         b->side_list.ensure((cn ? cn : 1) * sizeof(pgx_heavy_item));
                         b->side_count.ensure(16);
                         b->scan_tmp.ensure(cap * 8);
+                        b->scan_tmp.scan_epoch = 0; // (the list overwrites the scans' tile words: the next scan clears the buffer)
                         b->packed.ensure(((b->read_bytes + 15) / 16 + 64) * 4); // the reads as two bits per symbol (written by the same pass)
                         HIPCHECK(hipMemsetAsync(b->side_count.p, 0, 16, s));
                         HIPCHECK(hipMemsetAsync(b->read_flags.p, 0, ((cn + 3) & ~3ull) + 4, s));

@@ -29,8 +29,10 @@ using pgx::Error;
 struct DevBuf { // grow-only device buffer
     void *p = nullptr;
     size_t cap = 0;
+    uint32_t scan_epoch = 0; // pgx_scan_onepass_kernel's tile words in this buffer: epoch of the last scan; 0 = the memory has not been cleared yet
     void ensure(size_t bytes) {
         if (bytes <= cap) return;
+        scan_epoch = 0;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
