@@ -184,10 +184,10 @@ __device__ __forceinline__ void pgx_dense2_counts(const PgxDevImage &img, const 
 // count before p0).  NARROW: modulo 2^32 (like pgx_dense_pair32); otherwise modulo 2^64 from the exact 32-bit counts.
 template <bool NARROW>
 __device__ __forceinline__ void pgx_dense2_pair(const PgxDevImage &img, uint32_t p0, uint32_t p1, uint32_t cv, uint32_t mrow, uint64_t &A0, uint64_t &A1,
-                                                uint64_t &dB) {
+                                                uint64_t &dB, bool lower = true) {
     uint32_t r0, r1;
     const PgxDense2Blk k0 = pgx_dense2_load(img, p0, r0), k1 = pgx_dense2_load(img, p1, r1);
-    __builtin_amdgcn_s_setprio(0); // (the find_mems kernels raise their priority on the way to the loads: see pgx_find_mems_pairs_kernel)
+    if (lower) __builtin_amdgcn_s_setprio(0); // (the find_mems kernels raise their priority on the way to the loads: see pgx_find_mems_pairs_kernel)
     uint32_t c0[6], c1[6];
     pgx_dense2_counts(img, k0, p0, r0, c0);
     pgx_dense2_counts(img, k1, p1, r1, c1);
@@ -244,10 +244,10 @@ __device__ __forceinline__ void pgx_dense2w_counts(const PgxDevImage &img, const
     c[5] = base[3] + d[5];
 }
 __device__ __forceinline__ void pgx_dense2w_pair(const PgxDevImage &img, const uint64_t *__restrict__ sb, uint64_t p0, uint64_t p1, uint32_t cv, uint32_t mrow,
-                                                 uint64_t &A0, uint64_t &A1, uint64_t &dB) {
+                                                 uint64_t &A0, uint64_t &A1, uint64_t &dB, bool lower = true) {
     uint32_t r0, r1, b0, b1;
     const PgxDense2Blk k0 = pgx_dense2w_load(img, p0, r0, b0), k1 = pgx_dense2w_load(img, p1, r1, b1);
-    __builtin_amdgcn_s_setprio(0);
+    if (lower) __builtin_amdgcn_s_setprio(0);
     uint64_t c0[6], c1[6];
     pgx_dense2w_counts(img, sb, k0, p0, r0, b0, c0);
     pgx_dense2w_counts(img, sb, k1, p1, r1, b1, c1);
@@ -676,7 +676,10 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
     };
 
     for (;;) {
-        if (DENSE >= 2) __builtin_amdgcn_s_setprio(3); // up until the probes' loads are out (pgx_dense2_pair lowers it again): see pgx_find_mems_pairs_kernel
+        // up until the probes' loads are out (pgx_dense2_pair lowers it again): see pgx_find_mems_pairs_kernel.  A launch that serves a list of reads (the
+        // reads with a byte outside A C G T, on the second stream next to the pairs kernel: few, each a long chain) stays up: it is one wave per SIMD among
+        // the other kernel's five, and at equal terms it took 5 to 19 ms from run to run -- longer than the pairs kernel it is meant to hide behind
+        if (DENSE >= 2) __builtin_amdgcn_s_setprio(3);
         // ---- refill idle lanes ----
         unsigned long long idle = __ballot(ph == 0);
         while (idle) {
@@ -783,7 +786,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                 // wide dense2: the same probes with 64-bit positions and superblock bases from LDS
                 const uint64_t p0 = kk > n ? n : kk, p1 = (kk + s) > n ? n : (kk + s);
                 uint64_t q0, q1, dq;
-                pgx_dense2w_pair(img, s_sb, p0, p1, cv, mrow, q0, q1, dq);
+                pgx_dense2w_pair(img, s_sb, p0, p1, cv, mrow, q0, q1, dq, !rid_list);
                 A0 = (pos_t)q0; A1 = (pos_t)q1; dB = (pos_t)dq;
                 fin = true;
                 c_blk = s != n;
@@ -795,10 +798,10 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
                     const uint32_t ks = (uint32_t)kk + (uint32_t)s;
                     ovf |= ks < (uint32_t)kk;
                     const uint32_t p0 = (uint32_t)kk > (uint32_t)n ? (uint32_t)n : (uint32_t)kk, p1 = ks > (uint32_t)n ? (uint32_t)n : ks;
-                    pgx_dense2_pair<true>(img, p0, p1, cv, mrow, q0, q1, dq);
+                    pgx_dense2_pair<true>(img, p0, p1, cv, mrow, q0, q1, dq, !rid_list);
                 } else {
                     const uint64_t p0 = kk > n ? n : kk, p1 = (kk + s) > n ? n : (kk + s); // (kk + s wraps only from junk coordinates: either way >= n or tiny)
-                    pgx_dense2_pair<false>(img, (uint32_t)p0, (uint32_t)p1, cv, mrow, q0, q1, dq);
+                    pgx_dense2_pair<false>(img, (uint32_t)p0, (uint32_t)p1, cv, mrow, q0, q1, dq, !rid_list);
                 }
                 A0 = (pos_t)q0; A1 = (pos_t)q1; dB = (pos_t)dq;
                 fin = true;
