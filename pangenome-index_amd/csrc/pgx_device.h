@@ -41,6 +41,7 @@ enum PgxCounterSlot {
 };
 #define PGX_ARENA_SUBS 64u
 __global__ void pgx_arena_demand_kernel(unsigned long long *ctr);
+#define PGX_TBUCKET_RUNS 10u // run starts a bucket line holds (pgx_tag_bucket_kernel); a bucket with more is flagged and answered through tdir / tpair
 
 #define PGX_DENSE_LDS_U4 5 // uint4 slots per dense block in LDS (64 data bytes + 16 of padding)
 #define PGX_FM_THREADS 256
@@ -56,6 +57,9 @@ struct PgxDevImage {
     const uint64_t *tvals;    // n_tag_items
     const uint32_t *tdir;     // tag_dir_entries
     const ulonglong2 *tpair;  // (tstart[r], tvals[r]) side by side, max(n_tag_runs, n_tag_items) entries (NULL: not built)
+    const uint4 *tbucket;     // tag runs by bucket of 2^tbucket_shift BWT positions, one 128-byte line each (pgx_tag_kernels.hip; NULL: not built)
+    uint64_t n_tbuckets;
+    uint32_t tbucket_shift;
     uint64_t n;
     uint64_t dir_entries;
     uint64_t n_tag_runs, n_tag_items, tag_dir_entries;
@@ -149,6 +153,7 @@ __global__ void pgx_compact_mems_kernel(uint64_t first_read, uint64_t n_reads, c
                                         const pgx_mem *slots, const uint32_t *mem_count, const uint64_t *local_off,
                                         uint64_t mem_base, pgx_mem *mems, uint64_t cap_mems, uint64_t *abort, const uint32_t *ovf_base, uint64_t ovf_cap);
 __global__ void pgx_tag_pair_kernel(const uint64_t *tstart, const uint64_t *tvals, uint64_t n_runs, uint64_t n_items, ulonglong2 *out);
+__global__ void pgx_tag_bucket_kernel(const uint64_t *tstart, const uint64_t *tvals, uint64_t n_runs, uint64_t n_items, uint32_t shift, uint64_t n_buckets, uint4 *out);
 #define PGX_TAG_LOCATE_THREADS 1024 // workgroup of pgx_tag_locate_kernel (one list atomic per workgroup)
 #define PGX_SORT_LDS_CAP 2048 // values per wave sorted in an LDS slice (pgx_tag_sort_unique_kernel)
 #define PGX_TAG_SMALL 16      // queries with at most this many runs take the 16-lane path

@@ -82,7 +82,7 @@ static void use_device(int device) {
 struct pgx_device_image {
     int device = -1;
     PgxDevImage img{};
-    DevBuf blocks, dir, blow, consts, tstart, tvals, tdir, tpair, seed, seed_small, seed_end, exc, pairs, first_ext, sbase2, pbase;
+    DevBuf blocks, dir, blow, consts, tstart, tvals, tdir, tpair, tbucket, seed, seed_small, seed_end, exc, pairs, first_ext, sbase2, pbase;
     DevBuf rstart, rsamp, rdir, lpos, lnext, ldir; // locate image, uploaded on first use
     DevBuf lit_bstart, lit_cum, lit_runs, lit_roff, lit_tabs; // literal count image (quirk 3), uploaded on first use
     PgxLitImage lit{};
@@ -97,7 +97,7 @@ void pgx_release_device_images(pgx_index *h) {
         if (!d) continue;
         if (hipSetDevice(d->device) == hipSuccess) {
             d->blocks.release(); d->dir.release(); d->blow.release(); d->consts.release();
-            d->tstart.release(); d->tvals.release(); d->tdir.release(); d->tpair.release(); d->seed.release(); d->seed_small.release(); d->seed_end.release(); d->exc.release(); d->pairs.release(); d->first_ext.release(); d->sbase2.release(); d->pbase.release();
+            d->tstart.release(); d->tvals.release(); d->tdir.release(); d->tpair.release(); d->tbucket.release(); d->seed.release(); d->seed_small.release(); d->seed_end.release(); d->exc.release(); d->pairs.release(); d->first_ext.release(); d->sbase2.release(); d->pbase.release();
             d->lit_bstart.release(); d->lit_cum.release(); d->lit_runs.release(); d->lit_roff.release(); d->lit_tabs.release();
             d->rstart.release(); d->rsamp.release(); d->rdir.release(); d->lpos.release(); d->lnext.release(); d->ldir.release();
         }
@@ -200,6 +200,21 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipDeviceSynchronize());
         g.tpair = d->tpair.as<ulonglong2>();
+    }
+    g.tbucket = nullptr; g.n_tbuckets = 0; g.tbucket_shift = 0;
+    if (!m.tstart.empty() && !m.tvals.empty() && !std::getenv("PGX_NO_TBUCKET")) { // tag runs by bucket, one line each (pgx_tag_bucket_kernel): about four runs per bucket
+        const uint64_t nr = m.tstart.size(), span = m.tstart.back() + 1;
+        uint32_t sh = 0;
+        while (sh < 16 && (span >> (sh + 1)) >= nr / 4 + 1) sh++;
+        const uint64_t nbk = (span >> sh) + 1;
+        if (nbk * 128 <= (16ull << 30)) {
+            d->tbucket.ensure(nbk * 128);
+            hipLaunchKernelGGL(pgx_tag_bucket_kernel, dim3((unsigned)std::min<uint64_t>((nbk + 255) / 256, 1u << 20)), dim3(256), 0, nullptr, d->tstart.as<uint64_t>(),
+                               d->tvals.as<uint64_t>(), nr, (uint64_t)m.tvals.size(), sh, nbk, d->tbucket.as<uint4>());
+            HIPCHECK(hipGetLastError());
+            HIPCHECK(hipDeviceSynchronize());
+            g.tbucket = d->tbucket.as<uint4>(); g.n_tbuckets = nbk; g.tbucket_shift = sh;
+        }
     }
     g.n = m.consts.n;
     g.dir_entries = m.consts.dir_entries;

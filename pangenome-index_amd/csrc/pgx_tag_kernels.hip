@@ -33,6 +33,60 @@ __device__ __forceinline__ uint64_t pgx_tag_rank(const PgxDevImage &img, uint64_
     return lo;
 }
 
+// Tag runs by bucket (round 3): the locate kernel is two to three dependent random lines per MEM through tdir and tpair (directory entry, the pair the
+// search ends at, sometimes a neighbour) -- 1.24 ms for 18.8 M MEMs at chr22 scale, at the rate random lines reach.  A bucket is the 2^shift BWT positions
+// [b << shift, (b + 1) << shift) and ONE 128-byte line:
+//   dw 0        R0 = number of run starts below the bucket
+//   dw 1        c = run starts inside it (bits 0..7; 255: more than PGX_TBUCKET_RUNS, the line holds nothing else)
+//   dw 2..6     the c starts as 16-bit offsets into the bucket, ascending
+//   dw 8..31    the values of items R0 - 1 .. R0 + c (u64 each; 0 where there is no such item): whichever item a one-run query reads (f - 1, or f
+//               itself where f % 10 == 0) is in the line
+// so a MEM whose interval stays inside one bucket (nearly all: shift is chosen for ~4 runs per bucket) costs one line.
+__global__ void __launch_bounds__(256)
+pgx_tag_bucket_kernel(const uint64_t *__restrict__ tstart, const uint64_t *__restrict__ tvals, uint64_t n_runs, uint64_t n_items, uint32_t shift,
+                      uint64_t n_buckets, uint4 *__restrict__ out) {
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets; b += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p0 = b << shift, p1 = (b + 1) << shift;
+        uint64_t lo = 0, hi = n_runs;
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (tstart[mid] < p0) lo = mid + 1; else hi = mid; }
+        const uint64_t r0 = lo;
+        hi = n_runs;
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (tstart[mid] < p1) lo = mid + 1; else hi = mid; }
+        const uint64_t c = lo - r0;
+        uint32_t dw[32];
+#pragma unroll
+        for (int i = 0; i < 32; i++) dw[i] = 0u;
+        dw[0] = (uint32_t)r0;
+        if (c > PGX_TBUCKET_RUNS) dw[1] = 255u;
+        else {
+            dw[1] = (uint32_t)c;
+#pragma unroll
+            for (uint32_t i = 0; i < PGX_TBUCKET_RUNS; i++)
+                if (i < c) dw[2 + (i >> 1)] |= (uint32_t)(tstart[r0 + i] - p0) << (16u * (i & 1u));
+#pragma unroll
+            for (uint32_t i = 0; i < PGX_TBUCKET_RUNS + 2u; i++) {
+                const uint64_t it = r0 + i; // item it - 1
+                const uint64_t v = (i <= c + 1 && it >= 1 && it - 1 < n_items) ? tvals[it - 1] : 0ull;
+                dw[8 + 2 * i] = (uint32_t)v; dw[9 + 2 * i] = (uint32_t)(v >> 32);
+            }
+        }
+        uint4 *o = out + b * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o[i] = make_uint4(dw[4 * i], dw[4 * i + 1], dw[4 * i + 2], dw[4 * i + 3]);
+    }
+}
+// number of the bucket's run starts <= off (the 16-bit offsets of dw 2..6)
+__device__ __forceinline__ uint32_t pgx_tbucket_le(const uint4 &h0, const uint4 &h1, uint32_t c, uint32_t off) {
+    const uint32_t w[5] = {h0.z, h0.w, h1.x, h1.y, h1.z};
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < PGX_TBUCKET_RUNS; i++) {
+        const uint32_t s = (w[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu;
+        k += (i < c && s <= off) ? 1u : 0u;
+    }
+    return k;
+}
+
 // per query: run_nums (number_of_runs, :860) and the index of the first item read (:862-874,
 // including the off-by-one when first_bit_index % 10 == 0)
 // Counts that live on the device: every kernel of the tag stage takes its element count as a value (an upper bound: the
@@ -62,9 +116,39 @@ pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *__restrict__ mems, const u
         uint64_t st, en;
         if (mems) { st = mems[i].bwt_start; en = st + (uint64_t)mems[i].size - 1; } // find_mems.cpp:129
         else { st = qstart[i]; en = qend[i]; }
-        const uint64_t f = pgx_tag_rank(img, st);
+        // through the bucket of `st` where there is one (and it is not flagged): f, usually g, and a one-run query's value from a single line
+        bool done = false;
+        uint64_t f = 0, g = 0, bval = 0;
+        bool bval_ok = false;
+        if (img.tbucket && en >= st && (st >> img.tbucket_shift) < img.n_tbuckets) {
+            const uint32_t sh = img.tbucket_shift, msk = (1u << sh) - 1u;
+            const uint64_t b0 = st >> sh, b1 = en >> sh;
+            const uint4 *bp = img.tbucket + b0 * 8;
+            const uint4 h0 = bp[0], h1 = bp[1];
+            const uint32_t c0 = h0.y & 0xFFu;
+            if (c0 != 255u) {
+                f = (uint64_t)h0.x + pgx_tbucket_le(h0, h1, c0, (uint32_t)st & msk);
+                if (b1 == b0) { g = (uint64_t)h0.x + pgx_tbucket_le(h0, h1, c0, (uint32_t)en & msk); done = true; }
+                else if (b1 < img.n_tbuckets) {
+                    const uint4 *ep = img.tbucket + b1 * 8;
+                    const uint4 e0 = ep[0], e1 = ep[1];
+                    const uint32_t c1 = e0.y & 0xFFu;
+                    if (c1 != 255u) { g = (uint64_t)e0.x + pgx_tbucket_le(e0, e1, c1, (uint32_t)en & msk); done = true; }
+                }
+                if (done && g == f) { // one run: its item's value is in the line of b0 (items R0 - 1 .. R0 + c)
+                    const uint64_t fi0 = (f % 10) ? f - 1 : f;
+                    const uint32_t slot = (uint32_t)(fi0 + 1 - (uint64_t)h0.x); // 0 .. c + 1
+                    const uint2 *vp = reinterpret_cast<const uint2 *>(bp) + 4 + slot;
+                    const uint2 vv = *vp;
+                    bval = (uint64_t)vv.x | ((uint64_t)vv.y << 32);
+                    bval_ok = true;
+                }
+            }
+        }
+        if (!done) {
+        f = pgx_tag_rank(img, st);
         // rank of `en`: an interval usually ends inside the run it starts in, so gallop upwards from f (one load when it does)
-        uint64_t g = f;
+        g = f;
         if (en >= st) {
             const uint64_t nr = img.n_tag_runs;
             uint64_t step = 1, lo = f, hi = f;
@@ -75,13 +159,14 @@ pgx_tag_locate_kernel(PgxDevImage img, const pgx_mem *__restrict__ mems, const u
             }
             g = lo;
         } else g = pgx_tag_rank(img, en);
+        }
         cnt = g - f + 1;
         run_nums[i] = cnt;
         const uint64_t fi = (f % 10) ? f - 1 : f;
         first_item[i] = fi;
         if (cnt == 1) { // one run = one position: the common case (a MEM inside one node); no segment, no sort
             uint64_t v = 0;
-            if (fi < img.n_tag_items) v = img.tpair ? img.tpair[fi].y : img.tvals[fi];
+            if (fi < img.n_tag_items) v = bval_ok ? bval : (img.tpair ? img.tpair[fi].y : img.tvals[fi]);
             else atomicAdd(n_overflow, 1ull); // the reference reads past the stored runs (UB there): value 0
             single[i] = v;
             ucount[i] = 1;
