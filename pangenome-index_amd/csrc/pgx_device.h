@@ -13,7 +13,6 @@ enum PgxCounterSlot {
     PGX_CTR_EXT = 0,          // extensions performed (equal to the oracle's count)
     PGX_CTR_TAG_OVERFLOW = 1, // tag queries that read past the stored runs (quirk 7)
     PGX_CTR_CURSOR = 5,       // read cursor of the main launch
-    PGX_CTR_HEAVY_SIDE = 6,   // reads the side-stream launch handed to pgx_find_mems_heavy_kernel (a list and a launch of their own, on that stream)
     PGX_CTR_HEAVY = 8,        // reads handed to pgx_find_mems_heavy_kernel
     PGX_CTR_OVF32 = 9,        // a coordinate left 32 bits (NARROW kernels): the chunk is repeated in 64 bits
     PGX_CTR_MEMS = 10,        // MEMs of the chunk (scan total)

@@ -1254,8 +1254,8 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     if (const char *e = std::getenv("PGX_FM_HEAVY_EXT")) heavy_ext = (uint32_t)std::strtoul(e, nullptr, 10);
     unsigned long long *d_heavy_count = d_next + PGX_CTR_HEAVY;
     if (heavy_ext) {
-        b->heavy_list.ensure(2 * (size_t)PGX_FM_HEAVY_CAP * sizeof(pgx_heavy_item)); // (second half: the side-stream launch's list)
-        b->heavy_scratch.ensure(2 * (size_t)PGX_FM_HEAVY_GRID * PGX_FM_HEAVY_MAXLEN * sizeof(PgxHeavyResult)); // (second half: the side stream's launch)
+        b->heavy_list.ensure((size_t)PGX_FM_HEAVY_CAP * sizeof(pgx_heavy_item));
+        b->heavy_scratch.ensure((size_t)PGX_FM_HEAVY_GRID * PGX_FM_HEAVY_MAXLEN * sizeof(PgxHeavyResult));
     }
     unsigned long long *d_cursor = d_next + PGX_CTR_CURSOR;
     const char *spec_env = std::getenv("PGX_SPEC");
@@ -1355,23 +1355,9 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                     const pgx_heavy_item *s_list = b->side_list.as<pgx_heavy_item>();
                     const unsigned long long *s_count = b->side_count.as<unsigned long long>();
                     unsigned long long *s_cur = d_next + PGX_CTR_SIDE_CURSOR;
-                    // heavy reads of this launch (reads cut from an N run are) go to a list of their own, and the kernel that finishes them runs on this
-                    // stream too, next to the pairs kernel instead of behind it (0.19 ms per step at chr22 scale)
-                    pgx_heavy_item *s_hlist = b->heavy_list.as<pgx_heavy_item>() + PGX_FM_HEAVY_CAP;
-                    unsigned long long *s_hcount = d_next + PGX_CTR_HEAVY_SIDE;
                     void *sargs[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &s_cur, &a_first, &a_base,
-                                     &a_hext, &a_hcap, &s_hlist, &s_hcount, &s_list, &s_count, &a_ovf, &a_ovf_cap};
+                                     &a_hext, &a_hcap, &a_hlist, &a_hcount, &s_list, &s_count, &a_ovf, &a_ovf_cap};
                     HIPCHECK(hipLaunchKernel(kf, dim3(std::min<unsigned>(grid, (unsigned)cus)), dim3(PGX_FM_THREADS), sargs, b->dimg->lds_bytes, b->side));
-                    if (heavy_ext) {
-                        if (b->dimg->lds_bytes)
-                            hipLaunchKernelGGL(pgx_find_mems_heavy_kernel<true>, dim3(PGX_FM_HEAVY_GRID), dim3(256), b->dimg->lds_bytes, b->side, img, a_reads, a_off,
-                                               min_len, min_occ, a_slot_off, c.slot_base, a_slots, a_cnt, d_next, (const pgx_heavy_item *)s_hlist,
-                                               (const unsigned long long *)s_hcount, (uint32_t)PGX_FM_HEAVY_CAP, b->heavy_scratch.as<PgxHeavyResult>() + (size_t)PGX_FM_HEAVY_GRID * PGX_FM_HEAVY_MAXLEN, c.r0, cn, a_ovf, a_ovf_cap);
-                        else
-                            hipLaunchKernelGGL(pgx_find_mems_heavy_kernel<false>, dim3(PGX_FM_HEAVY_GRID), dim3(256), 0, b->side, img, a_reads, a_off, min_len, min_occ,
-                                               a_slot_off, c.slot_base, a_slots, a_cnt, d_next, (const pgx_heavy_item *)s_hlist,
-                                               (const unsigned long long *)s_hcount, (uint32_t)PGX_FM_HEAVY_CAP, b->heavy_scratch.as<PgxHeavyResult>() + (size_t)PGX_FM_HEAVY_GRID * PGX_FM_HEAVY_MAXLEN, c.r0, cn, a_ovf, a_ovf_cap);
-                    }
                     HIPCHECK(hipEventRecord(b->ev_side[1], b->side));
                     side_running = true;
                   }
@@ -1441,7 +1427,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             const bool forced = attempt == 0 && kf != kfn_wide && std::getenv("PGX_FM_NARROW_FORCE_REDO") != nullptr; // tests
             if ((cc[PGX_CTR_OVF32] || forced) && kf != kfn_wide) { kf = kfn_wide; continue; } // a coordinate left 32 bits: repeat the chunk in 64 bits
             n_ext_host += cc[PGX_CTR_EXT];
-            b->timing.heavy_reads += (uint32_t)std::min<unsigned long long>(cc[PGX_CTR_HEAVY], PGX_FM_HEAVY_CAP) + (uint32_t)std::min<unsigned long long>(cc[PGX_CTR_HEAVY_SIDE], PGX_FM_HEAVY_CAP);
+            b->timing.heavy_reads += (uint32_t)std::min<unsigned long long>(cc[PGX_CTR_HEAVY], PGX_FM_HEAVY_CAP);
             b->timing.pairs_other_steps += (uint32_t)cc[PGX_CTR_REDO];
             cm = cc[PGX_CTR_MEMS];
             break;
@@ -1494,7 +1480,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         b->last_ovf_used = cnt[PGX_CTR_OVF_TOP];
         b->n_mems = cnt[PGX_CTR_MEMS];
         n_ext_host = cnt[PGX_CTR_EXT];
-        b->timing.heavy_reads = (uint32_t)std::min<unsigned long long>(cnt[PGX_CTR_HEAVY], PGX_FM_HEAVY_CAP) + (uint32_t)std::min<unsigned long long>(cnt[PGX_CTR_HEAVY_SIDE], PGX_FM_HEAVY_CAP);
+        b->timing.heavy_reads = (uint32_t)std::min<unsigned long long>(cnt[PGX_CTR_HEAVY], PGX_FM_HEAVY_CAP);
         b->timing.pairs_other_steps = (uint32_t)cnt[PGX_CTR_REDO];
         if (want_tags) {
             TagWork &w = b->tw;
