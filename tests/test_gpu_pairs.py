@@ -151,6 +151,28 @@ def test_pairs_kernel_empty_and_tiny_batches(pan):
     idx.close()
 
 
+@pytest.mark.parametrize("read_len,variant", [(250, 2), (353, 2), (354, 1), (600, 1), (1000, 1)])
+def test_pairs_kernel_read_lengths(pan, read_len, variant):
+    """read lengths around the limit of the packed-reads form (24 words of LDS per lane with one of padding: up to 353 symbols at the worst phase) and beyond it, where the
+    kernel reads 16-byte windows of the read bytes instead; some reads with N, reads that end a sequence"""
+    ri_path, tags_path, _, _ = pan
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    seqs = W.load_sequences(os.path.join(os.path.dirname(ri_path), "pairpan.txt"))
+    cat, offs = W.sample_reads(seqs, 3000, read_len, seed=1000 + read_len)
+    extra = [bytes(s[-read_len:]) for s in seqs[:2]] + [bytes(s[:read_len]) for s in seqs[:2]] + [b"ACGT" * (read_len // 4), bytes(seqs[0][:read_len - 1])]
+    ecat, eoffs = O.pack_reads(extra)
+    cat = np.concatenate([cat, ecat]); offs = np.concatenate([offs, eoffs[1:] + offs[-1]])
+    idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | P.MODE_IMAGE_PAIRS)
+    for min_len, min_occ in [(20, 1), (31, 2)]:
+        ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, threads=O.lib().orc_max_threads())
+        b = idx.batch(cat, offs)
+        b.run(min_len, min_occ, flags=P.RUN_TAGS | P.RUN_TIMING)
+        _same(b.result(), ref)
+        assert b.timing().pairs_reads == variant
+        b.free()
+    idx.close()
+
+
 def test_pairs_kernel_with_mostly_lower_case_reads(pan):
     """more 16-byte chunks with a byte outside ACGT than the classification lists: no second-stream launch, the pairs kernel hands
     such reads on itself (no seed applies to them) -- same results"""
