@@ -1329,8 +1329,6 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
 #ifdef PGX_EXP_LOAD6 // sensitivity experiment (scripts/exp_dup.sh): a sixth piece of the same line, thrown away
                 { const uint4 xx = bp[(t1 + 1u) & 3u]; asm volatile("" ::"v"(xx.x), "v"(xx.y), "v"(xx.z), "v"(xx.w)); }
 #endif
-#ifdef PGX_EXP_LOAD4 // ... and one piece less (wrong results: timing only)
-#endif
                 __builtin_amdgcn_s_setprio(0);
 #ifdef PGX_FM_STATS
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(row.x), "+v"(hs.x), "+v"(d0.x), "+v"(d1.x), "+v"(d2.x) :: "memory");

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box): bash scripts/exp_dup.sh [bench args...]
-# Sensitivity of the pairs kernel to VALU work: a -D${EXP:-PGX_EXP_DUP} build (the popcount section of every trip computed twice, +~110 VALU
-# instructions of ~490 per wave trip) against the ordinary build, same bench run.  A kernel bound by memory does not notice.
+# Sensitivity builds of the pairs kernel: EXP=PGX_EXP_DUP (default: the popcount section of every trip computed twice, +~110 VALU
+# instructions of ~515 per wave trip) or EXP=PGX_EXP_LOAD6 (a sixth 16-byte piece of the probed line), against the ordinary build, same bench run.
 set -e
 D=/tmp/pgx_dup_build; rm -rf $D; mkdir -p $D
 cp -r pangenome-index_amd include oracle bench.py __graft_entry__.py tests $D/ 2>/dev/null || true
