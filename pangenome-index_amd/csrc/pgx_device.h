@@ -143,7 +143,8 @@ __global__ void pgx_fmf_kernel(PgxDevImage img, const uint8_t *reads, const uint
 __global__ void pgx_lf_kernel(PgxDevImage img, const pgx_range *in, const uint8_t *sym, uint64_t n, pgx_range *out);
 // n_dev (may be NULL): the element count lives on the device, `n` is then the capacity the launch was sized for
 __global__ void pgx_scan_partial_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, uint64_t *block_sums, const uint64_t *n_dev);
-__global__ void pgx_scan_onepass_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, uint64_t *out, uint64_t *total_out, const uint64_t *n_dev,
+template <int MODE>
+__global__ void pgx_scan_onepass_kernel(const void *in, uint64_t n, uint64_t min_len, uint64_t *out, uint64_t *total_out, const uint64_t *n_dev,
                                         unsigned long long *state, uint32_t epoch);
 __global__ void pgx_scan_sums_kernel(uint64_t *block_sums, uint64_t nb);
 __global__ void pgx_scan_apply_kernel(int mode, const void *in, uint64_t n, uint64_t min_len, const uint64_t *block_sums,

@@ -1788,9 +1788,11 @@ pgx_scan_apply_kernel(int mode, const void *in, uint64_t n_cap, uint64_t min_len
 // round with lane shifts, sixteen rounds), which the three-launch form above was not: 10 M counts take 177 us there.
 // state[0]: tile counter (the last tile sets it back to 0), state[1 + t]: word of tile t.
 #define PGX_SCAN1_ROUNDS 16
+template <int MODE>
 __global__ void __launch_bounds__(256)
-pgx_scan_onepass_kernel(int mode, const void *in, uint64_t n_cap, uint64_t min_len, uint64_t *__restrict__ out, uint64_t *__restrict__ total_out,
+pgx_scan_onepass_kernel(const void *in, uint64_t n_cap, uint64_t min_len, uint64_t *__restrict__ out, uint64_t *__restrict__ total_out,
                         const uint64_t *__restrict__ n_dev, unsigned long long *__restrict__ state, uint32_t epoch) {
+    constexpr int mode = MODE;
     __shared__ uint64_t s_wave[4];
     __shared__ uint64_t s_prefix;
     __shared__ uint32_t s_tile;
@@ -1802,9 +1804,13 @@ pgx_scan_onepass_kernel(int mode, const void *in, uint64_t n_cap, uint64_t min_l
     const uint64_t b0 = (uint64_t)tile * (256u * PGX_SCAN1_ROUNDS) + (uint64_t)w * (64u * PGX_SCAN1_ROUNDS);
     uint64_t x[PGX_SCAN1_ROUNDS], carry = 0;
 #pragma unroll
-    for (int r = 0; r < PGX_SCAN1_ROUNDS; r++) {
+    for (int r = 0; r < PGX_SCAN1_ROUNDS; r++) { // (all sixteen loads first: one memory latency per tile, not one per round)
         const uint64_t i = b0 + (uint64_t)(r * 64 + lane);
-        const uint64_t v = i < n ? pgx_scan_load(mode, in, i, min_len) : 0;
+        x[r] = i < n ? pgx_scan_load(mode, in, i, min_len) : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < PGX_SCAN1_ROUNDS; r++) {
+        const uint64_t v = x[r];
         uint64_t inc = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -1872,6 +1878,10 @@ pgx_scan_onepass_kernel(int mode, const void *in, uint64_t n_cap, uint64_t min_l
         __hip_atomic_store(reinterpret_cast<uint32_t *>(state), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+
+#define PGX_SCAN1_INSTANTIATE(M) \
+    template __global__ void pgx_scan_onepass_kernel<M>(const void *, uint64_t, uint64_t, uint64_t *, uint64_t *, const uint64_t *, unsigned long long *, uint32_t);
+PGX_SCAN1_INSTANTIATE(0) PGX_SCAN1_INSTANTIATE(1) PGX_SCAN1_INSTANTIATE(2) PGX_SCAN1_INSTANTIATE(3) PGX_SCAN1_INSTANTIATE(4) PGX_SCAN1_INSTANTIATE(5)
 
 // ------------------------------------------------------------------------------------------
 // MEM compaction: slots (pgx_slot_index: four per read in a dense array, the rest at the read's worst-case offset) -> dense CSR in read order

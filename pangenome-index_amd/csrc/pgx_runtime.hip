@@ -350,8 +350,16 @@ static void scan_excl(int mode, const void *in, uint64_t n, uint64_t min_len, ui
             tmp.scan_epoch = 0;
         }
         tmp.scan_epoch++;
-        hipLaunchKernelGGL(pgx_scan_onepass_kernel, dim3((unsigned)nt), dim3(256), 0, s, mode, in, n, min_len, out, total_out, n_dev, tmp.as<unsigned long long>(),
-                           tmp.scan_epoch);
+        unsigned long long *st = tmp.as<unsigned long long>();
+        const uint32_t ep = tmp.scan_epoch;
+        switch (mode) {
+        case 0: hipLaunchKernelGGL(pgx_scan_onepass_kernel<0>, dim3((unsigned)nt), dim3(256), 0, s, in, n, min_len, out, total_out, n_dev, st, ep); break;
+        case 1: hipLaunchKernelGGL(pgx_scan_onepass_kernel<1>, dim3((unsigned)nt), dim3(256), 0, s, in, n, min_len, out, total_out, n_dev, st, ep); break;
+        case 2: hipLaunchKernelGGL(pgx_scan_onepass_kernel<2>, dim3((unsigned)nt), dim3(256), 0, s, in, n, min_len, out, total_out, n_dev, st, ep); break;
+        case 3: hipLaunchKernelGGL(pgx_scan_onepass_kernel<3>, dim3((unsigned)nt), dim3(256), 0, s, in, n, min_len, out, total_out, n_dev, st, ep); break;
+        case 4: hipLaunchKernelGGL(pgx_scan_onepass_kernel<4>, dim3((unsigned)nt), dim3(256), 0, s, in, n, min_len, out, total_out, n_dev, st, ep); break;
+        default: hipLaunchKernelGGL(pgx_scan_onepass_kernel<5>, dim3((unsigned)nt), dim3(256), 0, s, in, n, min_len, out, total_out, n_dev, st, ep); break;
+        }
         HIPCHECK(hipGetLastError());
         return;
     }
