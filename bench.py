@@ -253,7 +253,7 @@ def roofline_record(info, cat_len, n_reads, counts, k_ms, timing, workload_key, 
             same = (int(t.get("bwt_size", -1)) == int(info.bwt_size) and int(t.get("reads", -1)) == int(n_reads)
                     and int(t.get("min_len", -1)) == int(min_len) and int(t.get("image_kind", -1)) == int(info.image_kind)
                     and int(t.get("image_pairs", 0)) == int(info.image_pairs) and bool(t.get("tags", True)) == bool(tags)
-                    and int(t.get("pairs_syms", 96 if info.image_pairs else 0)) == int(info.pairs_syms))
+                    and int(t.get("pairs_stride", 96 if info.image_pairs else 0)) == int(info.pairs_stride))
             if same:
                 rec["traffic"] = t.get("find_mems_hbm_bytes_per_launch")
                 rec["traffic_source"] = ("profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, recorded %s; all find_mems launches of a step)"
@@ -403,7 +403,7 @@ def main():
         K, n = args.steps, args.reads
         reads_total = n * world * K
         kinds = {P.IMAGE_RL: "run-length blocks", P.IMAGE_DENSE: "dense bit planes", P.IMAGE_DENSE2: "dense2 bit planes"}
-        image = (("LDS copy of " if info.image_in_lds else "") + kinds[info.image_kind] + (" + two-step pairs image (%d positions per 128-byte block)" % info.pairs_syms if info.image_pairs else "")
+        image = (("LDS copy of " if info.image_in_lds else "") + kinds[info.image_kind] + (" + two-step pairs image (a 128-byte block of 96 positions every %d)" % info.pairs_stride if info.image_pairs else "")
                  + (" (64-bit form: counts as deltas against superblock bases)" if info.image_wide else ""))
         line = {
             "metric": "find_mems reads/sec (150 bp batch)",
@@ -430,7 +430,7 @@ def main():
                 "bwt_size": int(info.bwt_size), "bwt_runs": int(info.n_runs), "image_in_lds": bool(info.image_in_lds),
                 "rank_image": "%s, %.1f MB%s" % (image, info.image_bytes / 1e6, "" if info.image_in_lds else
                                                  (", global memory (fits the 256 MB memory-side cache)" if info.image_bytes < 240e6 else ", resident in HBM")),
-                "image_kind": int(info.image_kind), "image_pairs": int(info.image_pairs), "image_wide": int(info.image_wide), "pairs_syms": int(info.pairs_syms),
+                "image_kind": int(info.image_kind), "image_pairs": int(info.image_pairs), "image_wide": int(info.image_wide), "pairs_stride": int(info.pairs_stride),
                 "tag_image_MB": info.tag_image_bytes / 1e6,
                 "index_build_host_s": round(build_s, 1), "prep_s": round(prep_s, 1),
             },

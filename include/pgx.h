@@ -98,7 +98,7 @@ typedef struct {
                              * 2 = dense2 (384 symbols per 128-byte block, two planes + exception runs) */
     uint32_t image_pairs;   /* 1 = a PAIRS image (two extensions per cache line) accompanies the dense / dense2 image */
     uint32_t image_wide;    /* 1 = the 64-bit form of dense2 / PAIRS (BWTs of 2^32 symbols or more, or PGX_MODE_IMAGE_WIDE) */
-    uint32_t pairs_syms;    /* positions per block of the PAIRS image: 96 (five 16-byte pieces of the line per probe) or 64 (three), 0 without one */
+    uint32_t pairs_stride;  /* positions between the starts of consecutive blocks of the PAIRS image (each covers 96): 96, or 64 = overlapping blocks; 0 without one */
 } pgx_index_info;
 
 const char *pgx_last_error(void);

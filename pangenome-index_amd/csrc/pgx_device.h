@@ -87,7 +87,7 @@ struct PgxDevImage {
     const uint64_t *sbase2, *pbase;
     uint32_t d2_sb_shift, pairs_sb_shift, n_sb2, n_sbp;
     uint32_t wide;
-    uint32_t pairs_syms; // positions per PAIRS block: PGX_PAIRS_SYMS or PGX_PAIRS_SYMS64 (pgx_image.h)
+    uint32_t pairs_stride; // positions between PAIRS block starts: PGX_PAIRS_SYMS or PGX_PAIRS_STRIDE64 (pgx_image.h)
 };
 #define PGX_SEED_UNUSABLE 255u // depth value of entries the kernels must not use (a coordinate does not fit the entry)
 #define PGX_SEED_MAX_K 16
@@ -121,7 +121,7 @@ __global__ void pgx_find_mems_kernel(PgxDevImage img, const uint8_t *reads, cons
                                      uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap, pgx_heavy_item *heavy_list, unsigned long long *heavy_count,
                                      const pgx_heavy_item *rid_list, const unsigned long long *rid_count, uint32_t *ovf_base, uint64_t ovf_cap);
 // PAIRS image (pgx_image.h): two extensions per loop trip; an extension its blocks cannot answer (special positions) goes through the other image
-template <bool SEED, bool WIDE, bool PACKED, bool COOP, bool B64>
+template <bool SEED, bool WIDE, bool PACKED, bool COOP, bool S64>
 __global__ void pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
                                            uint64_t min_len, uint64_t min_occ, const uint64_t *slot_off, pgx_mem *slots,
                                            uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor, uint64_t first_read,

@@ -84,18 +84,14 @@
  * with at most 1023 special runs -- a few dozen sequences; now any number of sequences qualifies.) */
 #define PGX_PAIRS_SYMS 96u
 #define PGX_PAIRS_BLOCK_BYTES 128u
-/* PAIRS, 64 symbols per block (PgxConsts.pairs_syms = 64; only on request, PGX_PAIRS_SYMS=64, for narrow images of BWTs shorter than 2^31):
- * the same pairs, laid out so that a probe reads THREE 16-byte pieces of the line instead of five.  An experiment of round 3 (the texture-address
- * path of the pairs kernel is 83 % busy and a sixth piece of the same line cost +9.6 %: profiles/r03_pairs_kernel_counters.txt) that did not pay:
- * fewer requests per line changed nothing, the 3 % more lines of the shorter blocks did (profiles/r03_pairs64_layout.json).
- *   dw 4 y       bits 0..30: number of positions q < 64 b with c1(q) = y (c2 regular OR special: the rank of y itself); bit 31: the block
- *                holds a special position (the flag, in every one of the four pieces)
- *   dw 4 y + 1 + x   (x = 0, 1, 2) number of positions q < 64 b with c1(q) = y, c2(q) = x
- *   dw 16 + y    as above (c1 = y, c2 special; bit 31 of dw 16 = flag): not read by the kernel, kept for the checks
- *   dw 20 + y    number of positions q < 64 b with c1(q) = y, c2(q) = 3 (read only by a probe whose second symbol is the last code)
- *   dw 24, 25 / 26, 27   bit planes of c1 (bit 0, bit 1), 64 bits each;  dw 28, 29 / 30, 31  bit planes of c2
- * A probe reads piece y (bytes 16 y ..), pieces 6 and 7, and piece 5 when its second symbol has code 3. */
-#define PGX_PAIRS_SYMS64 64u
+/* PAIRS at stride 64 (PgxConsts.pairs_stride = 64; narrow images whose 2 n bytes stay within the reach of the address-translation caches): the
+ * same 96-position blocks, but one every 64 positions -- block b covers [64 b, 64 b + 96) and its counts are those before 64 b --, so that an
+ * interval of up to 32 positions lies inside ONE block wherever it starts.  At stride 96 an interval that crosses a block border costs a second
+ * line (6 % of the kernel's lines at chr22 scale, where intervals are a handful of positions wide); here only intervals that end beyond
+ * position 96 of their block do.  The second block of such an interval overlaps the first by 32 positions: its part starts at position 32.
+ * (Round 3 also tried blocks of 64 positions read as three 16-byte pieces instead of five: fewer requests per line changed nothing, the extra
+ * lines of the shorter blocks did -- profiles/r03_pairs64_layout.json -- and the layout was dropped.) */
+#define PGX_PAIRS_STRIDE64 64u
 /* WIDE variants of DENSE2 and PAIRS (BWTs of 2^32 symbols or more, up to PGX_SB_MAX superblocks; FastLocate is size_t end to end,
  * r-index.hpp:118-130): the same 128-byte blocks, but every count in a block header is a 32-bit DELTA against its superblock --
  * 2^sb_shift consecutive blocks, at most 2^31 symbols -- whose 64-bit bases sit in a small table the kernels stage in LDS:
@@ -144,7 +140,7 @@ typedef struct {
     uint32_t wide;            /* header counts are deltas against superblock bases; 64-bit kernels */
     uint32_t d2_sb_shift, pairs_sb_shift; /* blocks per superblock = 1 << shift */
     uint32_t n_sb2, n_sbp;    /* superblocks of the DENSE2 / PAIRS image */
-    uint32_t pairs_syms;      /* positions per PAIRS block: PGX_PAIRS_SYMS (96) or PGX_PAIRS_SYMS64 (64: the three-piece layout) */
+    uint32_t pairs_stride;    /* positions between the starts of consecutive PAIRS blocks: PGX_PAIRS_SYMS (96) or PGX_PAIRS_STRIDE64 (overlapping blocks) */
     uint64_t pair_t2w[32];    /* pair_t2 in 64 bits (always filled) */
 } PgxConsts;
 

@@ -526,10 +526,11 @@ static void build_dense2_image(const RiFile &ri, HostImage &img, bool wide, uint
 // Returns false (and leaves img without one) when the index does not qualify: an extension entry that ranks a regular symbol must
 // place its interval at that symbol's true C value -- the second step of a pair relies on LF mapping the positions with c1 = a
 // onto the interval after the first -- and the special runs must fit ptab.
-// syms: positions per block, PGX_PAIRS_SYMS (96, five pieces of the line per probe) or PGX_PAIRS_SYMS64 (64, three pieces: narrow images of fewer than 2^31 symbols)
-static bool build_pairs_image(const RiFile &ri, HostImage &img, bool wide, uint32_t sb_shift_want, uint32_t syms) {
-    if (syms != PGX_PAIRS_SYMS && syms != PGX_PAIRS_SYMS64) return false;
-    if (syms == PGX_PAIRS_SYMS64 && (wide || (img.consts.n >> 31))) return false;
+// stride: positions between block starts, PGX_PAIRS_SYMS (96: the blocks tile the BWT) or PGX_PAIRS_STRIDE64 (64: they overlap by 32; narrow images).
+// A block always covers PGX_PAIRS_SYMS positions.
+static bool build_pairs_image(const RiFile &ri, HostImage &img, bool wide, uint32_t sb_shift_want, uint32_t stride) {
+    if (stride != PGX_PAIRS_SYMS && stride != PGX_PAIRS_STRIDE64) return false;
+    if (stride == PGX_PAIRS_STRIDE64 && wide) return false;
     PgxConsts &c = img.consts;
     img.pairs.clear(); img.pbase.clear();
     c.has_pairs = 0; c.pair_runs = 0;
@@ -567,7 +568,7 @@ static bool build_pairs_image(const RiFile &ri, HostImage &img, bool wide, uint3
             if (((PGX_EXT_M(en) >> (3 * code_of_two[y])) & 7u) != (y > two_bit[cv] ? 1u : 0u)) return false;
     }
     // chunks of whole blocks; per chunk the counts of the six codes (for LF), later of the sixteen pairs
-    const uint64_t nb = n / (uint64_t)syms + 1;
+    const uint64_t nb = n / (uint64_t)stride + 1;
     struct Special { uint64_t start, len; uint64_t cnt[5]; }; // cnt: {positions, c2 special with c1 = A, C, G, T}
     std::vector<std::vector<Special>> spec_of;
     std::vector<std::array<uint64_t, 6>> code_cnt;
@@ -587,7 +588,7 @@ static bool build_pairs_image(const RiFile &ri, HostImage &img, bool wide, uint3
         std::mutex mu;
         for (size_t t = 0; t < nt; t++)
             th.emplace_back([&, t]() {
-                try { fn(t, std::min<uint64_t>(range_of[t].first * (uint64_t)syms, n), std::min<uint64_t>(range_of[t].second * (uint64_t)syms, n)); }
+                try { fn(t, std::min<uint64_t>(range_of[t].first * (uint64_t)stride, n), std::min<uint64_t>(range_of[t].second * (uint64_t)stride, n)); }
                 catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
             });
         for (auto &x : th) x.join();
@@ -644,7 +645,7 @@ static bool build_pairs_image(const RiFile &ri, HostImage &img, bool wide, uint3
     // superblocks (wide): bases of the sixteen pair counts and their four row sums
     if ((nb >> 32)) return false;
     const uint32_t sb_shift = wide ? sb_shift_for(nb, sb_shift_want) : 31u;
-    if (wide && ((uint64_t)(uint64_t)syms << sb_shift) > (1ull << 31)) return false;
+    if (wide && ((uint64_t)(uint64_t)stride << sb_shift) > (1ull << 31)) return false;
     const uint64_t n_sb = wide ? ((nb - 1) >> sb_shift) + 1 : 1;
     img.pbase.assign(n_sb * 24, 0);
     if (wide) { // pair counts before every superblock: those before its chunk + a scan of the chunk's positions before it
@@ -658,7 +659,7 @@ static bool build_pairs_image(const RiFile &ri, HostImage &img, bool wide, uint3
                     while (t + 1 < nt && range_of[t].second <= b) t++;
                     std::array<uint64_t, 16> pc{};
                     for (size_t u = 0; u < t; u++) for (int i = 0; i < 16; i++) pc[i] += pair_cnt[u][i];
-                    for (uint64_t p = std::min<uint64_t>(range_of[t].first * (uint64_t)syms, n); p < std::min<uint64_t>(b * (uint64_t)syms, n); p++)
+                    for (uint64_t p = std::min<uint64_t>(range_of[t].first * (uint64_t)stride, n); p < std::min<uint64_t>(b * (uint64_t)stride, n); p++)
                         if (!(pr[p] & 0x80)) pc[pr[p]]++;
                     uint64_t *sb = img.pbase.data() + sbi * 24;
                     for (int i = 0; i < 16; i++) { sb[i] = pc[i]; sb[16 + (i >> 2)] += pc[i]; }
@@ -674,52 +675,44 @@ static bool build_pairs_image(const RiFile &ri, HostImage &img, bool wide, uint3
         std::array<uint64_t, 4> ps{};
         for (size_t u = 0; u < t; u++) { for (int i = 0; i < 16; i++) pc[i] += pair_cnt[u][i]; for (int i = 0; i < 4; i++) ps[i] += spec_cnt[u][i]; }
         const uint64_t b0 = range_of[t].first, b1 = range_of[t].second;
-        size_t r = std::lower_bound(runs.begin(), runs.end(), b0 * (uint64_t)syms, [](const Special &a, uint64_t v) { return a.start < v; }) - runs.begin(); // runs starting before the block
+        size_t r = std::lower_bound(runs.begin(), runs.end(), b0 * (uint64_t)stride, [](const Special &a, uint64_t v) { return a.start < v; }) - runs.begin(); // runs starting before the block
         for (uint64_t b = b0; b < b1; b++) {
             uint32_t *h = dw + b * 32;
-            const uint64_t s0 = b * (uint64_t)syms, s1 = std::min<uint64_t>(s0 + (uint64_t)syms, n);
+            const uint64_t s0 = b * (uint64_t)stride, s1 = std::min<uint64_t>(s0 + PGX_PAIRS_SYMS, n);
             while (r < runs.size() && runs[r].start < s0) r++;
             const uint64_t *sb = img.pbase.data() + (wide ? (b >> sb_shift) : 0) * 24; // (zero in a narrow image)
-            bool flag = (r > 0 && runs[r - 1].start + runs[r - 1].len > s0) || (r < runs.size() && runs[r].start < s1);
-            if (syms == PGX_PAIRS_SYMS64) { // piece y: rank of y (+ flag), pairs (y, 0..2); dw 20 + y: pairs (y, 3)
-                for (int y = 0; y < 4; y++) {
-                    const uint64_t rank = pc[4 * y] + pc[4 * y + 1] + pc[4 * y + 2] + pc[4 * y + 3] + ps[y]; // (< n < 2^31)
-                    h[4 * y] = (uint32_t)rank | (flag ? 0x80000000u : 0u);
-                    for (int x = 0; x < 3; x++) h[4 * y + 1 + x] = (uint32_t)pc[4 * y + x];
-                    h[20 + y] = (uint32_t)pc[4 * y + 3];
-                }
-            } else
-                for (int i = 0; i < 16; i++) h[i] = (uint32_t)(pc[i] - sb[i]);
+            for (int i = 0; i < 16; i++) h[i] = (uint32_t)(pc[i] - sb[i]);
+            const bool flag = (r > 0 && runs[r - 1].start + runs[r - 1].len > s0) || (r < runs.size() && runs[r].start < s1);
             for (int i = 0; i < 4; i++) h[16 + i] = (uint32_t)ps[i];
             if (flag) h[16] |= 0x80000000u;
-            const uint32_t pl0 = syms == PGX_PAIRS_SYMS64 ? 24u : 20u, plw = syms == PGX_PAIRS_SYMS64 ? 2u : 3u; // first plane dword, dwords per plane
-            for (uint64_t p = std::min(s0, p1); p < std::min(s1, p1); p++) {
+            const uint64_t adv = std::min<uint64_t>(s0 + stride, n); // the running counts move on by the stride; the planes cover the whole block
+            for (uint64_t p = s0; p < s1; p++) {
                 const uint8_t v = pr[p];
-                if (v & 0x80) { if (v > 0x80) ps[v - 0x81]++; continue; }
+                if (v & 0x80) { if (v > 0x80 && p < adv) ps[v - 0x81]++; continue; }
                 const uint32_t i = (uint32_t)(p - s0), bit = 1u << (i & 31), w = i >> 5;
-                if (v & 4) h[pl0 + w] |= bit;
-                if (v & 8) h[pl0 + plw + w] |= bit;
-                if (v & 1) h[pl0 + 2 * plw + w] |= bit;
-                if (v & 2) h[pl0 + 3 * plw + w] |= bit;
-                pc[v]++;
+                if (v & 4) h[20 + w] |= bit;
+                if (v & 8) h[23 + w] |= bit;
+                if (v & 1) h[26 + w] |= bit;
+                if (v & 2) h[29 + w] |= bit;
+                if (p < adv) pc[v]++;
             }
         }
-        (void)p0;
+        (void)p0; (void)p1;
     });
     // pair_t2[8 y + c]: number of c in BWT[0, true C of y)
     for (int y = 0; y < 4; y++) {
         const uint64_t P = trueC[code_of_two[y]];
         uint64_t cnt[6] = {0, 0, 0, 0, 0, 0};
         size_t t = 0;
-        for (; t + 1 < nt && std::min<uint64_t>(range_of[t].second * (uint64_t)syms, n) <= P; t++)
+        for (; t + 1 < nt && std::min<uint64_t>(range_of[t].second * (uint64_t)stride, n) <= P; t++)
             for (int i = 0; i < 6; i++) cnt[i] += code_cnt[t][i];
-        for (uint64_t p = std::min<uint64_t>(range_of[t].first * (uint64_t)syms, n); p < P; p++) cnt[bw[p]]++;
+        for (uint64_t p = std::min<uint64_t>(range_of[t].first * (uint64_t)stride, n); p < P; p++) cnt[bw[p]]++;
         for (int i = 0; i < 6; i++) { c.pair_t2[8 * y + i] = (uint32_t)cnt[i]; c.pair_t2w[8 * y + i] = cnt[i]; }
     }
     c.has_pairs = 1;
     c.pair_runs = (uint32_t)runs.size();
     c.pairs_sb_shift = sb_shift;
-    c.pairs_syms = syms;
+    c.pairs_stride = stride;
     c.n_sbp = (uint32_t)n_sb;
     return true;
 }
@@ -791,23 +784,22 @@ void build_rank_image(const RiFile &ri, uint32_t mode_bits, HostImage &img) {
     // superblock sizes (tests shrink them so that small indexes have many: PGX_SB_SHIFT = blocks of the dense2 image per superblock, log2)
     uint32_t sh2 = PGX_D2_SB_SHIFT, shp = PGX_PAIRS_SB_SHIFT;
     if (const char *e = std::getenv("PGX_SB_SHIFT")) { sh2 = (uint32_t)std::min<unsigned long>(std::strtoul(e, nullptr, 10), PGX_D2_SB_SHIFT); shp = sh2 + 2; }
-    // PAIRS block size: 96 positions (five 16-byte pieces of the line per probe, 4 n / 3 bytes).  PGX_PAIRS_SYMS=64 asks for the three-piece
-    // layout (narrow images of fewer than 2^31 symbols, 2 n bytes): measured at chr22 scale it is no faster -- 16.7 against 16.4 ms for the main
-    // kernel, 3 % more lines for the shorter blocks (profiles/r03_pairs64_layout.json) -- because the kernel is bound by the random lines HBM
-    // delivers, not by the requests per line; it stays as an option with its tests
-    uint32_t psyms = PGX_PAIRS_SYMS;
-    if (const char *e = std::getenv("PGX_PAIRS_SYMS")) {
+    // PAIRS blocks every 96 positions (4 n / 3 bytes) or every 64 (2 n bytes: an interval of up to 32 positions never needs a second block):
+    // the overlapping form for narrow images that stay within the reach of the address-translation caches; PGX_PAIRS_STRIDE=96|64 forces one
+    uint32_t pstride = (!wide && 2 * c.n <= (3ull << 30)) ? PGX_PAIRS_STRIDE64 : PGX_PAIRS_SYMS;
+    if (const char *e = std::getenv("PGX_PAIRS_STRIDE")) {
         const unsigned long v = std::strtoul(e, nullptr, 10);
-        if (v == PGX_PAIRS_SYMS64 && !wide && !(c.n >> 31)) psyms = PGX_PAIRS_SYMS64;
+        if (v == PGX_PAIRS_SYMS) pstride = PGX_PAIRS_SYMS;
+        else if (v == PGX_PAIRS_STRIDE64 && !wide) pstride = PGX_PAIRS_STRIDE64;
     }
     if (kind == PGX_IMAGE_DENSE) {
         build_dense_image(ri, img);
-        if (pairs) (void)build_pairs_image(ri, img, false, shp, psyms);
+        if (pairs) (void)build_pairs_image(ri, img, false, shp, pstride);
         return;
     }
     if (kind == PGX_IMAGE_DENSE2) {
         build_dense2_image(ri, img, wide, sh2);
-        if (pairs && !build_pairs_image(ri, img, wide, shp, psyms) && pairs == 2)
+        if (pairs && !build_pairs_image(ri, img, wide, shp, pstride) && pairs == 2)
             throw Error(PGX_ERR_UNSUPPORTED, "pairs image: the index does not qualify (extension tables of a COMPAT quirk, or too many N / endmarker runs)");
         return;
     }
@@ -1089,7 +1081,7 @@ extern "C" pgx_status pgx_index_info_get(const pgx_index *h, pgx_index_info *inf
     info->image_kind = c.image_kind;
     info->image_pairs = c.has_pairs;
     info->image_wide = c.wide;
-    info->pairs_syms = c.has_pairs ? c.pairs_syms : 0;
+    info->pairs_stride = c.has_pairs ? c.pairs_stride : 0;
     return PGX_OK;
     PGX_GUARD_END
 }

@@ -1035,10 +1035,9 @@ __device__ __forceinline__ uint32_t pgx_window_byte(uint64_t w0, uint64_t w1, ui
 // For images beyond the reach of the address-translation caches (~3 GB: profiles/r03_ubench_gather_loads_per_line.txt) a random line costs one
 // translation per load INSTRUCTION that touches it: 1 x 16 B of a line runs at 48 G lines/s, 5 x 16 B at 16-18 G/s, which is where the five-load
 // probe sat on the 5.8 GB image of the 4.35e9-symbol index (17 G lines/s).
-// B64 (narrow, no COOP): the image with 64 positions per block (pgx_image.h): a probe reads piece t1 (rank of its first symbol with the flag, pairs
-// (t1, 0..2)), the two plane pieces, and piece 5 (pairs (., 3)) only where its second symbol has code 3 -- three or four 16-byte requests per lane
-// instead of five, two plane words instead of three.
-template <bool SEED, bool WIDE, bool PACKED, bool COOP, bool B64>
+// S64 (narrow, no COOP): the image with a block every 64 positions (pgx_image.h): block b covers [64 b, 64 b + 96), so an interval of up to 32 positions
+// never needs a second block; the second block of one that does overlaps the first by 32 positions and is read from position 32 on.
+template <bool SEED, bool WIDE, bool PACKED, bool COOP, bool S64>
 __global__ void __launch_bounds__(PGX_FM_THREADS, (PACKED && !WIDE && !COOP) ? PGX_PAIRS_PACKED_WAVES : PGX_FM_WAVES_PER_SIMD) // (<= 96 VGPRs: five waves per SIMD fit and are what the launch uses; four are as fast -- 20.7 against 20.6-21.0 ms at chr22 scale --, three 21.8)
 pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                            uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
@@ -1055,8 +1054,8 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     __shared__ uint4 s_fe[PACKED ? 16 : 512];
     extern __shared__ __align__(16) unsigned char pgx_dyn_lds[];
     static_assert(!COOP || PACKED, "the cooperative loads come with the packed reads");
-    static_assert(!B64 || (!WIDE && !COOP), "the 64-position image is narrow and within the reach of the translation caches");
-    constexpr uint32_t SYMS = B64 ? PGX_PAIRS_SYMS64 : PGX_PAIRS_SYMS;
+    static_assert(!S64 || (!WIDE && !COOP), "the overlapping blocks are for narrow images within the reach of the translation caches");
+    constexpr uint32_t SYMS = PGX_PAIRS_SYMS, STRIDE = S64 ? PGX_PAIRS_STRIDE64 : PGX_PAIRS_SYMS;
     uint32_t *s_rd = reinterpret_cast<uint32_t *>(pgx_dyn_lds); // PACKED: word w of this thread's read at s_rd[w * blockDim.x + threadIdx.x] (pk_words words per thread)
     const uint32_t rd_stride = blockDim.x;
     // COOP: behind the packed reads, 8 KiB per wave: piece p of the line of lane q's probe at [q * 8 + (p ^ (q & 7))] (the swizzle spreads the banks)
@@ -1300,21 +1299,14 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             const pos_t kk = fwd ? kp : k, kq = fwd ? k : kp;
             const pos_t p0 = kk, p1 = kk + s;
             // the block of p0 (96 positions); a second trip (pend) reads the block after it
-            const uint32_t bfirst = B64 ? (uint32_t)(p0 >> 6) : (uint32_t)(((uint64_t)(p0 >> 5) * 0xAAAAAAABull) >> 33); // p0 / 96 (p0 < 2^37)
-            const pos_t endrel_p = p1 - (pos_t)bfirst * SYMS;                                 // p1 relative to the first block
+            const uint32_t bfirst = S64 ? (uint32_t)(p0 >> 6) : (uint32_t)(((uint64_t)(p0 >> 5) * 0xAAAAAAABull) >> 33); // p0 / 96 (p0 < 2^37)
+            const pos_t endrel_p = p1 - (pos_t)bfirst * STRIDE;                               // p1 relative to the first block
             const uint32_t endrel = endrel_p > (pos_t)0xFFFFu ? 0xFFFFu : (uint32_t)endrel_p; // (anything beyond two blocks is "far")
-            const uint32_t relA = pend ? 0u : p0 - bfirst * SYMS;
-            const uint32_t relB = pend ? endrel - SYMS : (endrel < SYMS ? endrel : SYMS);
+            // the second block starts STRIDE positions after the first and the first has answered up to its position SYMS
+            const uint32_t relA = pend ? SYMS - STRIDE : p0 - bfirst * STRIDE;
+            const uint32_t relB = pend ? endrel - STRIDE : (endrel < SYMS ? endrel : SYMS);
             uint4 row, hs, d0, d1, d2;
-            if (B64) { // three pieces of the line, a fourth for a second symbol of code 3
-                const uint4 *bp = img.pairs + (size_t)(bfirst + pend) * 8;
-                row = bp[t1];                                                                  // rank of t1 before the block | flag << 31, pairs (t1, 0), (t1, 1), (t1, 2)
-                d0 = bp[6]; d1 = bp[7];                                                        // planes: c1 bit 0, c1 bit 1 | c2 bit 0, c2 bit 1, two dwords each
-                hs = make_uint4(0u, 0u, 0u, 0u);
-                if (t2 == 3u) hs = bp[5];                                                      // pairs (0..3, 3)
-                d2 = make_uint4(0u, 0u, 0u, 0u);
-                __builtin_amdgcn_s_setprio(0);
-            } else if (COOP) { // the line of this lane's probe is in LDS (fetched by the whole wave above)
+            if (COOP) { // the line of this lane's probe is in LDS (fetched by the whole wave above)
                 const uint4 *mine = s_stage + (uint32_t)lane * 8u;
                 const uint32_t sw = (uint32_t)lane & 7u;
                 row = mine[t1 ^ sw]; hs = mine[4u ^ sw]; d0 = mine[5u ^ sw]; d1 = mine[6u ^ sw]; d2 = mine[7u ^ sw];
@@ -1335,18 +1327,17 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 st_t_line += __builtin_readcyclecounter() - st_l0;
 #endif
             }
-            const bool flagged = ((B64 ? row.x : hs.x) >> 31) != 0u;
-            const uint32_t pts = t1 == 0u ? (hs.x & 0x7FFFFFFFu) : (t1 == 1u ? hs.y : (t1 == 2u ? hs.z : hs.w)); // (B64: the pair count (t1, 3) where t2 = 3)
+            const bool flagged = (hs.x >> 31) != 0u;
+            const uint32_t pts = t1 == 0u ? (hs.x & 0x7FFFFFFFu) : (t1 == 1u ? hs.y : (t1 == 2u ? hs.z : hs.w));
             // masks that turn "code == t" / "code > t" into plane expressions: (x ^ i0) & (y ^ i1) and (y & ua) | (x & (y | va) & wa)
             const uint32_t i0 = (t1 & 1u) ? 0u : 0xFFFFFFFFu, i1 = (t1 & 2u) ? 0u : 0xFFFFFFFFu, j0 = (t2 & 1u) ? 0u : 0xFFFFFFFFu, j1 = (t2 & 2u) ? 0u : 0xFFFFFFFFu;
             const uint32_t ua = t1 < 2u ? 0xFFFFFFFFu : 0u, va = t1 == 0u ? 0xFFFFFFFFu : 0u, wa = (t1 & 1u) ? 0u : 0xFFFFFFFFu;
             const uint32_t ub = t2 < 2u ? 0xFFFFFFFFu : 0u, vb = t2 == 0u ? 0xFFFFFFFFu : 0u, wb = (t2 & 1u) ? 0u : 0xFFFFFFFFu;
-            const uint32_t PX[3] = {d0.x, d0.y, B64 ? 0u : d0.z}, PY[3] = {B64 ? d0.z : d0.w, B64 ? d0.w : d1.x, B64 ? 0u : d1.y},
-                           PU[3] = {B64 ? d1.x : d1.z, B64 ? d1.y : d1.w, B64 ? 0u : d2.x}, PV[3] = {B64 ? d1.z : d2.y, B64 ? d1.w : d2.z, B64 ? 0u : d2.w};
+            const uint32_t PX[3] = {d0.x, d0.y, d0.z}, PY[3] = {d0.w, d1.x, d1.y}, PU[3] = {d1.z, d1.w, d2.x}, PV[3] = {d2.y, d2.z, d2.w};
             // counts below relA (absolute ranks need them) and in [relA, relB) (sizes and the other coordinate are differences)
             uint32_t e1p = 0, e2p = 0, e1r = 0, g1r = 0, e2r = 0, g2r = 0;
 #pragma unroll
-            for (int h = 0; h < (B64 ? 2 : 3); h++) {
+            for (int h = 0; h < 3; h++) {
                 const int32_t ta = (int32_t)relA - 32 * h, tb = (int32_t)relB - 32 * h;
                 const uint32_t mP = ta >= 32 ? 0xFFFFFFFFu : (ta > 0 ? ((1u << ta) - 1u) : 0u);
                 const uint32_t mR = (tb >= 32 ? 0xFFFFFFFFu : (tb > 0 ? ((1u << tb) - 1u) : 0u)) & ~mP;
@@ -1377,15 +1368,14 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 asm volatile("" ::"v"(dsum));
             }
 #endif
-            pos_t a01 = B64 ? (pos_t)((row.x & 0x7FFFFFFFu) + e1p) : (pos_t)(row.x + row.y + row.z + row.w + pts + e1p);                       // rank of the first symbol at p0
-            pos_t a02 = B64 ? (pos_t)((t2 == 0u ? row.y : (t2 == 1u ? row.z : (t2 == 2u ? row.w : pts))) + e2p)
-                            : (pos_t)((t2 == 0u ? row.x : (t2 == 1u ? row.y : (t2 == 2u ? row.z : row.w))) + e2p); // rank of the pair at p0
+            pos_t a01 = (pos_t)(row.x + row.y + row.z + row.w + pts + e1p);                       // rank of the first symbol at p0
+            pos_t a02 = (pos_t)((t2 == 0u ? row.x : (t2 == 1u ? row.y : (t2 == 2u ? row.z : row.w))) + e2p); // rank of the pair at p0
             if (WIDE) { // the counts of a block are deltas against its superblock
                 const uint64_t *pb = s_pb + (size_t)((bfirst + pend) >> img.pairs_sb_shift) * 24u;
                 a01 += (pos_t)pb[16u + t1];
                 a02 += (pos_t)pb[4u * t1 + t2];
             }
-            const bool straddle = endrel > SYMS, far = endrel > 2u * SYMS;
+            const bool straddle = endrel > SYMS, far = endrel > STRIDE + SYMS;
             const bool bail = !fr && (flagged || far); // (a second block is used only when it is not flagged either: nothing special between the two ends)
             const bool wait = !fr && !pend && straddle && !bail; // the interval runs on into the next block: next trip
 #ifdef PGX_FM_STATS

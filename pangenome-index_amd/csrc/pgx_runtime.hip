@@ -231,7 +231,7 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
     upload(d->sbase2, m.sbase2.data(), m.sbase2.size() * 8);
     g.sbase2 = d->sbase2.as<uint64_t>();
     g.d2_sb_shift = m.consts.d2_sb_shift; g.n_sb2 = m.consts.n_sb2;
-    g.pbase = nullptr; g.pairs_sb_shift = 0; g.n_sbp = 0; g.pairs_syms = 0;
+    g.pbase = nullptr; g.pairs_sb_shift = 0; g.n_sbp = 0; g.pairs_stride = 0;
     g.exc = d->exc.as<uint32_t>();
     size_t img_bytes = m.blocks.size() + m.dir.size() * 8 + m.blow.size() * 2;
     if (g.dense == 1) img_bytes = (size_t)m.consts.n_blocks * 16 * PGX_DENSE_LDS_U4 + 16; // padded blocks, no directory (pgx_dense_load)
@@ -249,7 +249,7 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
         upload(d->pbase, m.pbase.data(), m.pbase.size() * 8);
         g.pbase = d->pbase.as<uint64_t>();
         g.pairs_sb_shift = m.consts.pairs_sb_shift; g.n_sbp = m.consts.n_sbp;
-        g.pairs_syms = m.consts.pairs_syms;
+        g.pairs_stride = m.consts.pairs_stride;
         d->first_ext.ensure(512 * sizeof(uint4));
         hipLaunchKernelGGL(pgx_first_ext_kernel, dim3(1), dim3(256), 0, nullptr, g, d->first_ext.as<uint4>());
         HIPCHECK(hipGetLastError());
@@ -1248,7 +1248,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         // (only behind the seed table: the wide intervals at the start of an unseeded stage always have special positions between their ends)
         if (img.pairs && seeded && !(n >> 32) && b->read_bytes < (1ull << 35) && !(pv && pv[0] == '0'))
             kfn_pairs = img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, false, false, false>
-                                 : (img.pairs_syms == PGX_PAIRS_SYMS64 ? (const void *)pgx_find_mems_pairs_kernel<true, false, false, false, true> : (const void *)pgx_find_mems_pairs_kernel<true, false, false, false, false>);
+                                 : (img.pairs_stride == PGX_PAIRS_STRIDE64 ? (const void *)pgx_find_mems_pairs_kernel<true, false, false, false, true> : (const void *)pgx_find_mems_pairs_kernel<true, false, false, false, false>);
         pairs_lds = img.wide ? (size_t)img.n_sbp * 192 : 0; // (superblock bases of the wide form, behind the other dynamic LDS)
         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn_pairs ? kfn_pairs : kfn, PGX_FM_THREADS, kfn_pairs ? pairs_lds : b->dimg->lds_bytes));
         HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
@@ -1383,7 +1383,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                     if (a_skip && pkw <= 24 && !(pe && pe[0] == '0')) {
                         // cooperative line fetches (one address translation per line instead of five) for PAIRS images beyond the reach of the
                         // translation caches, ~3 GB (profiles/r03_ubench_gather_loads_per_line.txt); PGX_FM_COOP=0 / 1 overrides
-                        const bool b64 = img.pairs_syms == PGX_PAIRS_SYMS64; // (three pieces of the line per probe: nothing to gain from fetching whole lines together)
+                        const bool b64 = img.pairs_stride == PGX_PAIRS_STRIDE64; // (overlapping blocks: images within translation reach, no cooperative fetches)
                         bool coop = !b64 && b->h->img.pairs.size() > (3ull << 30);
                         if (const char *ce = std::getenv("PGX_FM_COOP")) coop = !b64 && ce[0] == '1';
                         kp = b64    ? (const void *)pgx_find_mems_pairs_kernel<true, false, true, false, true>

@@ -34,7 +34,7 @@ class IndexInfo(C.Structure):
         ("mode", u32), ("has_tags", u32), ("tag_format", u32), ("n_tag_runs", u64), ("tag_dir_entries", u64),
         ("tag_dir_shift", u32), ("image_in_lds", u32), ("image_bytes", u64), ("tag_image_bytes", u64),
         ("ref_block_mean_bytes", C.c_double), ("max_length", u64), ("n_samples", u64), ("image_kind", u32), ("image_pairs", u32),
-        ("image_wide", u32), ("pairs_syms", u32),
+        ("image_wide", u32), ("pairs_stride", u32),
     ]
 
 

@@ -39,7 +39,7 @@ for wl in wls:
     # for THIS access pattern by profiles/r01_ubench_random_gather.txt: random 64-B and 128-B records are served at the same
     # record rate), so the read side is doubled.  WRITE_SIZE is exact.
     rec = {"workload": wl, "recorded": "round 3 (" + sys.argv[1].rsplit("prof_", 1)[-1] + ")", "kernel": fm, "bwt_size": cfg["bwt_size"], "reads": cfg["reads_per_gpu"], "min_len": cfg["min_len"], "tags": cfg["tags"],
-           "image_kind": cfg["image_kind"], "image_pairs": cfg.get("image_pairs", 0), "pairs_syms": cfg.get("pairs_syms", 0),
+           "image_kind": cfg["image_kind"], "image_pairs": cfg.get("image_pairs", 0), "pairs_stride": cfg.get("pairs_stride", 0),
            "rank_image": cfg["rank_image"],
            "FETCH_SIZE_KB_per_launch": out["FETCH_SIZE"][fm], "WRITE_SIZE_KB_per_launch": out["WRITE_SIZE"].get(fm, 0.0),  # per step of 1 batch
            "find_mems_hbm_bytes_per_launch": (2.0 * out["FETCH_SIZE"][fm] + out["WRITE_SIZE"].get(fm, 0.0)) * 1024.0,

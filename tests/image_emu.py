@@ -30,40 +30,37 @@ class Consts:
         self.image_kind, self.has_pairs = struct.unpack_from("<2I", raw, o); o += 8
         self.pair_t2 = struct.unpack_from("<32I", raw, o); o += 128
         self.pair_runs, _ = struct.unpack_from("<2I", raw, o); o += 8
-        self.wide, self.d2_sb_shift, self.pairs_sb_shift, self.n_sb2, self.n_sbp, self.pairs_syms = struct.unpack_from("<6I", raw, o); o += 24
+        self.wide, self.d2_sb_shift, self.pairs_sb_shift, self.n_sb2, self.n_sbp, self.pairs_stride = struct.unpack_from("<6I", raw, o); o += 24
         self.pair_t2w = struct.unpack_from("<32Q", raw, o); o += 256
         assert o == len(raw), (o, len(raw))
 
 
 class PairsLayout:
-    """where the fields of a PAIRS block (32 dwords) are, for the two block sizes of pgx_image.h: 96 positions (pair counts dw 0..15, c2-special
-    counts + flag dw 16..19, planes dw 20..31 of three words each) and 64 positions (piece y: rank of y | flag << 31, pairs (y, 0..2); dw 16..19
-    as before; dw 20 + y: pairs (y, 3); planes dw 24..31 of two words each)"""
+    """where the fields of a PAIRS block (32 dwords, 96 positions) are, and where the blocks start (pgx_image.h): pair counts dw 0..15, c2-special
+    counts + flag dw 16..19, planes dw 20..31 of three words each; block b starts at position stride * b (stride 96: the blocks tile the BWT;
+    stride 64: they overlap by 32 positions)"""
 
     def __init__(self, consts):
-        self.syms = consts.pairs_syms or 96
-        assert self.syms in (96, 64)
-        self.words = self.syms // 32
+        self.syms = 96
+        self.stride = consts.pairs_stride or 96
+        assert self.stride in (96, 64)
+        self.words = 3
 
     def flag(self, h):
-        return (int(h[0]) if self.syms == 64 else int(h[16])) >> 31
+        return int(h[16]) >> 31
 
     def rank_before(self, h, y):
         """positions before the block whose first symbol is y (second symbol regular or special)"""
-        if self.syms == 64:
-            return int(h[4 * y]) & 0x7FFFFFFF
         return sum(int(h[4 * y + x]) for x in range(4)) + (int(h[16 + y]) & 0x7FFFFFFF)
 
     def pair_before(self, h, y, x):
-        if self.syms == 64:
-            return int(h[4 * y + 1 + x]) if x < 3 else int(h[20 + y])
         return int(h[4 * y + x])
 
     def half_before(self, h, y):
         return int(h[16 + y]) & 0x7FFFFFFF
 
     def plane_word(self, h, plane, w):
-        return int(h[24 + 2 * plane + w]) if self.syms == 64 else int(h[20 + 3 * plane + w])
+        return int(h[20 + 3 * plane + w])
 
 
 class ImageEmu:

@@ -59,10 +59,10 @@ def pan(workdir):
 
 @pytest.mark.parametrize("seed_k,psyms", [("0", None), ("7", "96"), ("7", "64"), (None, "96"), (None, "64")])
 def test_pairs_kernel_equals_the_oracle(pan, monkeypatch, seed_k, psyms):
-    """psyms: the block size of the PAIRS image (pgx_image.h: 96 positions, five 16-byte pieces of the line per probe, or 64, three)"""
+    """psyms: the stride of the PAIRS image (pgx_image.h: blocks of 96 positions every 96 positions, or every 64)"""
     ri_path, tags_path, cat, offs = pan
     if psyms:
-        monkeypatch.setenv("PGX_PAIRS_SYMS", psyms)
+        monkeypatch.setenv("PGX_PAIRS_STRIDE", psyms)
     if seed_k is None:
         monkeypatch.delenv("PGX_SEED_K", raising=False)
     else:
@@ -71,7 +71,7 @@ def test_pairs_kernel_equals_the_oracle(pan, monkeypatch, seed_k, psyms):
     n_reads = len(offs) - 1
     for mode, omode in ((P.MODE_COMPAT, O.MODE_COMPAT), (P.MODE_STRICT, O.MODE_STRICT)):
         idx = P.Index(ri_path, tags_path, mode=mode | P.MODE_IMAGE_PAIRS)
-        assert idx.info().image_pairs == 1 and idx.info().image_kind == P.IMAGE_DENSE2 and idx.info().pairs_syms == int(psyms or 96)
+        assert idx.info().image_pairs == 1 and idx.info().image_kind == P.IMAGE_DENSE2 and idx.info().pairs_stride == int(psyms or 64)
         idx_seed_k = int(seed_k) if seed_k is not None else 10  # automatic: depth 12 for n = 1.2 M and the second table of depth 10
         for min_len, min_occ in [(20, 1), (21, 1), (8, 1), (7, 1), (3, 1), (1, 1), (0, 1), (20, 2), (25, 9), (20, 0), (40, 1), (33, 3)]:
             ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, mode=omode, threads=O.lib().orc_max_threads())
@@ -227,7 +227,7 @@ def _random_index_case(workdir, monkeypatch, seed, force):
     cat, offs = O.pack_reads(reads)
     if force:
         monkeypatch.setenv("PGX_SEED_K", str(int(rng.integers(3, 7))))
-        monkeypatch.setenv("PGX_PAIRS_SYMS", "96" if seed % 2 == 0 else "64")  # both block sizes of the PAIRS image
+        monkeypatch.setenv("PGX_PAIRS_STRIDE", "96" if seed % 2 == 0 else "64")  # both strides of the PAIRS image
     else:
         monkeypatch.delenv("PGX_SEED_K", raising=False)
     for mode, omode in ((P.MODE_COMPAT, O.MODE_COMPAT), (P.MODE_STRICT, O.MODE_STRICT)):
@@ -237,7 +237,7 @@ def _random_index_case(workdir, monkeypatch, seed, force):
             assert force and e.code == P.ERR_UNSUPPORTED and mode == P.MODE_COMPAT and not ri.has_N
             continue
         if force:
-            assert idx.info().pairs_syms == (96 if seed % 2 == 0 else 64)
+            assert idx.info().pairs_stride == (96 if seed % 2 == 0 else 64)
         for min_len, min_occ in [(7, 1), (8, 1), (12, 2), (20, 1), (10, 1)]:
             ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, mode=omode, threads=O.lib().orc_max_threads())
             res, (used, _) = _run(idx, cat, offs, min_len, min_occ)

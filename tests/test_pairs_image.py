@@ -16,8 +16,9 @@ TWO = np.array([-1, 0, 1, 2, -1, 3])
 
 @pytest.fixture(params=["96", "64"])
 def psyms(request, monkeypatch):
-    """both block sizes of the PAIRS image (pgx_image.h): the host builder takes PGX_PAIRS_SYMS"""
-    monkeypatch.setenv("PGX_PAIRS_SYMS", request.param)
+    """both strides of the PAIRS image (pgx_image.h: blocks of 96 positions that tile the BWT, or one every 64 positions): the host builder
+    takes PGX_PAIRS_STRIDE"""
+    monkeypatch.setenv("PGX_PAIRS_STRIDE", request.param)
     return int(request.param)
 
 
@@ -44,9 +45,9 @@ def _check(idx, bw, syms=None):
     pair = np.where(special, -1, 4 * y + x)
     blocks = idx.image_view(20).reshape(-1, 32)
     L = PairsLayout(c)
-    B = L.syms
-    assert idx.info().pairs_syms == B and (syms is None or B == syms)
-    nb = n // B + 1
+    B, S = L.syms, L.stride
+    assert idx.info().pairs_stride == S and (syms is None or S == syms)
+    nb = n // S + 1
     assert len(blocks) == nb
     # special runs (statistics) and, per first symbol, the positions whose second symbol is special: what the pair counts do not see of it
     starts = np.flatnonzero(special & ~np.concatenate([[False], special[:-1]]))
@@ -55,13 +56,11 @@ def _check(idx, bw, syms=None):
     n_special = np.concatenate([[0], np.cumsum(special)])
     cum = np.zeros(16, dtype=np.int64)
     for b in range(nb):
-        s0, s1 = B * b, min(B * b + B, n)
+        s0, s1 = S * b, min(S * b + B, n)
         h = blocks[b]
         assert [L.pair_before(h, i >> 2, i & 3) for i in range(16)] == list(cum), b
         flag = bool(special[s0:s1].any())
         assert L.flag(h) == int(h[16]) >> 31 == (1 if flag else 0), (b, hex(int(h[16])), flag)
-        if B == 64:
-            assert all(int(h[4 * yy]) >> 31 == (1 if flag else 0) for yy in range(4))
         assert [L.half_before(h, yy) for yy in range(4)] == [int(half[yy][s0]) for yy in range(4)], b
         assert [L.rank_before(h, yy) for yy in range(4)] == [int((y[:s0] == yy).sum()) for yy in range(4)], b
         # every position before a block is a regular pair or a special position; rank of symbol y = its row sum + its half-special count
@@ -77,7 +76,8 @@ def _check(idx, bw, syms=None):
                 assert bits == [0, 0, 0, 0]
         for i in range(s1 - s0, B):
             assert all(((L.plane_word(h, pl, i >> 5) >> (i & 31)) & 1) == 0 for pl in range(4))
-        cum += np.bincount(pair[s0:s1][pair[s0:s1] >= 0], minlength=16)
+        adv = pair[s0:min(s0 + S, n)]  # the counts move on by the stride
+        cum += np.bincount(adv[adv >= 0], minlength=16)
     for yy, code in enumerate((1, 2, 3, 5)):
         exp = np.bincount(bw[:trueC[code]], minlength=6)
         assert [int(v) for v in c.pair_t2[8 * yy:8 * yy + 6]] == [int(v) for v in exp]
@@ -163,22 +163,22 @@ class PairsEmu:
         t1, t2 = cv1 - 1 - (cv1 >> 2), cv2 - 1 - (cv2 >> 2)
         kk, kq = (kp, k) if fwd else (k, kp)
         p0, p1 = kk, kk + s
-        B, L = self.L.syms, self.L
-        bf = p0 // B
-        endrel = p1 - B * bf
-        if endrel > 2 * B:
+        B, S, L = self.L.syms, self.L.stride, self.L
+        bf = p0 // S
+        endrel = p1 - S * bf
+        if endrel > S + B:
             return None
         h = self.blocks[bf]
         if L.flag(h):
             return None
-        e1p, e2p, e1r, g1r, e2r, g2r = self._counts(bf, p0 - B * bf, min(endrel, B), t1, t2)
+        e1p, e2p, e1r, g1r, e2r, g2r = self._counts(bf, p0 - S * bf, min(endrel, B), t1, t2)
         a01 = L.rank_before(h, t1) + e1p
         a02 = L.pair_before(h, t1, t2) + e2p
-        if endrel > B:
+        if endrel > B:  # the next block starts S positions on; the first has answered up to its position B
             h2 = self.blocks[bf + 1]
             if L.flag(h2):
                 return None
-            _, _, a, b, c, d = self._counts(bf + 1, 0, endrel - B, t1, t2)
+            _, _, a, b, c, d = self._counts(bf + 1, B - S, endrel - S, t1, t2)
             e1r, g1r, e2r, g2r = e1r + a, g1r + b, e2r + c, g2r + d
         s1, k1, q1 = e1r, a01 + self.c.C[(e1 >> 3) & 7], kq + g1r
         s2, k2, q2 = e2r, a02 + self.c.C[(e2 >> 3) & 7] + self.c.pair_t2[8 * t1 + cv2], q1 + g2r
