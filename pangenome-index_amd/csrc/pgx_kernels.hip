@@ -1091,7 +1091,8 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     uint32_t pend = 0, fresh = 0, restart = 0;
     uint64_t rnext = 0, rend = 0;
     bool exhausted = false;
-    unsigned long long ln_blk = 0, ln_seed = 0; // wave-uniform (scalar registers): block lines / seed entries the wave asked for (PGX_CTR_PAIRS_*)
+    unsigned long long ln_blk = 0, ln_seed = 0, ln_two = 0; // wave-uniform (scalar registers): block lines / seed entries the wave asked for, trips with two extensions (PGX_CTR_PAIRS_*)
+    uint32_t did2 = 0; // this lane's last trip performed two extensions (summed at the top of the next trip, where the wave is converged)
 #ifdef PGX_FM_STATS
     unsigned long long st_trips = 0, st_live = 0, st_wait = 0, st_fresh = 0; // diagnostics build only (scripts/fm_stats.sh)
     unsigned long long st_t_refill = 0, st_refills = 0, st_t_seed = 0, st_t_line = 0;
@@ -1205,6 +1206,8 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         // stage's first trip, which reads block 0 like every other such lane and takes its result from first_ext / the seed table
         // (seed / end table entries: one per first trip -- an upper bound: a stage with fewer than K extensions to go reads the shared entry 0)
         ln_blk += (unsigned long long)__popcll(__ballot(ph > 0 && fresh == 0u));
+        ln_two += (unsigned long long)__popcll(__ballot(did2 != 0u));
+        did2 = 0u;
         if (SEED) ln_seed += (unsigned long long)__popcll(__ballot(ph > 0 && fresh != 0u));
         if (COOP) { // every lane names the block it is about to probe (idle lanes: block 0, like the first trip of a stage), the wave fetches all 64 lines
             const pos_t kk_c = (ph == 2) ? kp : k;
@@ -1441,6 +1444,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                     j = fwd ? j + 1 : j - 1;
                 }
                 next += do2 ? 2u : 1u;
+                did2 = do2 ? 1u : 0u;
                 s = ns;
                 k = fwd ? nq : nk;
                 kp = fwd ? nk : nq;
@@ -1477,7 +1481,8 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
     if (lane == 0 && tot) atomicAdd(n_ext_total + PGX_CTR_EXT, tot);
-    if (lane == 0 && ln_blk) { atomicAdd(n_ext_total + PGX_CTR_PAIRS_LINES, ln_blk); atomicAdd(n_ext_total + PGX_CTR_PAIRS_SEEDS, ln_seed); }
+    ln_two += (unsigned long long)__popcll(__ballot(did2 != 0u));
+    if (lane == 0 && ln_blk) { atomicAdd(n_ext_total + PGX_CTR_PAIRS_LINES, ln_blk); atomicAdd(n_ext_total + PGX_CTR_PAIRS_SEEDS, ln_seed); atomicAdd(n_ext_total + PGX_CTR_PAIRS_TWO, ln_two); }
 #ifdef PGX_FM_STATS // wave trips / live lane-trips, lane-trips waiting for the second block / fresh
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) st_wait += __shfl_down(st_wait, off, 64);
