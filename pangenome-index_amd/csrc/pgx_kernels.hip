@@ -1795,6 +1795,13 @@ pgx_scan_onepass_kernel(const void *in, uint64_t n_cap, uint64_t min_len, uint64
     if (threadIdx.x == 0) s_tile = atomicAdd(reinterpret_cast<uint32_t *>(state), 1u);
     __syncthreads();
     const uint32_t tile = s_tile;
+    // tiles behind the one that holds item n - 1 have nothing to do (n may be a device count well below the capacity the grid was sized for): they
+    // leave at once, and nobody looks back at them
+    const uint32_t last_tile = n ? (uint32_t)((n - 1) / (256u * PGX_SCAN1_ROUNDS)) : 0u;
+    if (tile > last_tile) {
+        if (tile == gridDim.x - 1 && threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<uint32_t *>(state), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t b0 = (uint64_t)tile * (256u * PGX_SCAN1_ROUNDS) + (uint64_t)w * (64u * PGX_SCAN1_ROUNDS);
     uint64_t x[PGX_SCAN1_ROUNDS], carry = 0;
@@ -1866,12 +1873,13 @@ pgx_scan_onepass_kernel(const void *in, uint64_t n_cap, uint64_t min_len, uint64
         const uint64_t i = b0 + (uint64_t)(r * 64 + lane);
         if (i < n) out[i] = P + x[r];
     }
-    if (tile == gridDim.x - 1 && threadIdx.x == 0) { // (every tile has its number by now)
+    if (tile == last_tile && threadIdx.x == 0) {
         const uint64_t grand = s_prefix + tile_total;
         out[n] = grand;
         if (total_out) *total_out = grand;
-        __hip_atomic_store(reinterpret_cast<uint32_t *>(state), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (tile == gridDim.x - 1 && threadIdx.x == 0) // (every tile has its number by now)
+        __hip_atomic_store(reinterpret_cast<uint32_t *>(state), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 #define PGX_SCAN1_INSTANTIATE(M) \
