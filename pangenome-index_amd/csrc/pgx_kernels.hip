@@ -526,17 +526,17 @@ pgx_seed_build_kernel(PgxDevImage img, const uint4 *__restrict__ src, uint4 *__r
   }
 }
 
-// MEM slots of one chunk of reads: the first PGX_FAST_SLOTS MEMs of a read live in one 128-byte line of a dense array at the start of the
-// slot buffer (read r of the chunk: entries 4 r .. 4 r + 3) -- a read has 1.9 MEMs on average, so the writes of neighbouring reads fall into
-// neighbouring lines instead of 4 KiB apart, and the compaction reads them as a stream --, further ones at the read's worst-case
-// offset (slot_off) behind that array
+// MEM slots of one chunk of reads: the first PGX_FAST_SLOTS MEMs of a read live in a dense array at the start of the slot buffer, slot-major (the
+// k-th MEM of read r of the chunk: entry k * chunk_reads + r) -- a read has 1.9 MEMs on average, so the compaction reads the 0.6 GB that exist of
+// that 1.28 GB array, coalesced over neighbouring reads (read-major, entries 4 r .. 4 r + 3, it read every line: 0.53 -> 0.41 ms at chr22 scale) --,
+// further ones in the arena or at the read's worst-case offset (slot_off) behind that array
 #define PGX_FAST_SLOTS 4u
 #ifndef PGX_PAIRS_PACKED_WAVES
 #define PGX_PAIRS_PACKED_WAVES 5 // waves per SIMD the packed narrow pairs kernel is compiled for (95 VGPRs with the inline dense2 step; 79 and six waves without it were no faster)
 #endif
 #define PGX_PK_GROUP 12u // packed words of a read fetched per round of loads when a lane takes the read
 __device__ __forceinline__ uint64_t pgx_slot_index(uint64_t read_in_chunk, uint64_t chunk_reads, uint64_t slot, uint32_t nm) {
-    return nm < PGX_FAST_SLOTS ? read_in_chunk * PGX_FAST_SLOTS + nm : chunk_reads * PGX_FAST_SLOTS + slot + nm;
+    return nm < PGX_FAST_SLOTS ? (uint64_t)nm * chunk_reads + read_in_chunk : chunk_reads * PGX_FAST_SLOTS + slot + nm;
 }
 // Where the fifth and later MEMs of a read go (`slot` of pgx_slot_index).  Worst-case layout (ovf_cap == 0): the read's offset in the scan of
 // min(len, len - min_len + 1), 131 slots per 150-bp read -- 42 GB for 10 M reads that write 0.6 GB.  ARENA (round 3): a read reserves its extent when it
@@ -1887,7 +1887,7 @@ pgx_scan_onepass_kernel(const void *in, uint64_t n_cap, uint64_t min_len, uint64
 PGX_SCAN1_INSTANTIATE(0) PGX_SCAN1_INSTANTIATE(1) PGX_SCAN1_INSTANTIATE(2) PGX_SCAN1_INSTANTIATE(3) PGX_SCAN1_INSTANTIATE(4) PGX_SCAN1_INSTANTIATE(5)
 
 // ------------------------------------------------------------------------------------------
-// MEM compaction: slots (pgx_slot_index: four per read in a dense array, the rest at the read's worst-case offset) -> dense CSR in read order
+// MEM compaction: slots (pgx_slot_index: four per read in a dense slot-major array, the rest in the arena / at the read's worst-case offset) -> dense CSR in read order
 __global__ void __launch_bounds__(256)
 pgx_compact_mems_kernel(uint64_t first_read, uint64_t n_reads, const uint64_t *__restrict__ slot_off, uint64_t slot_base,
                         const pgx_mem *__restrict__ slots, const uint32_t *__restrict__ mem_count,
