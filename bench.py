@@ -133,7 +133,7 @@ def synth_index(W, wd, base_len, haps, rank, barrier):
         W.build_index_from_text(text, wd, name)
         open(done, "w").write("ok\n")
         build_s = time.time() - t0
-        sys.stderr.write("[bench] synthetic index built in %.1f s (host: SA-IS over four groups of sequences + k-way merge)\n" % build_s)
+        sys.stderr.write("[bench] synthetic index built in %.1f s (host: SA-IS over eight groups of sequences + k-way merge)\n" % build_s)
     barrier()
     return os.path.join(wd, name + ".ri"), os.path.join(wd, name + ".compact.tags"), text, build_s
 

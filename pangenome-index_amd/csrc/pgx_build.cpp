@@ -40,6 +40,33 @@ struct BuildTimer {
 };
 
 // sort with host threads: slices sorted side by side, then merged pairwise (std::inplace_merge), round by round
+// Sort by a 64-bit key that is spread over [0, key_end): the elements are dealt into one bucket per thread by key range (count, scatter), the
+// buckets sorted side by side -- no merge passes (the last merge of parallel_sort below runs on one thread: 65 M samples took 22 s on 8 cores).
+template <class T, class Key> static void parallel_range_sort(std::vector<T> &v, uint64_t key_end, Key key) {
+    const size_t n = v.size();
+    const unsigned P = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 16u));
+    auto less = [&](const T &a, const T &b) { return key(a) < key(b); };
+    if (n < (1u << 20) || P < 2 || key_end == 0 || std::getenv("PGX_BUILD_SERIAL_SORT")) { std::sort(v.begin(), v.end(), less); return; } // (the variable: a check of this function)
+    const unsigned B = 4 * P; // more buckets than threads: uneven key ranges even out
+    auto bucket_of = [&](const T &x) { const unsigned __int128 t = (unsigned __int128)std::min<uint64_t>(key(x), key_end - 1) * B; return (unsigned)(t / key_end); };
+    std::vector<std::vector<size_t>> cnt(P, std::vector<size_t>(B, 0));
+    auto run = [&](auto &&fn) {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < P; t++) th.emplace_back([&, t]() { fn(t, n * t / P, n * (t + 1) / P); });
+        for (auto &x : th) x.join();
+    };
+    run([&](unsigned t, size_t a, size_t b) { for (size_t i = a; i < b; i++) cnt[t][bucket_of(v[i])]++; });
+    std::vector<size_t> start(B + 1, 0);
+    for (unsigned b = 0; b < B; b++) { size_t c = 0; for (unsigned t = 0; t < P; t++) c += cnt[t][b]; start[b + 1] = start[b] + c; }
+    std::vector<std::vector<size_t>> at(P, std::vector<size_t>(B, 0));
+    for (unsigned b = 0; b < B; b++) { size_t o = start[b]; for (unsigned t = 0; t < P; t++) { at[t][b] = o; o += cnt[t][b]; } }
+    std::vector<T> out(n);
+    run([&](unsigned t, size_t a, size_t b) { for (size_t i = a; i < b; i++) out[at[t][bucket_of(v[i])]++] = v[i]; });
+    std::atomic<unsigned> next{0};
+    run([&](unsigned, size_t, size_t) { for (;;) { const unsigned b = next.fetch_add(1); if (b >= B) break; std::sort(out.begin() + (std::ptrdiff_t)start[b], out.begin() + (std::ptrdiff_t)start[b + 1], less); } });
+    v.swap(out);
+}
+
 template <class It, class Cmp> static void parallel_sort(It first, It last, Cmp cmp) {
     const size_t n = (size_t)(last - first);
     unsigned T = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 16u));
@@ -566,9 +593,8 @@ static void build_rindex_core(const std::vector<std::pair<uint8_t, uint64_t>> &f
     if (heads.size() < total_runs || tails.size() < total_runs)
         throw Error(PGX_ERR_FORMAT, "rl_bwt is not the BWT of a newline-terminated collection (sampling walk incomplete)");
     if (!tb) std::stable_sort(heads.begin(), heads.end(), [](const Sample &a, const Sample &b) { return a.run_id < b.run_id; }); // (already in run order otherwise)
-    parallel_sort(tails.begin(), tails.end(), [](const Sample &a, const Sample &b) {
-        return a.seq_id < b.seq_id || (a.seq_id == b.seq_id && a.seq_offset < b.seq_offset);
-    });
+    // by text position (sequence, offset): distinct per sample, spread over the whole text
+    parallel_range_sort(tails, n_seq * max_length, [&](const Sample &a) { return a.seq_id * max_length + a.seq_offset; });
     auto bits_length = [](uint64_t x) { return (uint8_t)(x ? hi_bit(x) + 1 : 0); }; // sdsl::bits::length
     auto pack = [&](uint64_t id, uint64_t off) { return id * max_length + off; };   // r-index.hpp:420-422
     put<uint64_t>(out, max_length);
@@ -577,10 +603,19 @@ static void build_rindex_core(const std::vector<std::pair<uint8_t, uint64_t>> &f
         std::vector<uint64_t> sv(total_runs), l2r(total_runs);
         SdVector last;
         last.size = n_seq * max_length; // sd_vector_builder(n_seq * max_length, total_runs)
-        for (uint64_t i = 0; i < total_runs; i++) {
-            sv[i] = pack(heads[i].seq_id, heads[i].seq_offset);
-            last.ones.push_back(pack(tails[i].seq_id, tails[i].seq_offset));
-            l2r[i] = tails[i].run_id;
+        last.ones.resize(total_runs);
+        {
+            const unsigned nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 16u));
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; t++)
+                th.emplace_back([&, t]() {
+                    for (uint64_t i = total_runs * t / nt; i < total_runs * (t + 1) / nt; i++) {
+                        sv[i] = pack(heads[i].seq_id, heads[i].seq_offset);
+                        last.ones[i] = pack(tails[i].seq_id, tails[i].seq_offset);
+                        l2r[i] = tails[i].run_id;
+                    }
+                });
+            for (auto &t : th) t.join();
         }
         uint8_t w = bits_length(pack(n_seq - 1, max_length - 1));
         IntVector::pack(sv, w ? w : 64).write(out, true);
