@@ -84,7 +84,7 @@
  * with at most 1023 special runs -- a few dozen sequences; now any number of sequences qualifies.) */
 #define PGX_PAIRS_SYMS 96u
 #define PGX_PAIRS_BLOCK_BYTES 128u
-/* PAIRS at stride 64 (PgxConsts.pairs_stride = 64; narrow images whose 2 n bytes stay within the reach of the address-translation caches): the
+/* PAIRS at stride 64 (PgxConsts.pairs_stride = 64; the default up to 64 GiB of image, narrow and WIDE): the
  * same 96-position blocks, but one every 64 positions -- block b covers [64 b, 64 b + 96) and its counts are those before 64 b --, so that an
  * interval of up to 32 positions lies inside ONE block wherever it starts.  At stride 96 an interval that crosses a block border costs a second
  * line (6 % of the kernel's lines at chr22 scale, where intervals are a handful of positions wide); here only intervals that end beyond

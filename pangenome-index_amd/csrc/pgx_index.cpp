@@ -526,11 +526,10 @@ static void build_dense2_image(const RiFile &ri, HostImage &img, bool wide, uint
 // Returns false (and leaves img without one) when the index does not qualify: an extension entry that ranks a regular symbol must
 // place its interval at that symbol's true C value -- the second step of a pair relies on LF mapping the positions with c1 = a
 // onto the interval after the first -- and the special runs must fit ptab.
-// stride: positions between block starts, PGX_PAIRS_SYMS (96: the blocks tile the BWT) or PGX_PAIRS_STRIDE64 (64: they overlap by 32; narrow images).
+// stride: positions between block starts, PGX_PAIRS_SYMS (96: the blocks tile the BWT) or PGX_PAIRS_STRIDE64 (64: they overlap by 32).
 // A block always covers PGX_PAIRS_SYMS positions.
 static bool build_pairs_image(const RiFile &ri, HostImage &img, bool wide, uint32_t sb_shift_want, uint32_t stride) {
     if (stride != PGX_PAIRS_SYMS && stride != PGX_PAIRS_STRIDE64) return false;
-    if (stride == PGX_PAIRS_STRIDE64 && wide) return false;
     PgxConsts &c = img.consts;
     img.pairs.clear(); img.pbase.clear();
     c.has_pairs = 0; c.pair_runs = 0;
@@ -784,13 +783,13 @@ void build_rank_image(const RiFile &ri, uint32_t mode_bits, HostImage &img) {
     // superblock sizes (tests shrink them so that small indexes have many: PGX_SB_SHIFT = blocks of the dense2 image per superblock, log2)
     uint32_t sh2 = PGX_D2_SB_SHIFT, shp = PGX_PAIRS_SB_SHIFT;
     if (const char *e = std::getenv("PGX_SB_SHIFT")) { sh2 = (uint32_t)std::min<unsigned long>(std::strtoul(e, nullptr, 10), PGX_D2_SB_SHIFT); shp = sh2 + 2; }
-    // PAIRS blocks every 96 positions (4 n / 3 bytes) or every 64 (2 n bytes: an interval of up to 32 positions never needs a second block):
-    // the overlapping form for narrow images that stay within the reach of the address-translation caches; PGX_PAIRS_STRIDE=96|64 forces one
-    uint32_t pstride = (!wide && 2 * c.n <= (3ull << 30)) ? PGX_PAIRS_STRIDE64 : PGX_PAIRS_SYMS;
+    // PAIRS blocks every 96 positions (4 n / 3 bytes) or every 64 (2 n bytes: an interval of up to 32 positions never needs a second block, 6 % fewer
+    // lines at chr22 scale): the overlapping form up to 64 GiB of image; PGX_PAIRS_STRIDE=96|64 forces one
+    uint32_t pstride = (2 * c.n <= (64ull << 30)) ? PGX_PAIRS_STRIDE64 : PGX_PAIRS_SYMS;
     if (const char *e = std::getenv("PGX_PAIRS_STRIDE")) {
         const unsigned long v = std::strtoul(e, nullptr, 10);
         if (v == PGX_PAIRS_SYMS) pstride = PGX_PAIRS_SYMS;
-        else if (v == PGX_PAIRS_STRIDE64 && !wide) pstride = PGX_PAIRS_STRIDE64;
+        else if (v == PGX_PAIRS_STRIDE64) pstride = PGX_PAIRS_STRIDE64;
     }
     if (kind == PGX_IMAGE_DENSE) {
         build_dense_image(ri, img);

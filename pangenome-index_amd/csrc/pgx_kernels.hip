@@ -1035,7 +1035,7 @@ __device__ __forceinline__ uint32_t pgx_window_byte(uint64_t w0, uint64_t w1, ui
 // For images beyond the reach of the address-translation caches (~3 GB: profiles/r03_ubench_gather_loads_per_line.txt) a random line costs one
 // translation per load INSTRUCTION that touches it: 1 x 16 B of a line runs at 48 G lines/s, 5 x 16 B at 16-18 G/s, which is where the five-load
 // probe sat on the 5.8 GB image of the 4.35e9-symbol index (17 G lines/s).
-// S64 (narrow, no COOP): the image with a block every 64 positions (pgx_image.h): block b covers [64 b, 64 b + 96), so an interval of up to 32 positions
+// S64: the image with a block every 64 positions (pgx_image.h): block b covers [64 b, 64 b + 96), so an interval of up to 32 positions
 // never needs a second block; the second block of one that does overlaps the first by 32 positions and is read from position 32 on.
 template <bool SEED, bool WIDE, bool PACKED, bool COOP, bool S64>
 __global__ void __launch_bounds__(PGX_FM_THREADS, (PACKED && !WIDE && !COOP) ? PGX_PAIRS_PACKED_WAVES : PGX_FM_WAVES_PER_SIMD) // (<= 96 VGPRs: five waves per SIMD fit and are what the launch uses; four are as fast -- 20.7 against 20.6-21.0 ms at chr22 scale --, three 21.8)
@@ -1054,7 +1054,6 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     __shared__ uint4 s_fe[PACKED ? 16 : 512];
     extern __shared__ __align__(16) unsigned char pgx_dyn_lds[];
     static_assert(!COOP || PACKED, "the cooperative loads come with the packed reads");
-    static_assert(!S64 || (!WIDE && !COOP), "the overlapping blocks are for narrow images within the reach of the translation caches");
     constexpr uint32_t SYMS = PGX_PAIRS_SYMS, STRIDE = S64 ? PGX_PAIRS_STRIDE64 : PGX_PAIRS_SYMS;
     uint32_t *s_rd = reinterpret_cast<uint32_t *>(pgx_dyn_lds); // PACKED: word w of this thread's read at s_rd[w * blockDim.x + threadIdx.x] (pk_words words per thread)
     const uint32_t rd_stride = blockDim.x;
@@ -1211,7 +1210,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         if (SEED) ln_seed += (unsigned long long)__popcll(__ballot(ph > 0 && fresh != 0u));
         if (COOP) { // every lane names the block it is about to probe (idle lanes: block 0, like the first trip of a stage), the wave fetches all 64 lines
             const pos_t kk_c = (ph == 2) ? kp : k;
-            const uint32_t myblk = ph > 0 ? (uint32_t)(((uint64_t)(kk_c >> 5) * 0xAAAAAAABull) >> 33) + pend : 0u;
+            const uint32_t myblk = ph > 0 ? (S64 ? (uint32_t)(kk_c >> 6) : (uint32_t)(((uint64_t)(kk_c >> 5) * 0xAAAAAAABull) >> 33)) + pend : 0u;
             // (global_load_lds_dwordx4: straight into LDS, no registers for the data; lane l of instruction i lands at [64 i + l] = slot l & 7 of
             //  probe q = 8 i + (l >> 3), so the swizzle is applied to the piece it fetches)
 #pragma unroll
@@ -1503,7 +1502,11 @@ PGX_PAIRS_INSTANTIATE(true, true, true, false, false)
 PGX_PAIRS_INSTANTIATE(true, false, true, true, false)
 PGX_PAIRS_INSTANTIATE(true, true, true, true, false)
 PGX_PAIRS_INSTANTIATE(true, false, false, false, true)
+PGX_PAIRS_INSTANTIATE(true, true, false, false, true)
 PGX_PAIRS_INSTANTIATE(true, false, true, false, true)
+PGX_PAIRS_INSTANTIATE(true, true, true, false, true)
+PGX_PAIRS_INSTANTIATE(true, false, true, true, true)
+PGX_PAIRS_INSTANTIATE(true, true, true, true, true)
 
 // first extension of every backward stage: the full interval extended by each byte value
 __global__ void __launch_bounds__(256) pgx_first_ext_kernel(PgxDevImage img, uint4 *__restrict__ out) { // out[512]

@@ -1247,8 +1247,11 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         const char *pv = std::getenv("PGX_FM_PAIRS");
         // (only behind the seed table: the wide intervals at the start of an unseeded stage always have special positions between their ends)
         if (img.pairs && seeded && !(n >> 32) && b->read_bytes < (1ull << 35) && !(pv && pv[0] == '0'))
-            kfn_pairs = img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, false, false, false>
-                                 : (img.pairs_stride == PGX_PAIRS_STRIDE64 ? (const void *)pgx_find_mems_pairs_kernel<true, false, false, false, true> : (const void *)pgx_find_mems_pairs_kernel<true, false, false, false, false>);
+        {
+            const bool s64 = img.pairs_stride == PGX_PAIRS_STRIDE64;
+            kfn_pairs = img.wide ? (s64 ? (const void *)pgx_find_mems_pairs_kernel<true, true, false, false, true> : (const void *)pgx_find_mems_pairs_kernel<true, true, false, false, false>)
+                                 : (s64 ? (const void *)pgx_find_mems_pairs_kernel<true, false, false, false, true> : (const void *)pgx_find_mems_pairs_kernel<true, false, false, false, false>);
+        }
         pairs_lds = img.wide ? (size_t)img.n_sbp * 192 : 0; // (superblock bases of the wide form, behind the other dynamic LDS)
         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn_pairs ? kfn_pairs : kfn, PGX_FM_THREADS, kfn_pairs ? pairs_lds : b->dimg->lds_bytes));
         HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
@@ -1383,12 +1386,12 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                     if (a_skip && pkw <= 24 && !(pe && pe[0] == '0')) {
                         // cooperative line fetches (one address translation per line instead of five) for PAIRS images beyond the reach of the
                         // translation caches, ~3 GB (profiles/r03_ubench_gather_loads_per_line.txt); PGX_FM_COOP=0 / 1 overrides
-                        const bool b64 = img.pairs_stride == PGX_PAIRS_STRIDE64; // (overlapping blocks: images within translation reach, no cooperative fetches)
-                        bool coop = !b64 && b->h->img.pairs.size() > (3ull << 30);
-                        if (const char *ce = std::getenv("PGX_FM_COOP")) coop = !b64 && ce[0] == '1';
-                        kp = b64    ? (const void *)pgx_find_mems_pairs_kernel<true, false, true, false, true>
-                             : coop ? (img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, true, true, false> : (const void *)pgx_find_mems_pairs_kernel<true, false, true, true, false>)
-                                    : (img.wide ? (const void *)pgx_find_mems_pairs_kernel<true, true, true, false, false> : (const void *)pgx_find_mems_pairs_kernel<true, false, true, false, false>);
+                        const bool s64 = img.pairs_stride == PGX_PAIRS_STRIDE64;
+                        bool coop = b->h->img.pairs.size() > (3ull << 30);
+                        if (const char *ce = std::getenv("PGX_FM_COOP")) coop = ce[0] == '1';
+#define PGX_PK(W, C) (s64 ? (const void *)pgx_find_mems_pairs_kernel<true, W, true, C, true> : (const void *)pgx_find_mems_pairs_kernel<true, W, true, C, false>)
+                        kp = coop ? (img.wide ? PGX_PK(true, true) : PGX_PK(false, true)) : (img.wide ? PGX_PK(true, false) : PGX_PK(false, false));
+#undef PGX_PK
                         a_packed = b->packed.as<uint32_t>();
                         a_pkw = pkw;
                         plds = (size_t)pkw * PGX_FM_THREADS * 4 + (coop ? (size_t)(PGX_FM_THREADS / 64) * 8192 : 0) + (img.wide ? (size_t)img.n_sbp * 192 : 0);

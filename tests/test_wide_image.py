@@ -22,10 +22,10 @@ def wide_case(workdir):
     return ri[0], ri[1], text
 
 
-@pytest.mark.parametrize("shift", ["2", "4", "7"])
-def test_wide_images_are_the_narrow_ones_rebased(wide_case, monkeypatch, shift):
+@pytest.mark.parametrize("shift,stride", [("2", "96"), ("4", "96"), ("7", "96"), ("3", "64"), ("6", "64")])
+def test_wide_images_are_the_narrow_ones_rebased(wide_case, monkeypatch, shift, stride):
     ri, _, _ = wide_case
-    monkeypatch.setenv("PGX_PAIRS_STRIDE", "96")  # the wide form keeps the tiling blocks: compare with the narrow image of that stride
+    monkeypatch.setenv("PGX_PAIRS_STRIDE", stride)  # both strides of the PAIRS blocks, narrow and wide alike
     narrow = P.Index(ri, None, mode=P.MODE_COMPAT | P.MODE_IMAGE_PAIRS)
     monkeypatch.setenv("PGX_SB_SHIFT", shift)
     wide = P.Index(ri, None, mode=P.MODE_COMPAT | P.MODE_IMAGE_PAIRS | P.MODE_IMAGE_WIDE)
@@ -134,15 +134,15 @@ def test_wide_kernels_against_the_oracle(wide_case, monkeypatch, shift):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("wide", [0, 1])
-def test_cooperative_line_fetches_against_the_oracle(wide_case, monkeypatch, wide):
+@pytest.mark.parametrize("wide,stride", [(0, "96"), (1, "96"), (0, "64"), (1, "64")])
+def test_cooperative_line_fetches_against_the_oracle(wide_case, monkeypatch, wide, stride):
     """pgx_find_mems_pairs_kernel<.., COOP>: the wave fetches the 64 block lines of its lanes together through LDS (global_load_lds), the variant
     for PAIRS images beyond the reach of the address-translation caches -- forced here on a small index, narrow and wide, with reads that
     meet flagged blocks, heavy reads and idle lanes in the mix"""
     ri_path, tags_path, text = wide_case
     monkeypatch.setenv("PGX_SB_SHIFT", "3")
     monkeypatch.setenv("PGX_FM_COOP", "1")
-    monkeypatch.setenv("PGX_PAIRS_STRIDE", "96")  # (images that large have the tiling blocks: the overlapping ones are for images within translation reach)
+    monkeypatch.setenv("PGX_PAIRS_STRIDE", stride)
     ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
     seqs = W.load_sequences(text)
     cat, offs = W.sample_reads(seqs, 60_000, 150, seed=9)
