@@ -133,6 +133,7 @@ __global__ void pgx_classify_reads_kernel(const uint8_t *reads, const uint64_t *
                                           uint64_t cap, uint32_t *flag_words, pgx_heavy_item *list, unsigned long long *count);
 __global__ void pgx_first_ext_kernel(PgxDevImage img, uint4 *out); // out[byte] = {k, k', s, 0} of the full interval extended backward by byte; out[256 + byte]: by 0, then by byte
 __global__ void pgx_rank_kernel(PgxDevImage img, const uint64_t *pos, uint64_t n, int true_codes, uint64_t *out);
+template <bool LOOP, bool MULHI> __global__ void pgx_rank_probe_kernel(PgxDevImage img, const uint64_t *pos, uint64_t n, uint64_t *out);
 template <bool LDS_IMAGE>
 __global__ void pgx_extend_kernel(PgxDevImage img, const pgx_biint *in, const uint8_t *sym, const uint8_t *forward, uint64_t n,
                                   pgx_biint *out);

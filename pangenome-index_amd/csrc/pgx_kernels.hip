@@ -221,8 +221,11 @@ __device__ __forceinline__ void pgx_dense2_rank(const PgxDevImage &img, uint32_t
 // ------------------------------------------------------------------------------------------
 // WIDE DENSE2 (pgx_image.h): the same blocks, header counts as deltas against the 64-bit bases of the block's superblock; positions
 // and counts in 64 bits.  `sb` = the base table (img.sbase2 or its LDS copy): 8 words per superblock {A, C, G, T, N, their sum}.
+// (MULHI: the form of pos / 384 this function had until round 3, kept for scripts/anomaly_probe.py only)
+template <bool MULHI = false>
 __device__ __forceinline__ PgxDense2Blk pgx_dense2w_load(const PgxDevImage &img, uint64_t pos, uint32_t &rel, uint32_t &blk) {
-    blk = (uint32_t)(((pos >> 7) * 0xAAAAAAABull) >> 33); // pos / 384 = (pos / 128) / 3, exact while pos / 128 < 2^32
+    blk = MULHI ? (uint32_t)(__umul64hi(pos, 0xAAAAAAAAAAAAAAABull) >> 8)
+                : (uint32_t)(((pos >> 7) * 0xAAAAAAABull) >> 33); // pos / 384 = (pos / 128) / 3, exact while pos / 128 < 2^32
     rel = (uint32_t)(pos - (uint64_t)blk * PGX_D2_SYMS);
     const uint4 *bp = img.blocks + (size_t)blk * 8;
     PgxDense2Blk b;
@@ -260,9 +263,10 @@ __device__ __forceinline__ void pgx_dense2w_pair(const PgxDevImage &img, const u
     }
     A0 = a0; A1 = a1; dB = d;
 }
+template <bool MULHI = false>
 __device__ __forceinline__ void pgx_dense2w_rank(const PgxDevImage &img, uint64_t pos, uint32_t cv, uint32_t mrow, uint64_t &A, uint64_t &B) {
     uint32_t rel, blk;
-    const PgxDense2Blk k = pgx_dense2w_load(img, pos, rel, blk);
+    const PgxDense2Blk k = pgx_dense2w_load<MULHI>(img, pos, rel, blk);
     uint64_t c[6];
     pgx_dense2w_counts(img, img.sbase2, k, pos, rel, blk, c);
     uint64_t a = 0, bb = 0;
@@ -1643,6 +1647,33 @@ pgx_rank_kernel(PgxDevImage img, const uint64_t *__restrict__ pos, uint64_t n, i
     else if (sl < sigma) pgx_rank_ab<false>(img, nullptr, nullptr, nullptr, pos[i], img.consts->slot_code[sl], 0, A, B);
     out[t] = A;
 }
+// Probe of the round-3 anomaly (DESIGN.md "stale counts"; scripts/anomaly_probe.py; PGX_RANK_PROBE selects it in pgx_rank_batch): the shape
+// pgx_rank_kernel had until commit 66308c2 -- LOOP: one thread walks the six slots of its position -- and the form of pos / 384 it used -- MULHI --,
+// each switchable on its own, over a wide dense2 image with true codes.  Test-only.
+template <bool LOOP, bool MULHI>
+__global__ void __launch_bounds__(256)
+pgx_rank_probe_kernel(PgxDevImage img, const uint64_t *__restrict__ pos, uint64_t n, uint64_t *__restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (LOOP) {
+        if (t >= n) return;
+        for (uint32_t sl = 0; sl < 6; sl++) {
+            uint64_t A = 0, B;
+            const uint64_t p = pos[t] > img.n ? img.n : pos[t];
+            pgx_dense2w_rank<MULHI>(img, p, sl, 0, A, B);
+            out[t * 6 + sl] = A;
+        }
+    } else {
+        if (t >= 6 * n) return;
+        const uint64_t i = t / 6;
+        uint64_t A = 0, B;
+        const uint64_t p = pos[i] > img.n ? img.n : pos[i];
+        pgx_dense2w_rank<MULHI>(img, p, (uint32_t)(t - 6 * i), 0, A, B);
+        out[t] = A;
+    }
+}
+template __global__ void pgx_rank_probe_kernel<true, true>(PgxDevImage, const uint64_t *, uint64_t, uint64_t *);
+template __global__ void pgx_rank_probe_kernel<true, false>(PgxDevImage, const uint64_t *, uint64_t, uint64_t *);
+template __global__ void pgx_rank_probe_kernel<false, true>(PgxDevImage, const uint64_t *, uint64_t, uint64_t *);
 
 template <bool LDS_IMAGE>
 __global__ void __launch_bounds__(256)

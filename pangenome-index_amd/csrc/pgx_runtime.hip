@@ -1683,6 +1683,14 @@ extern "C" pgx_status pgx_rank_batch(pgx_index *h, int device, const uint64_t *p
         dout.ensure(n * 48);
         HIPCHECK(hipMemcpy(dp.p, pos, n * 8, hipMemcpyHostToDevice));
         HIPCHECK(hipMemset(dout.p, 0, n * 48));
+        const char *probe = std::getenv("PGX_RANK_PROBE"); // scripts/anomaly_probe.py: the round-3 shapes of this kernel (wide dense2 image, true codes)
+        if (probe && d->img.dense == 3 && true_codes) {
+            const std::string v(probe);
+            if (v == "loop_mulhi") hipLaunchKernelGGL((pgx_rank_probe_kernel<true, true>), dim3(grid_for(n, 256)), dim3(256), 0, 0, d->img, dp.as<uint64_t>(), n, dout.as<uint64_t>());
+            else if (v == "loop") hipLaunchKernelGGL((pgx_rank_probe_kernel<true, false>), dim3(grid_for(n, 256)), dim3(256), 0, 0, d->img, dp.as<uint64_t>(), n, dout.as<uint64_t>());
+            else if (v == "mulhi") hipLaunchKernelGGL((pgx_rank_probe_kernel<false, true>), dim3(grid_for(6 * n, 256)), dim3(256), 0, 0, d->img, dp.as<uint64_t>(), n, dout.as<uint64_t>());
+            else throw Error(PGX_ERR_ARG, "PGX_RANK_PROBE: loop_mulhi | loop | mulhi");
+        } else
         hipLaunchKernelGGL(pgx_rank_kernel, dim3(grid_for(6 * n, 256)), dim3(256), 0, 0, d->img, dp.as<uint64_t>(), n, true_codes, dout.as<uint64_t>());
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipMemcpy(out, dout.p, n * 48, hipMemcpyDeviceToHost));

@@ -151,12 +151,11 @@ def test_count_batch_gpu(workdir):
 
 
 @pytest.mark.gpu
-def test_query_tags_cli(built):
+def test_query_tags_cli(built, tmp_path):
     """stdout grammar of src/query_tags.cpp:103-108 + tag_arrays.cpp:885-889 on the reference's fixture pair"""
     ri_path, tags_path = os.path.join(BT, "xy.ri"), os.path.join(BT, "xy_bidirectional_compressed.tags")
     reads = [l for l in open(os.path.join(BT, "reads.txt")).read().split("\n") if l] + ["ACG", "GAT", "TTTTGG"]
-    path = os.path.join(ROOT, "gpurun_out", "qt_reads.txt")
-    os.makedirs(os.path.dirname(path), exist_ok=True)
+    path = str(tmp_path / "qt_reads.txt")
     open(path, "w").write("\n".join(reads) + "\n\n")
     r = subprocess.run([os.path.join(ROOT, "pangenome-index_amd", "query_tags"), ri_path, tags_path, path], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
