@@ -57,6 +57,16 @@ def pan(workdir):
     return ri_path, tags_path, cat, offs
 
 
+_REF = {}  # the oracle's answers, computed once per (mode, min_len, min_occ): they do not depend on the device layout under test
+
+
+def _oracle(ri, tags, cat, offs, min_len, min_occ, omode):
+    key = (omode, min_len, min_occ, len(offs))
+    if key not in _REF:
+        _REF[key] = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, mode=omode, threads=O.lib().orc_max_threads())
+    return _REF[key]
+
+
 @pytest.mark.parametrize("seed_k,psyms", [("0", None), ("7", "96"), ("7", "64"), (None, "96"), (None, "64")])
 def test_pairs_kernel_equals_the_oracle(pan, monkeypatch, seed_k, psyms):
     """psyms: the stride of the PAIRS image (pgx_image.h: blocks of 96 positions every 96 positions, or every 64)"""
@@ -74,7 +84,7 @@ def test_pairs_kernel_equals_the_oracle(pan, monkeypatch, seed_k, psyms):
         assert idx.info().image_pairs == 1 and idx.info().image_kind == P.IMAGE_DENSE2 and idx.info().pairs_stride == int(psyms or 64)
         idx_seed_k = int(seed_k) if seed_k is not None else 10  # automatic: depth 12 for n = 1.2 M and the second table of depth 10
         for min_len, min_occ in [(20, 1), (21, 1), (8, 1), (7, 1), (3, 1), (1, 1), (0, 1), (20, 2), (25, 9), (20, 0), (40, 1), (33, 3)]:
-            ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, mode=omode, threads=O.lib().orc_max_threads())
+            ref = _oracle(ri, tags, cat, offs, min_len, min_occ, omode)
             res, (used, redo) = _run(idx, cat, offs, min_len, min_occ)
             _same(res, ref)
             seeded = seed_k != "0" and min_len >= idx_seed_k

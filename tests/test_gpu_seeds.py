@@ -46,6 +46,9 @@ def pan(workdir):
     return ri_path, tags_path, cat, offs
 
 
+_REF = {}  # the oracle's answers, computed once per (mode, min_len, min_occ): they do not depend on the seed table under test
+
+
 @pytest.mark.parametrize("seed_k", ["0", "3", "8", "11", None])
 def test_results_do_not_depend_on_the_seed_table(pan, monkeypatch, seed_k):
     ri_path, tags_path, cat, offs = pan
@@ -59,8 +62,10 @@ def test_results_do_not_depend_on_the_seed_table(pan, monkeypatch, seed_k):
         idx = P.Index(ri_path, tags_path, mode=mode)
         assert not idx.info().image_in_lds
         for min_len, min_occ in [(20, 1), (8, 1), (11, 1), (12, 1), (3, 1), (20, 2), (25, 9), (20, 0), (40, 1)]:
-            ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, mode=omode, threads=O.lib().orc_max_threads())
-            _same(idx.find_mems(cat, offs, min_len, min_occ, tags=True), ref)
+            key = (omode, min_len, min_occ)
+            if key not in _REF:
+                _REF[key] = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, mode=omode, threads=O.lib().orc_max_threads())
+            _same(idx.find_mems(cat, offs, min_len, min_occ, tags=True), _REF[key])
         idx.close()
 
 
