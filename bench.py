@@ -69,6 +69,10 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target core-seconds of the CPU sample")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the measured batch (parity_sample)")
     ap.add_argument("--no-overlap", action="store_true", help="skip the extra measurement with two batches in flight (two_batches_in_flight)")
+    ap.add_argument("--no-fresh", action="store_true", help="skip the fresh-batch measurement (fresh_batch: every step uploads a different batch from pinned host memory, runs it and downloads its results)")
+    ap.add_argument("--batch-sweep", action="store_true", help="also report reads/s against the batch size (64 k ... --reads), resident and fresh (batch_size_sweep)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --reads per GPU; strong (BASELINE configs[3] as worded): ONE batch of --reads cut into --gpus contiguous slices, one per rank")
     ap.add_argument("--parity-reads", type=int, default=100_000, help="reads of the measured batch the oracle re-computes (parity_sample)")
     ap.add_argument("--workdir", default=None)
     ap.add_argument("--pcie", action="store_true",
@@ -238,6 +242,153 @@ def measure_two_in_flight(idx, cat, offs, local, min_len, min_occ, flags, steps,
     if err:
         raise err[0]
     return dt, counts
+
+
+class HostBatch:
+    """one batch of reads resident in PINNED host memory in both forms pgx takes: bytes + offsets (pgx_batch_upload) and packed words + offsets
+    + the listed reads with a byte outside A C G T (pgx_batch_upload_packed; packed by pgx_pack_reads before the timed region, as the CLI's
+    parse threads do it while they parse)"""
+
+    def __init__(self, P, cat, offs, keep_bytes=True):
+        import numpy as np
+
+        self.n = len(offs) - 1
+        self.offs = P.pinned_array(len(offs), np.uint64)
+        self.offs[:] = offs
+        words = (len(cat) + 15) // 16
+        self.packed = P.pinned_array(max(words, 1), np.uint32)
+        side_cap_ids, side_cap_bytes = self.n // 8 + 1024, len(cat) // 8 + 4096
+        self.side_ids = P.pinned_array(side_cap_ids, np.uint64)
+        self.side_bytes = P.pinned_array(side_cap_bytes, np.uint8)
+        t0 = time.perf_counter()
+        self.n_side, self.n_side_bytes = P.pack_reads(cat, offs, self.packed, self.side_ids, self.side_bytes)
+        self.pack_s = time.perf_counter() - t0
+        self.cat = None
+        if keep_bytes:
+            self.cat = P.pinned_array(max(len(cat), 1), np.uint8)
+            self.cat[: len(cat)] = cat
+        self.h2d_bytes_packed = words * 4 + 8 * (self.n + 1) + 8 * self.n_side + self.n_side_bytes
+        self.h2d_bytes_plain = len(cat) + 8 * (self.n + 1)
+
+
+def measure_fresh(idx, host_batches, local, min_len, min_occ, flags, steps, sync, packed, workers=3, warm=2):
+    """NOT the bench value: K steps that each upload a batch DIFFERENT from the one the device batch held (rotating over the pinned host
+    batches), run it and download its results into pinned host arrays -- `workers` device batches, a host thread and a stream each, so that the
+    upload of one, the kernels of another and the download of a third overlap (what the find_mems CLI's device workers do).  Returns
+    (seconds, per-step counts of the last step of every worker)."""
+    import threading
+
+    dbs = [idx.batch_empty(device=local) for _ in range(workers)]
+    nb = len(host_batches)
+    err, last = [], [None] * workers
+
+    def one(w, k):
+        hb = host_batches[(w + k) % nb]
+        if packed:
+            dbs[w].upload_packed(hb.packed, hb.offs, hb.side_ids, hb.side_bytes, hb.n_side)
+        else:
+            dbs[w].upload(hb.cat, hb.offs)
+        dbs[w].run(min_len, min_occ, flags & ~2, 0)  # (no event timing inside; the batch's own stream)
+        nm, npos = dbs[w].result_counts()  # D2H of offsets, MEMs, run counts, positions into the batch's pinned arrays
+        last[w] = ((w + k) % nb, nm, npos)
+
+    def work(w, k0, k1):
+        try:
+            for k in range(k0, k1):
+                one(w, k)
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+
+    for w in range(workers):  # warm-up: allocations, shapes for the speculative sizing
+        work(w, 0, warm)
+    sync()
+    if err:
+        raise err[0]
+    share = [steps // workers + (1 if w < steps % workers else 0) for w in range(workers)]
+    th = [threading.Thread(target=work, args=(w, warm, warm + share[w])) for w in range(workers)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    sync()
+    dt = time.perf_counter() - t0
+    if err:
+        raise err[0]
+    return dt, last, dbs
+
+
+def fresh_record(P, idx, host_batches, local, args, flags, sync, resident_result, resident_counts):
+    """the fresh_batch object of the bench line (+ per_upload_ms of both upload forms)"""
+    import numpy as np
+
+    n, K = host_batches[0].n, args.steps
+    out = {"what": "K steps that each pgx_batch_upload[_packed] a batch different from the one before (three batches resident in pinned host memory, rotating), "
+                   "pgx_batch_run it and pgx_batch_result it into pinned host arrays; three device batches / host threads / streams, so H2D, kernels and D2H of "
+                   "consecutive steps overlap; whole batches of %d reads, tags included" % n,
+           "unit": "reads/s", "steps": K, "workers": 3}
+    for key, packed in (("packed", True), ("bytes", False)):
+        dt, last, dbs = measure_fresh(idx, host_batches, local, args.min_len, args.min_occ, flags, K, sync, packed)
+        rec = {"value": n * K / dt, "ms_per_step": 1e3 * dt / K,
+               "h2d_MB_per_step": (host_batches[0].h2d_bytes_packed if packed else host_batches[0].h2d_bytes_plain) / 1e6}
+        # a step that uploaded host batch 0 must give exactly what the resident (measured) batch gave: full arrays, device vs device
+        ident = None
+        for w, l in enumerate(last):
+            if l is not None and l[0] == 0 and resident_result is not None:
+                r = dbs[w].result()
+                ident = bool(np.array_equal(r["mem_offsets"], resident_result["mem_offsets"]) and r["mems"].tobytes() == resident_result["mems"].tobytes()
+                             and ("positions" not in resident_result or (np.array_equal(r["pos_offsets"], resident_result["pos_offsets"])
+                                                                         and np.array_equal(r["positions"], resident_result["positions"]))))
+                del r
+                break
+        rec["identical_to_the_resident_batch"] = ident
+        # per-upload device passes, timed by HIP events on one worker: upload batch 0 again, then the first run after it
+        db = dbs[0]
+        hb = host_batches[0]
+        if packed:
+            db.upload_packed(hb.packed, hb.offs, hb.side_ids, hb.side_bytes, hb.n_side)
+        else:
+            db.upload(hb.cat, hb.offs)
+        db.run(args.min_len, args.min_occ, flags | 2, 0)
+        rec["per_upload_ms"] = float(db.timing().ms_per_upload)
+        rec["counts_equal_the_bench_steps"] = bool(tuple(db.counts()) == tuple(resident_counts))
+        for b in dbs:
+            b.free()
+        out[key] = rec
+    out["value"] = out["packed"]["value"]
+    out["ms_per_step"] = out["packed"]["ms_per_step"]
+    out["per_upload_ms"] = out["packed"]["per_upload_ms"]
+    out["pack_on_host_s_per_batch"] = host_batches[0].pack_s
+    out["per_upload_ms_what"] = ("device time before the first find_mems launch that a fresh batch pays and a re-run of resident reads (the bench value) does not: "
+                                 "packed upload = unpack to bytes + the listed reads' bytes + the MEM slot scan; byte upload = the pass that packs the reads and finds bytes outside "
+                                 "A C G T, its read-back, the pass that lists those reads, the slot scan (pgx_timing.ms_per_upload)")
+    return out
+
+
+def batch_size_sweep(P, idx, cat, offs, local, args, flags, stream, sync):
+    """reads/s against the batch size: the resident re-run rate (the bench value's definition) and the fresh-batch rate (packed uploads), prefixes
+    of the measured batch"""
+    L = args.read_len
+    rows = []
+    size = 65536
+    sizes = []
+    while size < args.reads:
+        sizes.append(size)
+        size *= 4
+    sizes.append(args.reads)
+    for m in sizes:
+        c, o = cat[: m * L], offs[: m + 1]
+        steps = max(5, min(40, int(40e6 // m)))
+        batch, dt, k_ms, counts = measure(P, idx, c, o, local, args.min_len, args.min_occ, flags, steps, 2, stream, sync, lambda: None)
+        batch.free()
+        hbs = [HostBatch(P, c, o, keep_bytes=False)]
+        dtf, _, dbs = measure_fresh(idx, hbs, local, args.min_len, args.min_occ, flags, max(steps, 6), sync, True)
+        for b in dbs:
+            b.free()
+        rows.append({"reads": m, "resident_reads_per_s": m * steps / dt, "resident_ms_per_step": 1e3 * dt / steps, "find_mems_main_ms": k_ms["find_mems_main"],
+                     "fresh_reads_per_s": m * max(steps, 6) / dtf, "fresh_ms_per_step": 1e3 * dtf / max(steps, 6)})
+        del hbs
+    return rows
 
 
 def roofline_record(info, cat_len, n_reads, counts, k_ms, timing, workload_key, min_len, tags):

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PGX_ABI_VERSION 3 /* 2: pgx_timing grew (pairs_reads, redo_reads), pgx_index_info.image_pairs, PGX_MODE_IMAGE_PAIRS; 3: pgx_timing grew (ms_find_mems_main, traffic counters) */
+#define PGX_ABI_VERSION 4 /* 2: pgx_timing grew (pairs_reads, redo_reads), pgx_index_info.image_pairs, PGX_MODE_IMAGE_PAIRS; 3: pgx_timing grew (ms_find_mems_main, traffic counters); 4: pgx_timing.ms_per_upload, pgx_pack_reads, pgx_batch_upload_packed */
 
 typedef enum {
     PGX_OK = 0,
@@ -291,6 +291,12 @@ typedef struct {
     uint64_t main_lines, main_seed_loads;   /* the launch ms_find_mems_main times */
     uint64_t other_lines, other_seed_loads; /* the other pgx_find_mems_kernel launches of the run */
     uint64_t two_step_trips;                /* PAIRS kernel: lane trips that performed two extensions from one line */
+    /* Device time every FRESH batch pays before its first find_mems launch and a re-run of resident reads does not: with pgx_batch_upload the
+     * pass that finds the chunks holding a byte outside A C G T and packs the reads to two bits per symbol, its read-back, the pass that lists
+     * the reads concerned, and the scan of the worst-case MEM slots -- all inside the first pgx_batch_run after the upload (from its first
+     * event to the first find_mems launch); with pgx_batch_upload_packed the unpack pass and the listed reads' bytes (inside the upload) plus
+     * that scan.  0 for a run that found everything in place. */
+    float ms_per_upload;
 } pgx_timing;
 
 /* Upload reads (read i = reads[offsets[i] .. offsets[i+1]); the `std::getline` lines of
@@ -305,6 +311,19 @@ void pgx_host_free(void *p);
 /* Replace the reads of an existing batch (its device and pinned host buffers only ever grow: a long-lived
  * batch costs no allocation per call).  Invalidates the results of the previous run. */
 pgx_status pgx_batch_upload(pgx_batch *b, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads);
+/* The same with the reads packed by the caller (the find_mems CLI's parse threads do it): a quarter of the bytes over the link, and no pass over
+ * the read bytes on the device before the search.  `packed`: two bits per symbol, (byte >> 1) & 3 (A C T G = 0 1 2 3), symbol i of the
+ * concatenation reads[offsets[0] ..) in bits 2 (i & 15) of word i >> 4, (offsets[n_reads] + 15) / 16 words; offsets[0] must be 0.  Reads that hold
+ * any other byte are listed -- side_ids ascending, their bytes as they are concatenated in side_bytes in list order -- and what the packed words
+ * say about them is ignored.  pgx_pack_reads produces all of it from a batch in the form pgx_batch_upload takes; results are the same bytes
+ * either way (tests/test_gpu_parity.py).  Replaces the same per-read loop: src/find_mems.cpp:94-139. */
+pgx_status pgx_batch_upload_packed(pgx_batch *b, const uint32_t *packed, const uint64_t *offsets, uint64_t n_reads, const uint64_t *side_ids,
+                                   const uint8_t *side_bytes, uint64_t n_side);
+/* Host side of it (no device needed): packs reads[offsets[0] .. offsets[n_reads]) into `packed` ((bytes + 15) / 16 words) on `threads` host
+ * threads (0 = half the cores, at most 16) and lists the reads with a byte outside A C G T (upper case) with their bytes.  *n_side / *n_side_bytes
+ * are always what the batch needs; PGX_ERR_NOMEM when that exceeds side_ids_cap / side_bytes_cap (upload such a batch as bytes). */
+pgx_status pgx_pack_reads(const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads, uint32_t threads, uint32_t *packed, uint64_t *side_ids,
+                          uint64_t side_ids_cap, uint8_t *side_bytes, uint64_t side_bytes_cap, uint64_t *n_side, uint64_t *n_side_bytes);
 /* Run find_all_mems (+ tag queries) for every read of the batch; results stay on the device.
  * (A run whose predecessor on this batch had the same shape is enqueued whole, with buffer sizes taken from that run and the
  * counts kept on the device, and synchronises once at the end: pgx_batch_spec_stats.)

@@ -129,6 +129,9 @@ __global__ void pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *reads
                                            const uint8_t *skip, const uint32_t *packed, uint32_t pk_words,
                                            uint32_t *ovf_base, uint64_t ovf_cap);
 __global__ void pgx_bad_chunks_kernel(const uint8_t *reads, uint64_t n_bytes, uint64_t *chunks, unsigned long long *count, uint64_t cap, uint32_t *packed);
+__global__ void pgx_unpack_reads_kernel(const uint32_t *packed, uint64_t n_chunks, uint8_t *reads);
+__global__ void pgx_side_reads_kernel(uint8_t *reads, const uint64_t *offsets, const uint64_t *side_ids, const uint64_t *side_off, const uint8_t *side_bytes, uint64_t n_side,
+                                      uint8_t *flags, pgx_heavy_item *list, unsigned long long *count);
 __global__ void pgx_classify_reads_kernel(const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads, const uint64_t *chunks, const unsigned long long *n_chunks,
                                           uint64_t cap, uint32_t *flag_words, pgx_heavy_item *list, unsigned long long *count);
 __global__ void pgx_first_ext_kernel(PgxDevImage img, uint4 *out); // out[byte] = {k, k', s, 0} of the full interval extended backward by byte; out[256 + byte]: by 0, then by byte

@@ -1132,3 +1132,79 @@ extern "C" pgx_status pgx_index_image_view(const pgx_index *h, int which, const 
     return PGX_OK;
     PGX_GUARD_END
 }
+
+// ------------------------------------------------------------------------------------------
+// Host-side packing of a batch of reads for pgx_batch_upload_packed: two bits per symbol, 16 symbols per word ((byte >> 1) & 3: A C T G =
+// 0 1 2 3, symbol i of the concatenation in bits 2 (i & 15) of word i >> 4 -- what pgx_bad_chunks_kernel writes when the reads arrive as
+// bytes), and the list of reads that hold any other byte, whose bytes travel as they are.
+namespace {
+// eight bytes -> eight codes in 16 bits; bad = nonzero where a byte is not one of A C G T (upper case)
+inline uint32_t pack8(uint64_t x, uint64_t &bad) {
+    const uint64_t c = (x >> 1) & 0x0303030303030303ull;
+    const uint64_t b0 = c & 0x0101010101010101ull, b1 = (c >> 1) & 0x0101010101010101ull;
+    const uint64_t recon = 0x4141414141414141ull + 2 * (b0 & ~b1) + 0x13 * (b1 & ~b0) + 6 * (b0 & b1);
+    bad = x ^ recon;
+    uint64_t t = (c | (c >> 6)) & 0x000F000F000F000Full;
+    t = (t | (t >> 12)) & 0x000000FF000000FFull;
+    t = (t | (t >> 24)) & 0xFFFFull;
+    return (uint32_t)t;
+}
+} // namespace
+
+extern "C" pgx_status pgx_pack_reads(const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads, uint32_t threads, uint32_t *packed,
+                                     uint64_t *side_ids, uint64_t side_ids_cap, uint8_t *side_bytes, uint64_t side_bytes_cap, uint64_t *n_side,
+                                     uint64_t *n_side_bytes) {
+    PGX_GUARD_BEGIN
+    if (!offsets || !n_side || !n_side_bytes || (n_reads && offsets[n_reads] != offsets[0] && (!reads || !packed)))
+        throw Error(PGX_ERR_ARG, "pgx_pack_reads: null argument");
+    const uint64_t lo = offsets[0], n_bytes = offsets[n_reads] - lo, n_chunks = (n_bytes + 15) >> 4;
+    const uint8_t *src = reads + lo;
+    if (threads == 0) threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 2));
+    threads = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(threads, n_chunks / 65536 + 1));
+    std::vector<std::vector<uint64_t>> bad_chunks(threads); // chunks with a byte outside A C G T, per slice, ascending
+    auto slice = [&](uint32_t t) {
+        const uint64_t c0 = n_chunks * t / threads, c1 = n_chunks * (t + 1) / threads;
+        for (uint64_t c = c0; c < c1; c++) {
+            uint64_t x0 = 0, x1 = 0, b0, b1;
+            const uint64_t at = c << 4, left = n_bytes - at;
+            if (left >= 16) { std::memcpy(&x0, src + at, 8); std::memcpy(&x1, src + at + 8, 8); }
+            else { uint8_t tmp[16] = {0}; std::memcpy(tmp, src + at, (size_t)left); std::memcpy(&x0, tmp, 8); std::memcpy(&x1, tmp + 8, 8); }
+            const uint32_t p0 = pack8(x0, b0), p1 = pack8(x1, b1);
+            packed[c] = p0 | (p1 << 16);
+            if (left < 8) { b0 &= (1ull << (8 * left)) - 1ull; b1 = 0; }
+            else if (left < 16) b1 &= (1ull << (8 * (left - 8))) - 1ull;
+            if (b0 | b1) bad_chunks[t].push_back(c);
+        }
+    };
+    if (threads == 1) slice(0);
+    else {
+        std::vector<std::thread> th;
+        for (uint32_t t = 0; t < threads; t++) th.emplace_back(slice, t);
+        for (auto &x : th) x.join();
+    }
+    // the reads those bytes belong to (ascending, each once): chunks and reads are both in order, one forward walk
+    uint64_t ns = 0, nb = 0, rid = 0;
+    bool overflow = false;
+    uint64_t last = ~0ull;
+    for (uint32_t t = 0; t < threads; t++)
+        for (uint64_t c : bad_chunks[t]) {
+            const uint64_t at = c << 4, end = std::min(n_bytes, at + 16);
+            for (uint64_t p = at; p < end; p++) {
+                const uint8_t ch = src[p];
+                if (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') continue;
+                while (offsets[rid + 1] - lo <= p) rid++; // (p < n_bytes: some read holds it)
+                if (rid == last) continue;
+                last = rid;
+                const uint64_t len = offsets[rid + 1] - offsets[rid];
+                if (ns < side_ids_cap && nb + len <= side_bytes_cap && side_ids && side_bytes) {
+                    side_ids[ns] = rid;
+                    std::memcpy(side_bytes + nb, reads + offsets[rid], (size_t)len);
+                } else overflow = true;
+                ns++; nb += len;
+            }
+        }
+    *n_side = ns; *n_side_bytes = nb; // (what the batch needs, whether or not it fitted)
+    if (overflow) throw Error(PGX_ERR_NOMEM, "pgx_pack_reads: the side list does not fit the caller's buffers (upload the reads as bytes instead)");
+    return PGX_OK;
+    PGX_GUARD_END
+}

@@ -1009,6 +1009,44 @@ pgx_classify_reads_kernel(const uint8_t *__restrict__ reads, const uint64_t *__r
     }
 }
 
+// Reads that arrive packed (pgx_batch_upload_packed: two bits per symbol from the host, a quarter of the bytes over the link): back to bytes for the
+// kernels that read bytes ("ACTG"[code]; one packed word = 16 symbols per thread, one 16-byte store) ...
+__global__ void __launch_bounds__(256)
+pgx_unpack_reads_kernel(const uint32_t *__restrict__ packed, uint64_t n_chunks, uint8_t *__restrict__ reads) {
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t w = packed[c];
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v |= ((0x47544341u >> (8u * ((w >> (2 * (4 * q + k))) & 3u))) & 0xFFu) << (8 * k);
+            o[q] = v;
+        }
+        *reinterpret_cast<uint4 *>(reads + (c << 4)) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+// ... and the reads that hold a byte outside A C G T, which the host lists with their bytes as they are: copied over what the packed words gave,
+// flagged for the two-step kernel to skip and listed for the kernel that serves them (what pgx_bad_chunks_kernel + pgx_classify_reads_kernel
+// find on the device when the reads arrive as bytes).  One 64-lane wave per listed read.
+__global__ void __launch_bounds__(256)
+pgx_side_reads_kernel(uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ side_ids, const uint64_t *__restrict__ side_off,
+                      const uint8_t *__restrict__ side_bytes, uint64_t n_side, uint8_t *__restrict__ flags, pgx_heavy_item *__restrict__ list,
+                      unsigned long long *__restrict__ count) {
+    const uint64_t k = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (k >= n_side) return;
+    const uint64_t rid = side_ids[k], dst = offsets[rid], len = offsets[rid + 1] - dst, src = side_off[k];
+    for (uint64_t i = lane; i < len; i += 64) reads[dst + i] = side_bytes[src + i];
+    if (lane == 0) {
+        flags[rid] = 1;
+        pgx_heavy_item it;
+        it.rid = rid; it.x = 0; it.nm = 0;
+        list[k] = it;
+        if (k == 0) *count = n_side;
+    }
+}
+
 // find_all_mems over the PAIRS image (pgx_image.h): the loop of pgx_find_mems_kernel, but a trip reads ONE 128-byte block that
 // answers both ends of an interval (p1 within the block of p0; otherwise the interval runs on into the next block, which takes a
 // second trip) and, where the stage has two more symbols to go, performs BOTH extensions from it.  With (c1, c2) the pair at a

@@ -1020,7 +1020,9 @@ struct pgx_batch {
     hipEvent_t ev_side[2] = {nullptr, nullptr};
     bool class_valid = false, class_ok = false; // read_flags / side_list / side_count describe the uploaded reads (ok: few enough such reads to list)
     uint64_t n_reads = 0, read_bytes = 0;
-    std::vector<uint64_t> h_offsets; // rebased host copy (chunk planning)
+    HostBuf h_off[2];                // rebased host copy of the offsets (chunk planning; pinned: its upload runs at link speed), and the one being filled
+    int h_off_cur = 0;
+    const uint64_t *h_offsets() const { return h_off[h_off_cur].as<uint64_t>(); }
     std::vector<pgx_chunk> chunks;   // plan of the last run (reused while min_len / budget are unchanged)
     bool plan_valid = false, slot_off_valid = false;
     uint64_t slot_off_min_len = 0;
@@ -1028,6 +1030,10 @@ struct pgx_batch {
     DevBuf reads, offsets;
     // run state
     DevBuf slot_off, slots, mem_count, mem_off, mems, scan_tmp, counters, heavy_list, heavy_scratch, read_flags, side_list, side_count, packed, ovf_base;
+    DevBuf up_side_ids, up_side_off, up_side_bytes; // pgx_batch_upload_packed: the listed reads as they arrive
+    std::vector<uint64_t> h_side_off;
+    hipEvent_t ev_up[2] = {nullptr, nullptr};        // around the device passes of an upload
+    float ms_upload_passes = 0;                      // device time of the passes this upload needed before its first find_mems launch (pgx_timing.ms_per_upload adds the run's own)
     uint64_t last_ovf_used = 0; // arena slots the last run handed out (sizes the next arena)
     uint64_t max_read_len = 0; // longest read of the upload (sizes the LDS columns of the packed pairs kernel)
     TagWork tw;
@@ -1041,7 +1047,7 @@ struct pgx_batch {
     // host copies
     HostBuf h_mem_off, h_mems, h_run_nums, h_pos_off, h_positions;
     // timing
-    hipEvent_t ev[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // [8]: behind the first find_mems launch
+    hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // [8]: behind the first find_mems launch; [9]: before it, behind the passes a fresh upload needs
     bool timed = false;
     pgx_timing timing{};
 };
@@ -1050,16 +1056,19 @@ static void batch_release(pgx_batch *b) {
     if (!b) return;
     if (hipSetDevice(b->device) == hipSuccess) {
         DevBuf *all[] = {&b->reads, &b->offsets, &b->slot_off, &b->slots, &b->mem_count, &b->mem_off, &b->mems, &b->scan_tmp,
-                         &b->counters, &b->heavy_list, &b->heavy_scratch, &b->read_flags, &b->side_list, &b->side_count, &b->packed, &b->ovf_base};
+                         &b->counters, &b->heavy_list, &b->heavy_scratch, &b->read_flags, &b->side_list, &b->side_count, &b->packed, &b->ovf_base,
+                         &b->up_side_ids, &b->up_side_off, &b->up_side_bytes};
         for (DevBuf *d : all) d->release();
         b->tw.release();
-        HostBuf *hb[] = {&b->h_mem_off, &b->h_mems, &b->h_run_nums, &b->h_pos_off, &b->h_positions};
+        HostBuf *hb[] = {&b->h_mem_off, &b->h_mems, &b->h_run_nums, &b->h_pos_off, &b->h_positions, &b->h_off[0], &b->h_off[1]};
         for (HostBuf *x : hb) x->release();
         for (auto &e : b->ev)
             if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (b->own) { (void)hipStreamDestroy(b->own); b->own = nullptr; }
         if (b->side) { (void)hipStreamDestroy(b->side); b->side = nullptr; }
         for (auto &e : b->ev_side)
+            if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        for (auto &e : b->ev_up)
             if (e) { (void)hipEventDestroy(e); e = nullptr; }
     }
     delete b;
@@ -1068,27 +1077,101 @@ static void batch_release(pgx_batch *b) {
 extern "C" void pgx_batch_free(pgx_batch *b) { batch_release(b); }
 
 // (re)fill a batch: device buffers only ever grow, so a long-lived batch costs no allocation per call
-static void batch_upload(pgx_batch *b, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads) {
+// offsets: validated, rebased to 0 (host copy for the chunk planner, device copy for the kernels), longest read -- one pass over them
+static void batch_take_offsets(pgx_batch *b, const uint64_t *offsets, uint64_t n_reads, const char *who) {
+    const uint64_t lo = offsets[0];
+    HostBuf &hb = b->h_off[b->h_off_cur ^ 1]; // (swapped in once the offsets have proved valid: a refused upload leaves the batch as it was)
+    hb.ensure((n_reads + 1) * 8);
+    uint64_t *ho = hb.as<uint64_t>();
+    uint64_t longest = 0, prev = lo;
+    ho[0] = 0;
+    for (uint64_t i = 1; i <= n_reads; i++) {
+        const uint64_t o = offsets[i];
+        if (o < prev) throw Error(PGX_ERR_ARG, std::string(who) + ": offsets must be non-decreasing");
+        longest = std::max(longest, o - prev);
+        ho[i] = o - lo;
+        prev = o;
+    }
+    if (longest >= (1ull << 31)) throw Error(PGX_ERR_UNSUPPORTED, "read longer than 2^31 bytes");
+    b->h_off_cur ^= 1;
     b->n_reads = n_reads;
     b->ran = b->ran_tags = false;
     b->plan_valid = false;
     b->slot_off_valid = false;
     b->class_valid = false;
-    const uint64_t lo = offsets[0], hi = offsets[n_reads];
-    b->read_bytes = hi - lo;
-    // device offsets are rebased to 0; 16 bytes of zero padding after the last read
+    b->ms_upload_passes = 0;
+    b->max_read_len = longest;
+    b->read_bytes = offsets[n_reads] - lo;
+    b->offsets.ensure((n_reads + 1) * 8);
+    HIPCHECK(hipMemcpyAsync(b->offsets.p, ho, (n_reads + 1) * 8, hipMemcpyHostToDevice, b->own));
+}
+
+static void batch_upload(pgx_batch *b, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads) {
+    batch_take_offsets(b, offsets, n_reads, "pgx_batch_upload");
+    // device offsets are rebased to 0; 32 bytes of zero padding after the last read
     // copies go through the batch's own non-blocking stream: batches of other host threads (other streams of the same device)
     // are not serialised behind them the way copies on the legacy default stream would be
     b->reads.ensure(b->read_bytes + 32);
     HIPCHECK(hipMemsetAsync((uint8_t *)b->reads.p + b->read_bytes, 0, 32, b->own));
-    if (b->read_bytes) HIPCHECK(hipMemcpyAsync(b->reads.p, reads + lo, b->read_bytes, hipMemcpyHostToDevice, b->own));
-    b->h_offsets.resize(n_reads + 1);
-    for (uint64_t i = 0; i <= n_reads; i++) b->h_offsets[i] = offsets[i] - lo;
-    b->max_read_len = 0;
-    for (uint64_t i = 0; i < n_reads; i++) b->max_read_len = std::max(b->max_read_len, offsets[i + 1] - offsets[i]);
-    b->offsets.ensure((n_reads + 1) * 8);
-    HIPCHECK(hipMemcpyAsync(b->offsets.p, b->h_offsets.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, b->own));
+    if (b->read_bytes) HIPCHECK(hipMemcpyAsync(b->reads.p, reads + offsets[0], b->read_bytes, hipMemcpyHostToDevice, b->own));
     HIPCHECK(hipStreamSynchronize(b->own));
+}
+
+// the reads as the host packed them (pgx_pack_reads): a quarter of the bytes over the link, and neither pgx_bad_chunks_kernel nor
+// pgx_classify_reads_kernel nor their read-back on the device -- the packed words, the flags and the side list the two-step kernel wants arrive
+// ready; the bytes the other kernels read are rebuilt on the device (pgx_unpack_reads_kernel + the listed reads' own bytes over them)
+static void batch_upload_packed(pgx_batch *b, const uint32_t *packed, const uint64_t *offsets, uint64_t n_reads, const uint64_t *side_ids,
+                                const uint8_t *side_bytes, uint64_t n_side) {
+    if (offsets[0] != 0) throw Error(PGX_ERR_ARG, "pgx_batch_upload_packed: offsets[0] must be 0 (word w of the packed stream holds symbols 16 w .. 16 w + 15)");
+    batch_take_offsets(b, offsets, n_reads, "pgx_batch_upload_packed");
+    if (n_side > n_reads) throw Error(PGX_ERR_ARG, "pgx_batch_upload_packed: more listed reads than reads");
+    b->h_side_off.resize(n_side + 1);
+    b->h_side_off[0] = 0;
+    for (uint64_t k = 0; k < n_side; k++) {
+        const uint64_t r = side_ids[k];
+        if (r >= n_reads || (k && r <= side_ids[k - 1])) throw Error(PGX_ERR_ARG, "pgx_batch_upload_packed: listed read ids must ascend and lie inside the batch");
+        b->h_side_off[k + 1] = b->h_side_off[k] + (offsets[r + 1] - offsets[r]);
+    }
+    const uint64_t n_chunks = (b->read_bytes + 15) >> 4, side_total = b->h_side_off[n_side];
+    hipStream_t s = b->own;
+    b->packed.ensure((n_chunks + 64) * 4);
+    b->reads.ensure(n_chunks * 16 + 32);
+    b->read_flags.ensure(((n_reads + 3) & ~3ull) + 4);
+    b->side_list.ensure((n_reads ? n_reads : 1) * sizeof(pgx_heavy_item));
+    b->side_count.ensure(16);
+    if (n_chunks) HIPCHECK(hipMemcpyAsync(b->packed.p, packed, n_chunks * 4, hipMemcpyHostToDevice, s));
+    if (n_side) {
+        b->up_side_ids.ensure(n_side * 8);
+        b->up_side_off.ensure((n_side + 1) * 8);
+        b->up_side_bytes.ensure(side_total ? side_total : 1);
+        HIPCHECK(hipMemcpyAsync(b->up_side_ids.p, side_ids, n_side * 8, hipMemcpyHostToDevice, s));
+        HIPCHECK(hipMemcpyAsync(b->up_side_off.p, b->h_side_off.data(), (n_side + 1) * 8, hipMemcpyHostToDevice, s));
+        if (side_total) HIPCHECK(hipMemcpyAsync(b->up_side_bytes.p, side_bytes, side_total, hipMemcpyHostToDevice, s));
+    }
+    for (auto &e : b->ev_up)
+        if (!e) HIPCHECK(hipEventCreate(&e));
+    HIPCHECK(hipEventRecord(b->ev_up[0], s));
+    HIPCHECK(hipMemsetAsync(b->side_count.p, 0, 16, s));
+    HIPCHECK(hipMemsetAsync(b->read_flags.p, 0, ((n_reads + 3) & ~3ull) + 4, s));
+    if (n_chunks) {
+        int cus = 0;
+        HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
+        hipLaunchKernelGGL(pgx_unpack_reads_kernel, dim3(std::min<unsigned>(grid_for(n_chunks, 256), (unsigned)cus * 16u)), dim3(256), 0, s, b->packed.as<uint32_t>(), n_chunks,
+                           b->reads.as<uint8_t>());
+        HIPCHECK(hipGetLastError());
+    }
+    HIPCHECK(hipMemsetAsync((uint8_t *)b->reads.p + b->read_bytes, 0, 32, s)); // (the tail of the last word unpacks to 'A's)
+    if (n_side) {
+        hipLaunchKernelGGL(pgx_side_reads_kernel, dim3(grid_for(n_side * 64, 256)), dim3(256), 0, s, b->reads.as<uint8_t>(), b->offsets.as<uint64_t>(), b->up_side_ids.as<uint64_t>(),
+                           b->up_side_off.as<uint64_t>(), b->up_side_bytes.as<uint8_t>(), n_side, b->read_flags.as<uint8_t>(), b->side_list.as<pgx_heavy_item>(),
+                           b->side_count.as<unsigned long long>());
+        HIPCHECK(hipGetLastError());
+    }
+    HIPCHECK(hipEventRecord(b->ev_up[1], s));
+    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(hipEventElapsedTime(&b->ms_upload_passes, b->ev_up[0], b->ev_up[1]));
+    b->class_valid = true; // what pgx_batch_run would otherwise find out with two passes over the bytes and a read-back
+    b->class_ok = true;
 }
 
 extern "C" pgx_status pgx_batch_create(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets,
@@ -1098,10 +1181,6 @@ extern "C" pgx_status pgx_batch_create(pgx_index *h, int device, const uint8_t *
         throw Error(PGX_ERR_ARG, "pgx_batch_create: null argument");
     if (!h->has_rank) throw Error(PGX_ERR_ARG, "pgx_batch_create: index opened without an r-index");
     *out = nullptr;
-    for (uint64_t i = 0; i < n_reads; i++) {
-        if (offsets[i + 1] < offsets[i]) throw Error(PGX_ERR_ARG, "pgx_batch_create: offsets must be non-decreasing");
-        if (offsets[i + 1] - offsets[i] >= (1ull << 31)) throw Error(PGX_ERR_UNSUPPORTED, "read longer than 2^31 bytes");
-    }
     pgx_device_image *dimg = device_image(h, device);
     std::unique_ptr<pgx_batch, void (*)(pgx_batch *)> b(new pgx_batch(), batch_release);
     b->h = h;
@@ -1118,19 +1197,28 @@ extern "C" pgx_status pgx_batch_upload(pgx_batch *b, const uint8_t *reads, const
     PGX_GUARD_BEGIN
     RoctxRange range("pgx_batch_upload");
     if (!b || !offsets || (!reads && n_reads && offsets[n_reads] != offsets[0])) throw Error(PGX_ERR_ARG, "pgx_batch_upload: null argument");
-    for (uint64_t i = 0; i < n_reads; i++) {
-        if (offsets[i + 1] < offsets[i]) throw Error(PGX_ERR_ARG, "pgx_batch_upload: offsets must be non-decreasing");
-        if (offsets[i + 1] - offsets[i] >= (1ull << 31)) throw Error(PGX_ERR_UNSUPPORTED, "read longer than 2^31 bytes");
-    }
     use_device(b->device);
     batch_upload(b, reads, offsets, n_reads);
     return PGX_OK;
     PGX_GUARD_END
 }
 
+extern "C" pgx_status pgx_batch_upload_packed(pgx_batch *b, const uint32_t *packed, const uint64_t *offsets, uint64_t n_reads, const uint64_t *side_ids,
+                                              const uint8_t *side_bytes, uint64_t n_side) {
+    PGX_GUARD_BEGIN
+    RoctxRange range("pgx_batch_upload_packed");
+    if (!b || !offsets || (!packed && n_reads && offsets[n_reads] != offsets[0]) || (n_side && (!side_ids || !side_bytes)))
+        throw Error(PGX_ERR_ARG, "pgx_batch_upload_packed: null argument");
+    use_device(b->device);
+    batch_upload_packed(b, packed, offsets, n_reads, side_ids, side_bytes, n_side);
+    return PGX_OK;
+    PGX_GUARD_END
+}
+
 static void record(pgx_batch *b, int i, hipStream_t s) {
-    static const char *const stage[9] = {"pgx: run begins (classify, sizing)", "pgx: find_mems launches follow", "pgx: find_mems enqueued", "pgx: compaction enqueued",
-                                         "pgx: tag locate enqueued", "pgx: tag gather enqueued", "pgx: tag sort/unique enqueued", "pgx: run enqueued", "pgx: main find_mems kernel enqueued"};
+    static const char *const stage[10] = {"pgx: run begins (classify, sizing)", "pgx: find_mems launches follow", "pgx: find_mems enqueued", "pgx: compaction enqueued",
+                                          "pgx: tag locate enqueued", "pgx: tag gather enqueued", "pgx: tag sort/unique enqueued", "pgx: run enqueued", "pgx: main find_mems kernel enqueued",
+                                          "pgx: per-upload passes enqueued"};
     if (roctx().on) roctx().mark(stage[i]);
     if (!b->timed) return;
     if (!b->ev[i]) HIPCHECK(hipEventCreate(&b->ev[i]));
@@ -1173,7 +1261,9 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     // 1. worst-case MEM slots per read: cap = min(len, len - min_len + 1).  The slot buffer is bounded by
     //    a budget; batches whose worst case exceeds it are processed in chunks of consecutive reads.
     b->slot_off.ensure((n + 1) * 8);
+    bool fresh_work = false; // this run performs passes only the first run after an upload needs (pgx_timing.ms_per_upload)
     if (!b->slot_off_valid || b->slot_off_min_len != min_len) { // depends on the reads and min_len only: kept across runs
+        fresh_work = true;
         scan_excl(2, b->offsets.p, n, min_len, b->slot_off.as<uint64_t>(), b->scan_tmp, s);
         b->slot_off_valid = true;
         b->slot_off_min_len = min_len;
@@ -1195,7 +1285,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         if (n && b->read_bytes <= budget_slots) b->chunks.push_back({0, n, 0, std::max<uint64_t>(b->read_bytes, 1)});
         else {
             for (uint64_t i = 0; i < n; i++) {
-                const uint64_t len = b->h_offsets[i + 1] - b->h_offsets[i];
+                const uint64_t len = b->h_offsets()[i + 1] - b->h_offsets()[i];
                 const uint64_t cap = len < min_len ? 0 : std::min<uint64_t>(len, len - min_len + 1);
                 if (acc && acc + cap > budget_slots) { b->chunks.push_back({r0, i, base, acc}); r0 = i; base += acc; acc = 0; }
                 acc += cap;
@@ -1335,6 +1425,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                         for (auto &e : b->ev_side) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
                     }
                     if (!b->class_valid) { // once per upload: two small passes and one scalar read back
+                        fresh_work = true;
                         const uint64_t cap = std::max<uint64_t>(cn, 1024); // chunks with such a byte; beyond that (lower-case reads, say) no side launch
                         b->read_flags.ensure(((cn + 3) & ~3ull) + 4);
                         b->side_list.ensure((cn ? cn : 1) * sizeof(pgx_heavy_item));
@@ -1359,6 +1450,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                         }
                         b->class_valid = true;
                     }
+                  record(b, 9, s);
                   if (b->class_ok) {
                     a_skip = b->read_flags.as<uint8_t>();
                     HIPCHECK(hipEventRecord(b->ev_side[0], s));
@@ -1537,7 +1629,10 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             b->timing.ms_tag_sort = el(5, 6);   // big path + final scan + compaction
         }
         b->timing.ms_total = el(0, 7);
+        // what a fresh batch pays before its first find_mems launch (one chunk on the side-stream path: where the passes are)
+        if (fresh_work) b->timing.ms_per_upload = b->ms_upload_passes + ((chunks.size() == 1 && b->ev[9] && kfn_pairs && !std::getenv("PGX_FM_NO_SIDE")) ? el(0, 9) : 0.0f);
     }
+    if (fresh_work) b->ms_upload_passes = 0; // (reported once)
     break;
     } // (speculative pass, then at most one exact pass)
     b->ran = true;

@@ -94,6 +94,11 @@ struct Job { // one batch of consecutive reads
     uint64_t id = 0, first_seq = 0; // batch number, reads before it in the file
     ReadBuf cat;
     std::vector<uint64_t> offs;
+    // the same reads packed to two bits per symbol by the parse thread (pgx_pack_reads): [packed words | bytes of the reads with a byte outside A C G T]
+    ReadBuf pk;
+    std::vector<uint64_t> side_ids;
+    uint64_t n_side = 0, side_at = 0;
+    bool packed = false;
 };
 struct Done {
     std::vector<std::string> outs, errs; // text pieces in read order
@@ -258,6 +263,7 @@ int main(int argc, char **argv) {
 
     // a range -> the reads it holds, concatenated, with offsets; empty lines are skipped (:97); a last line without a newline counts (std::getline)
     ReadBufPool pool;
+    const bool use_packed = !(std::getenv("PGX_CLI_PACKED") && std::getenv("PGX_CLI_PACKED")[0] == '0');
     auto parse_range = [&](uint64_t id) {
         std::unique_ptr<Job> j(new Job());
         const char *q = mf.p + ranges[id].first, *end = mf.p + ranges[id].second;
@@ -273,6 +279,18 @@ int main(int argc, char **argv) {
             q += len + 1;
         }
         j->cat.len = (size_t)(dst - j->cat.p);
+        // packed for the upload: a quarter of the bytes over the link and no pass over them on the device (PGX_CLI_PACKED=0: bytes as they are)
+        if (use_packed && j->offs.size() > 1) {
+            const size_t words = (j->cat.len + 15) / 16, side_cap = j->cat.len / 8 + 4096;
+            j->pk = pool.get(words * 4 + side_cap);
+            j->side_at = words * 4;
+            j->side_ids.resize(side_cap / 64 + 64);
+            uint64_t n_side = 0, n_side_bytes = 0;
+            const pgx_status st = pgx_pack_reads(reinterpret_cast<const uint8_t *>(j->cat.p), j->offs.data(), j->offs.size() - 1, 1, reinterpret_cast<uint32_t *>(j->pk.p),
+                                                 j->side_ids.data(), j->side_ids.size(), reinterpret_cast<uint8_t *>(j->pk.p) + j->side_at, side_cap, &n_side, &n_side_bytes);
+            if (st == PGX_OK) { j->packed = true; j->n_side = n_side; }
+            else { pool.put(j->pk); j->pk = ReadBuf(); } // (too many such reads for the side list: this batch travels as bytes)
+        }
         return j;
     };
     // PGX_CLI_STATS=1: busy seconds of every stage (summed over its threads) on stderr at the end
@@ -335,7 +353,14 @@ int main(int argc, char **argv) {
             pgx_result r;
             const uint8_t *rp = reinterpret_cast<const uint8_t *>(j->cat.p);
             uint64_t t0 = now_ns();
-            pgx_status st = b ? pgx_batch_upload(b, rp, j->offs.data(), n) : pgx_batch_create(h, device, rp, j->offs.data(), n, &b);
+            pgx_status st = PGX_OK;
+            if (j->packed) {
+                static const uint64_t no_offsets[1] = {0};
+                if (!b) st = pgx_batch_create(h, device, nullptr, no_offsets, 0, &b);
+                if (st == PGX_OK)
+                    st = pgx_batch_upload_packed(b, reinterpret_cast<const uint32_t *>(j->pk.p), j->offs.data(), n, j->side_ids.data(),
+                                                 reinterpret_cast<const uint8_t *>(j->pk.p) + j->side_at, j->n_side);
+            } else st = b ? pgx_batch_upload(b, rp, j->offs.data(), n) : pgx_batch_create(h, device, rp, j->offs.data(), n, &b);
             uint64_t t1 = now_ns();
             if (st == PGX_OK) st = pgx_batch_run(b, mem_length, min_occ, PGX_RUN_TAGS | PGX_RUN_TIMING, nullptr);
             uint64_t t2 = now_ns();
@@ -344,6 +369,8 @@ int main(int argc, char **argv) {
             ns_upload += t1 - t0; ns_run += t2 - t1; ns_download += t3 - t2;
             pool.put(j->cat); // (the upload has completed: pgx_batch_upload synchronises its copies)
             j->cat = ReadBuf();
+            pool.put(j->pk);
+            j->pk = ReadBuf();
             if (st != PGX_OK) d->error = pgx_last_error();
             else {
                 pgx_timing t;

@@ -163,3 +163,52 @@ def test_cooperative_line_fetches_against_the_oracle(wide_case, monkeypatch, wid
             assert np.array_equal(res["pos_offsets"], ref["pos_offsets"]) and np.array_equal(res["positions"], ref["positions"])
         b.free()
     idx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wide", [1, 0])
+def test_every_extension_through_the_other_image(workdir, monkeypatch, wide):
+    """The product twin of the round-3 rank primitive that looped over probes (DESIGN.md "stale counts"): the rolled two-probe loop the pairs kernel
+    takes when its own block cannot answer (pgx_kernels.hip, `bail`).  A text with an N at every twentieth position flags EVERY block of the PAIRS
+    image (some position of each has N as first or second symbol), so every extension behind a stage's first goes through that loop -- 64-bit
+    (pgx_dense2w_rank, superblock bases) and narrow --, in a launch of hundreds of workgroups, every run twice, against the oracle."""
+    rng = np.random.default_rng(123)
+    text = os.path.join(workdir, "n_rich.txt")
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    base = acgt[rng.integers(0, 4, 40_000)].copy()
+    with open(text, "wb") as f:
+        for h in range(3):
+            s = base.copy()
+            m = rng.random(len(s)) < 0.01
+            s[m] = acgt[rng.integers(0, 4, int(m.sum()))]
+            s[rng.random(len(s)) < 0.05] = ord("N")
+            f.write(s.tobytes() + b"\n")
+            f.write(W._COMP[s[::-1]].tobytes() + b"\n")
+    ri_path, tags_path = W.build_index_from_text(text, workdir, "n_rich")[:2]
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    assert ri.sigma == 6
+    seqs = W.load_sequences(text)
+    cat, offs = W.sample_reads(seqs, 60_000, 150, seed=4)
+    isn = cat == ord("N")
+    cat = cat.copy()
+    cat[isn] = acgt[rng.integers(0, 4, int(isn.sum()))]  # pure A C G T: every read stays with the pairs kernel
+    monkeypatch.setenv("PGX_SEED_K", "6")
+    monkeypatch.setenv("PGX_SB_SHIFT", "3")
+    idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | P.MODE_IMAGE_PAIRS | (P.MODE_IMAGE_WIDE if wide else 0))
+    assert idx.info().image_pairs == 1 and idx.info().image_wide == wide
+    pv = idx.image_view(20).view(np.uint32).reshape(-1, 32)
+    assert (pv[:-1, 16] >> 31).all()  # every block that holds a position is flagged
+    for min_len, min_occ in ((8, 1), (11, 2)):
+        ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, threads=O.lib().orc_max_threads())
+        b = idx.batch(cat, offs)
+        for _ in range(2):
+            b.run(min_len, min_occ, P.RUN_TAGS | P.RUN_TIMING)
+            t = b.timing()
+            assert t.pairs_reads == 2 and t.pairs_other_steps > 10 * (len(offs) - 1)  # the two-step kernel ran, and took its extensions through the other image
+            res = b.result()
+            assert np.array_equal(res["mem_offsets"], ref["mem_offsets"]), (wide, min_len, min_occ)
+            assert res["mems"].tobytes() == ref["mems"].tobytes()
+            assert res["n_extensions"] == ref["n_extensions"]
+            assert np.array_equal(res["pos_offsets"], ref["pos_offsets"]) and np.array_equal(res["positions"], ref["positions"])
+        b.free()
+    idx.close()
