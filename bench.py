@@ -183,8 +183,28 @@ def make_workload(args, workload, rank, wd, barrier, n_reads, base_len):
         desc = "synthetic pangenome: %d bp base x %d haplotypes x 2 strands, sigma=6" % (base_len, args.haps)
         if workload == "chr22":
             desc += " (chr22-scale, SURVEY 8d config 3 = BASELINE configs[2])"
-    cat, offs = W.sample_reads(seqs, n_reads, args.read_len, seed=seed + 1000 * rank, n_frac=args.n_read_frac if workload != "x" else None)
+    nf = args.n_read_frac if workload != "x" else None
+    strong = getattr(args, "scaling", "weak") == "strong"
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # weak: every rank samples its own n_reads; strong (BASELINE configs[3] as worded): ONE batch of n_reads, the same on every rank, cut into
+    # contiguous slices (make_slice below)
+    cat, offs = W.sample_reads(seqs, n_reads, args.read_len, seed=seed + (0 if strong else 1000 * rank), n_frac=nf)
+    if strong and world > 1:
+        cat, offs = strong_slice(cat, offs, rank, world)
+
+    def resample(k):  # further batches of the same shape (fresh_batch rotates over three)
+        return W.sample_reads(seqs, len(offs) - 1, args.read_len, seed=seed + 1000 * rank + 7919 * k, n_frac=nf)
+
+    make_workload.resample = resample
     return ri, tags, cat, offs, desc, build_s
+
+
+def strong_slice(cat, offs, rank, world):
+    """the contiguous slice of one batch that `rank` of `world` serves (reads [n r / world, n (r + 1) / world)), offsets rebased to 0"""
+    n = len(offs) - 1
+    lo, hi = n * rank // world, n * (rank + 1) // world
+    o = offs[lo:hi + 1]
+    return cat[int(o[0]):int(o[-1])], o - o[0]
 
 
 def measure(P, idx, cat, offs, local, min_len, min_occ, flags, steps, warmup, stream, sync, barrier):
@@ -530,12 +550,29 @@ def main():
             dist.barrier()
 
     if args.stub_workload:  # launcher self-test (CPU tier): no GPU, the line still goes through the same reductions
+        import numpy as np
+
         ones = torch.ones(1, dtype=torch.float64)
         if use_dist:
             dist.all_reduce(ones)
+        # the reads every rank would serve: its own batch (weak) or its slice of the one batch (strong), with the slicing of the real workloads
+        offs = np.arange(args.reads + 1, dtype=np.uint64) * np.uint64(args.read_len)
+        cat = np.zeros(args.reads * args.read_len, dtype=np.uint8)
+        first = 0
+        if args.scaling == "strong" and world > 1:
+            first = args.reads * rank // world
+            cat, offs = strong_slice(cat, offs, rank, world)
+        mine = torch.tensor([float(len(offs) - 1), float(first), float(len(cat))], dtype=torch.float64)
+        allr = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
+        if use_dist:
+            dist.all_gather(allr, mine)
+        else:
+            allr = [mine]
         if rank == 0:
             print(json.dumps({"metric": "stub", "value": float(world), "unit": "ranks", "n_gpus": world, "n_ranks_seen": int(ones.item()),
-                              "steps": args.steps, "warmup": args.warmup}), flush=True)
+                              "steps": args.steps, "warmup": args.warmup, "scaling": args.scaling,
+                              "reads_per_rank": [int(t[0].item()) for t in allr], "first_read_per_rank": [int(t[1].item()) for t in allr],
+                              "read_bytes_per_rank": [int(t[2].item()) for t in allr]}), flush=True)
         if use_dist:
             dist.destroy_process_group()
         return
@@ -586,10 +623,14 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     tot = [float(v) for v in tot.tolist()]
 
+    # reads this step processed on all ranks (weak: n per rank; strong: the slices of one batch of n)
+    nloc = torch.tensor([float(len(offs) - 1)], dtype=torch.float64, device=red_dev)
+    if use_dist:
+        dist.all_reduce(nloc, op=dist.ReduceOp.SUM)
     parity_failed = False
     if rank == 0:
-        K, n = args.steps, args.reads
-        reads_total = n * world * K
+        K, n = args.steps, len(offs) - 1
+        reads_total = int(nloc.item()) * K
         kinds = {P.IMAGE_RL: "run-length blocks", P.IMAGE_DENSE: "dense bit planes", P.IMAGE_DENSE2: "dense2 bit planes"}
         image = (("LDS copy of " if info.image_in_lds else "") + kinds[info.image_kind] + (" + two-step pairs image (a 128-byte block of 96 positions every %d)" % info.pairs_stride if info.image_pairs else "")
                  + (" (64-bit form: counts as deltas against superblock bases)" if info.image_wide else ""))
@@ -603,7 +644,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
@@ -612,9 +653,10 @@ def main():
                              "synth": desc + ", %d reads per GPU" % n,
                              "wg": desc + " (n = %d), %d reads per GPU" % (info.bwt_size, n),
                              "x": "BASELINE configs[1]: x.rl_bwt index, %d synthetic %d-bp reads per GPU" % (n, args.read_len)}[args.workload],
-                "index": desc, "reads_per_gpu": n, "read_len": args.read_len, "min_len": args.min_len,
+                "index": desc, "reads_per_gpu": n, "reads_per_step_all_ranks": int(nloc.item()), "read_len": args.read_len, "min_len": args.min_len,
                 "min_occ": args.min_occ, "mode": args.mode, "tags": not args.no_tags, "n_read_frac": args.n_read_frac,
-                "sharding": "reads sharded by rank, index replicated, no collective",
+                "sharding": ("reads sharded by rank, index replicated, no collective" if args.scaling == "weak" else
+                             "ONE batch of %d reads cut into %d contiguous slices, one per rank (BASELINE configs[3] as worded), index replicated, no collective" % (args.reads, world)),
                 "bwt_size": int(info.bwt_size), "bwt_runs": int(info.n_runs), "image_in_lds": bool(info.image_in_lds),
                 "rank_image": "%s, %.1f MB%s" % (image, info.image_bytes / 1e6, "" if info.image_in_lds else
                                                  (", global memory (fits the 256 MB memory-side cache)" if info.image_bytes < 240e6 else ", resident in HBM")),
@@ -643,11 +685,24 @@ def main():
                 "note": "not the bench value: K steps over two resident batches of the same reads, each on its own stream with its own host thread (what "
                         "the CLI's device workers do with consecutive batches): one batch's compaction and tag stage run under the other's find_mems kernel",
             }
+        resident_result = None
         if world == 1 and not args.no_parity:
             # the measured configuration itself under the oracle: the result of the last timed step, downloaded, against the oracle on a prefix
             sample = min(n, args.parity_reads)
-            line["parity_sample"] = parity_sample(args, ri, None if args.no_tags else tags, cat, offs, args.min_len, batch.result(), sample, idx, local)
+            resident_result = batch.result()
+            line["parity_sample"] = parity_sample(args, ri, None if args.no_tags else tags, cat, offs, args.min_len, resident_result, sample, idx, local)
             parity_failed = parity_failed or not line["parity_sample"]["identical"]
+        if world == 1 and not args.no_fresh and args.steps >= 3:
+            # what a caller that brings a NEW batch every step gets (the bench value re-runs reads already resident in HBM)
+            hbs = [HostBatch(P, cat, offs)] + [HostBatch(P, *make_workload.resample(k)) for k in (1, 2)]
+            line["fresh_batch"] = fresh_record(P, idx, hbs, local, args, flags, torch.cuda.synchronize, resident_result, counts)
+            for key in ("packed", "bytes"):
+                if line["fresh_batch"][key]["identical_to_the_resident_batch"] is False:
+                    parity_failed = True
+            del hbs
+        resident_result = None
+        if world == 1 and args.batch_sweep:
+            line["batch_size_sweep"] = batch_size_sweep(P, idx, cat, offs, local, args, flags, stream, torch.cuda.synchronize)
     batch.free()
     idx.close()
     del cat, offs

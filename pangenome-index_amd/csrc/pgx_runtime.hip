@@ -1123,15 +1123,13 @@ static void batch_upload(pgx_batch *b, const uint8_t *reads, const uint64_t *off
 static void batch_upload_packed(pgx_batch *b, const uint32_t *packed, const uint64_t *offsets, uint64_t n_reads, const uint64_t *side_ids,
                                 const uint8_t *side_bytes, uint64_t n_side) {
     if (offsets[0] != 0) throw Error(PGX_ERR_ARG, "pgx_batch_upload_packed: offsets[0] must be 0 (word w of the packed stream holds symbols 16 w .. 16 w + 15)");
-    batch_take_offsets(b, offsets, n_reads, "pgx_batch_upload_packed");
     if (n_side > n_reads) throw Error(PGX_ERR_ARG, "pgx_batch_upload_packed: more listed reads than reads");
+    for (uint64_t k = 0; k < n_side; k++) // (before anything of the batch changes: a refused upload leaves it as it was)
+        if (side_ids[k] >= n_reads || (k && side_ids[k] <= side_ids[k - 1])) throw Error(PGX_ERR_ARG, "pgx_batch_upload_packed: listed read ids must ascend and lie inside the batch");
+    batch_take_offsets(b, offsets, n_reads, "pgx_batch_upload_packed");
     b->h_side_off.resize(n_side + 1);
     b->h_side_off[0] = 0;
-    for (uint64_t k = 0; k < n_side; k++) {
-        const uint64_t r = side_ids[k];
-        if (r >= n_reads || (k && r <= side_ids[k - 1])) throw Error(PGX_ERR_ARG, "pgx_batch_upload_packed: listed read ids must ascend and lie inside the batch");
-        b->h_side_off[k + 1] = b->h_side_off[k] + (offsets[r + 1] - offsets[r]);
-    }
+    for (uint64_t k = 0; k < n_side; k++) b->h_side_off[k + 1] = b->h_side_off[k] + (offsets[side_ids[k] + 1] - offsets[side_ids[k]]);
     const uint64_t n_chunks = (b->read_bytes + 15) >> 4, side_total = b->h_side_off[n_side];
     hipStream_t s = b->own;
     b->packed.ensure((n_chunks + 64) * 4);
@@ -1261,7 +1259,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
     // 1. worst-case MEM slots per read: cap = min(len, len - min_len + 1).  The slot buffer is bounded by
     //    a budget; batches whose worst case exceeds it are processed in chunks of consecutive reads.
     b->slot_off.ensure((n + 1) * 8);
-    bool fresh_work = false; // this run performs passes only the first run after an upload needs (pgx_timing.ms_per_upload)
+    bool fresh_work = false, fresh_mark = false; // this run performs passes only the first run after an upload needs (pgx_timing.ms_per_upload); event 9 recorded behind them
     if (!b->slot_off_valid || b->slot_off_min_len != min_len) { // depends on the reads and min_len only: kept across runs
         fresh_work = true;
         scan_excl(2, b->offsets.p, n, min_len, b->slot_off.as<uint64_t>(), b->scan_tmp, s);
@@ -1450,7 +1448,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                         }
                         b->class_valid = true;
                     }
-                  record(b, 9, s);
+                  record(b, 9, s); fresh_mark = true;
                   if (b->class_ok) {
                     a_skip = b->read_flags.as<uint8_t>();
                     HIPCHECK(hipEventRecord(b->ev_side[0], s));
@@ -1503,6 +1501,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
             } else { // (the pairs kernel serves every read of the launch itself: where its image cannot answer, it takes that extension through the other one)
                 void *args[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &a_cur, &a_first, &a_base,
                                 &a_hext, &a_hcap, &a_hlist, &a_hcount, &a_rlist, &a_rcount, &a_ovf, &a_ovf_cap};
+                if (ci == 0 && attempt == 0) { record(b, 9, s); fresh_mark = true; }
                 HIPCHECK(hipLaunchKernel(kf, dim3(grid), dim3(PGX_FM_THREADS), args, b->dimg->lds_bytes, s)); // one of the variants
                 record(b, 8, s);
             }
@@ -1630,7 +1629,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         }
         b->timing.ms_total = el(0, 7);
         // what a fresh batch pays before its first find_mems launch (one chunk on the side-stream path: where the passes are)
-        if (fresh_work) b->timing.ms_per_upload = b->ms_upload_passes + ((chunks.size() == 1 && b->ev[9] && kfn_pairs && !std::getenv("PGX_FM_NO_SIDE")) ? el(0, 9) : 0.0f);
+        if (fresh_work) b->timing.ms_per_upload = b->ms_upload_passes + (fresh_mark ? el(0, 9) : 0.0f);
     }
     if (fresh_work) b->ms_upload_passes = 0; // (reported once)
     break;

@@ -71,6 +71,7 @@ class Timing(C.Structure):
         ("find_mems_launches", u32), ("heavy_reads", u32), ("pairs_reads", u32), ("pairs_other_steps", u32),
         ("ms_find_mems_main", C.c_float), ("seed_depth", u32),
         ("main_lines", u64), ("main_seed_loads", u64), ("other_lines", u64), ("other_seed_loads", u64), ("two_step_trips", u64),
+        ("ms_per_upload", C.c_float),
     ]
 
 
@@ -131,6 +132,11 @@ def lib():
     L.pgx_decompress_sa.argtypes = [p, C.c_int, u32, p]
     L.pgx_batch_create.argtypes = [p, C.c_int, p, p, u64, C.POINTER(p)]
     L.pgx_batch_upload.argtypes = [p, p, p, u64]
+    L.pgx_batch_upload_packed.argtypes = [p, p, p, u64, p, p, u64]
+    L.pgx_pack_reads.argtypes = [p, p, u64, u32, p, p, u64, p, u64, C.POINTER(u64), C.POINTER(u64)]
+    L.pgx_host_alloc.argtypes = [C.c_size_t, C.POINTER(p)]
+    L.pgx_host_free.argtypes = [p]
+    L.pgx_host_free.restype = None
     L.pgx_batch_run.argtypes = [p, u64, u64, u32, p]
     L.pgx_batch_result.argtypes = [p, C.POINTER(Result)]
     L.pgx_batch_counts.argtypes = [p, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
@@ -168,6 +174,41 @@ def device_name(device=0):
     buf = C.create_string_buffer(256)
     _check(lib().pgx_device_name(device, buf, 256))
     return buf.value.decode()
+
+
+class _Pinned:
+    """owner of one pgx_host_alloc block (freed with the last numpy view on it)"""
+
+    def __init__(self, nbytes):
+        self.ptr = p()
+        _check(lib().pgx_host_alloc(max(int(nbytes), 16), C.byref(self.ptr)))
+        self.nbytes = max(int(nbytes), 16)
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().pgx_host_free(self.ptr)
+            self.ptr = None
+
+
+def pinned_array(n, dtype):
+    """numpy array of n items in pinned host memory (pgx_host_alloc): uploads from it and downloads into it run at link speed"""
+    dt = np.dtype(dtype)
+    own = _Pinned(int(n) * dt.itemsize)
+    buf = (C.c_uint8 * own.nbytes).from_address(own.ptr.value)
+    buf._pgx_owner = own  # (the array's base is this ctypes object: the block lives as long as any view on it)
+    return np.frombuffer(buf, dtype=dt, count=int(n))
+
+
+def pack_reads(reads_cat, offsets, packed_out, side_ids_out, side_bytes_out, threads=0):
+    """pgx_pack_reads: the batch packed to two bits per symbol into packed_out (uint32[(bytes + 15) // 16]) and the reads with a byte outside
+    A C G T listed (ids, their bytes concatenated) -> (n_side, n_side_bytes); PgxError(ERR_NOMEM) when the list does not fit"""
+    reads_cat = np.ascontiguousarray(reads_cat, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    assert packed_out.dtype == np.uint32 and len(packed_out) >= (len(reads_cat) + 15) // 16
+    ns, nb = u64(0), u64(0)
+    _check(lib().pgx_pack_reads(reads_cat.ctypes.data if len(reads_cat) else None, offsets.ctypes.data, len(offsets) - 1, threads, packed_out.ctypes.data,
+                                side_ids_out.ctypes.data, len(side_ids_out), side_bytes_out.ctypes.data, len(side_bytes_out), C.byref(ns), C.byref(nb)))
+    return ns.value, nb.value
 
 
 def build_rindex(rlbwt_path, out_path, encoded=True):
@@ -362,6 +403,10 @@ class Index:
     def batch(self, reads_cat, offsets, device=0):
         return Batch(self, reads_cat, offsets, device)
 
+    def batch_empty(self, device=0):
+        """a batch without reads yet (upload / upload_packed fill it)"""
+        return Batch(self, np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.uint64), device)
+
     def find_mems(self, reads_cat, offsets, min_len, min_occ, tags=False, device=0):
         b = Batch(self, reads_cat, offsets, device)
         try:
@@ -483,6 +528,14 @@ class Batch:
         self.b = p()
         _check(self.L.pgx_batch_create(index.h, device, reads_cat.ctypes.data if len(reads_cat) else None,
                                        offsets.ctypes.data, self.n, C.byref(self.b)))
+
+    def upload_packed(self, packed, offsets, side_ids, side_bytes, n_side):
+        """pgx_batch_upload_packed: the arrays pack_reads() filled (offsets[0] == 0)"""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        assert packed.dtype == np.uint32 and packed.flags.c_contiguous
+        self.n = len(offsets) - 1
+        _check(self.L.pgx_batch_upload_packed(self.b, packed.ctypes.data, offsets.ctypes.data, self.n, side_ids.ctypes.data if n_side else None,
+                                              side_bytes.ctypes.data if n_side else None, n_side))
 
     def upload(self, reads_cat, offsets):
         reads_cat = np.ascontiguousarray(reads_cat, dtype=np.uint8)

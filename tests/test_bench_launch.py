@@ -58,3 +58,27 @@ def test_failing_rank_fails_the_launch():
         assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["n_gpus"] == 2
     else:
         assert "ranks failed" in r.stderr
+
+
+def test_strong_scaling_cuts_one_batch_into_contiguous_slices():
+    """bench.py --scaling strong (BASELINE configs[3] as worded: ONE batch read-sharded over the ranks; reference unit: the per-read loop
+    src/find_mems.cpp:94-139 over one reads file): the ranks' slices tile the batch; weak scaling gives every rank a batch of its own"""
+    r = _run(["--gpus", "2", "--stub-workload", "--dist-backend", "gloo", "--scaling", "strong", "--reads", "1001", "--read-len", "7"])
+    assert r.returncode == 0, r.stderr
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["scaling"] == "strong" and rec["reads_per_rank"] == [500, 501] and rec["first_read_per_rank"] == [0, 500]
+    assert rec["read_bytes_per_rank"] == [3500, 3507]
+    r = _run(["--gpus", "2", "--stub-workload", "--dist-backend", "gloo", "--reads", "1001", "--read-len", "7"])
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["scaling"] == "weak" and rec["reads_per_rank"] == [1001, 1001]
+    sys.path.insert(0, ROOT)
+    import numpy as np
+
+    import bench
+
+    offs = np.array([0, 3, 3, 10, 12, 20], dtype=np.uint64)
+    cat = np.arange(20, dtype=np.uint8)
+    parts = [bench.strong_slice(cat, offs, k, 3) for k in range(3)]
+    assert [len(o) - 1 for _, o in parts] == [1, 2, 2] and all(int(o[0]) == 0 for _, o in parts)
+    assert np.array_equal(np.concatenate([c for c, _ in parts]), cat)
+    assert [int(o[-1]) for _, o in parts] == [3, 7, 10]

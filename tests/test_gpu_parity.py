@@ -406,3 +406,92 @@ def test_wide_state_and_forced_redo(x_index, golden, monkeypatch, env, layout):
         launches = b.timing().find_mems_launches
         b.free()
         assert launches >= 3
+
+
+def _packed_arrays(cat, offs, pinned):
+    alloc = P.pinned_array if pinned else (lambda n, dt: np.zeros(n, dtype=dt))
+    packed = alloc(max((len(cat) + 15) // 16, 1), np.uint32)
+    ids, side = alloc(len(offs), np.uint64), alloc(len(cat) + 16, np.uint8)
+    ns, _ = P.pack_reads(cat, offs, packed, ids, side)
+    return packed, ids, side, ns
+
+
+def test_packed_upload_equals_byte_upload(workdir, x_index):
+    """pgx_batch_upload_packed (the reads packed to two bits per symbol by the caller, reads with a byte outside A C G T listed with their bytes;
+    what the find_mems CLI uploads) gives the bytes pgx_batch_upload gives: on a sigma = 6 pangenome under the automatic layout (two-step kernel
+    over the packed words, listed reads on the side stream) and forced dense2 (every kernel reads the bytes rebuilt on the device), and on the x
+    index (image in LDS); pinned and ordinary host memory; a long-lived batch refilled in both forms alternately; reads with N, lower case, \\0,
+    empty reads, lengths that are no multiple of 16.  Reference unit: the per-read loop src/find_mems.cpp:94-139."""
+    text = os.path.join(workdir, "pk6.txt")
+    W.synth_pangenome_text(text, base_len=300_000, n_hap=4, seed=12, n_runs=3, n_run_len=(100, 2000))
+    ri_path, tags_path = W.build_index_from_text(text, workdir, "pk6")[:2]
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    seqs = W.load_sequences(text)
+    cat, offs = W.sample_reads(seqs, 40_000, 150, seed=62, n_frac=0.02)
+    rng = np.random.default_rng(9)
+    extra = [b"", b"N" * 150, b"acgt" * 30, b"ACGT\x00ACGTACGTACGTACGTACGTACGT", bytes(seqs[0][-150:]), bytes(seqs[1][:150]), b"A", b"", bytes(seqs[2][500:533]),
+             bytes(seqs[3][100:351]), b"ACGTN"]
+    for _ in range(300):
+        s = seqs[int(rng.integers(0, len(seqs)))]
+        ln = int(rng.integers(1, 330))
+        a = int(rng.integers(0, len(s) - ln))
+        extra.append(bytes(s[a:a + ln]))
+    ecat, eoffs = O.pack_reads(extra)
+    cat = np.concatenate([cat, ecat]); offs = np.concatenate([offs, eoffs[1:] + offs[-1]])
+    cat2, offs2 = W.sample_reads(seqs, 30_000, 150, seed=63)  # a second batch without a single listed read ...
+    keep = ~(cat2.reshape(-1, 150) == ord("N")).any(axis=1)
+    cat2 = cat2.reshape(-1, 150)[keep].reshape(-1); offs2 = np.arange(int(keep.sum()) + 1, dtype=np.uint64) * np.uint64(150)
+    for mode in (P.MODE_COMPAT, P.MODE_COMPAT | P.MODE_IMAGE_DENSE2):
+        idx = P.Index(ri_path, tags_path, mode=mode)
+        assert idx.info().image_pairs == (1 if mode == P.MODE_COMPAT else 0)
+        for min_len, min_occ in ((20, 1), (12, 2)):
+            ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, threads=O.lib().orc_max_threads())
+            ref2 = O.find_mems_batch(ri, tags, cat2, offs2, min_len, min_occ, threads=O.lib().orc_max_threads())
+            b = idx.batch_empty()
+            for pinned in (True, False):
+                packed, ids, side, ns = _packed_arrays(cat, offs, pinned)
+                assert ns > 700  # reads that overlap an N run, lower case, \0
+                b.upload_packed(packed, offs, ids, side, ns)
+                b.run(min_len, min_occ, P.RUN_TAGS | P.RUN_TIMING)
+                t1 = b.timing()
+                res = b.result()
+                _assert_same(res, ref, True)
+                assert res["n_extensions"] == ref["n_extensions"]
+                b.run(min_len, min_occ, P.RUN_TAGS | P.RUN_TIMING)  # the same reads again: nothing left to prepare
+                assert b.timing().ms_per_upload == 0.0 and t1.ms_per_upload > 0.0
+                _assert_same(b.result(), ref, True)
+                if mode == P.MODE_COMPAT:
+                    assert t1.pairs_reads == 2  # the two-step kernel over the packed words as they came from the host
+                b.upload(cat2, offs2)  # refilled as bytes ...
+                b.run(min_len, min_occ, P.RUN_TAGS | P.RUN_TIMING)
+                assert b.timing().ms_per_upload > 0.0
+                _assert_same(b.result(), ref2, True)
+                p2, i2, s2, n2 = _packed_arrays(cat2, offs2, pinned)  # ... and packed, with an empty side list
+                assert n2 == 0
+                b.upload_packed(p2, offs2, i2, s2, 0)
+                b.run(min_len, min_occ, P.RUN_TAGS)
+                r2 = b.result()
+                _assert_same(r2, ref2, True)
+                assert r2["n_extensions"] == ref2["n_extensions"]
+            b.free()
+        idx.close()
+    # the x index (no N in the index, image in LDS, COMPAT quirks): the kernels read the rebuilt bytes
+    xri, xtags = x_index
+    xr, xt = O.RIndex(xri), O.Tags(xtags, O.TAGS_COMPACT)
+    xref = O.find_mems_batch(xr, xt, cat, offs, 10, 1, threads=O.lib().orc_max_threads())
+    idx = P.Index(xri, xtags, mode=P.MODE_COMPAT)
+    b = idx.batch_empty()
+    packed, ids, side, ns = _packed_arrays(cat, offs, True)
+    b.upload_packed(packed, offs, ids, side, ns)
+    b.run(10, 1, P.RUN_TAGS)
+    _assert_same(b.result(), xref, True)
+    # refused uploads leave the batch usable: offsets that do not start at 0, listed ids out of order
+    with pytest.raises(P.PgxError):
+        b.upload_packed(packed, offs + np.uint64(16), ids, side, ns)
+    bad_ids = ids.copy(); bad_ids[:2] = bad_ids[:2][::-1]
+    with pytest.raises(P.PgxError):
+        b.upload_packed(packed, offs, bad_ids, side, ns)
+    b.run(10, 1, P.RUN_TAGS)
+    _assert_same(b.result(), xref, True)
+    b.free()
+    idx.close()
