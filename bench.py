@@ -70,6 +70,7 @@ def parse(argv=None):
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the measured batch (parity_sample)")
     ap.add_argument("--no-overlap", action="store_true", help="skip the extra measurement with two batches in flight (two_batches_in_flight)")
     ap.add_argument("--no-fresh", action="store_true", help="skip the fresh-batch measurement (fresh_batch: every step uploads a different batch from pinned host memory, runs it and downloads its results)")
+    ap.add_argument("--fresh-workers", type=int, default=3, help="fresh_batch: device batches / host threads / streams in flight")
     ap.add_argument("--batch-sweep", action="store_true", help="also report reads/s against the batch size (64 k ... --reads), resident and fresh (batch_size_sweep)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --reads per GPU; strong (BASELINE configs[3] as worded): ONE batch of --reads cut into --gpus contiguous slices, one per rank")
@@ -301,21 +302,28 @@ def measure_fresh(idx, host_batches, local, min_len, min_occ, flags, steps, sync
     dbs = [idx.batch_empty(device=local) for _ in range(workers)]
     nb = len(host_batches)
     err, last = [], [None] * workers
+    phase = [[0.0, 0.0, 0.0] for _ in range(workers)]  # host seconds inside upload / run / result per worker (timed steps only)
 
-    def one(w, k):
+    def one(w, k, timed=False):
         hb = host_batches[(w + k) % nb]
+        t0 = time.perf_counter()
         if packed:
             dbs[w].upload_packed(hb.packed, hb.offs, hb.side_ids, hb.side_bytes, hb.n_side)
         else:
             dbs[w].upload(hb.cat, hb.offs)
+        t1 = time.perf_counter()
         dbs[w].run(min_len, min_occ, flags & ~2, 0)  # (no event timing inside; the batch's own stream)
+        t2 = time.perf_counter()
         nm, npos = dbs[w].result_counts()  # D2H of offsets, MEMs, run counts, positions into the batch's pinned arrays
+        t3 = time.perf_counter()
+        if timed:
+            phase[w][0] += t1 - t0; phase[w][1] += t2 - t1; phase[w][2] += t3 - t2
         last[w] = ((w + k) % nb, nm, npos)
 
-    def work(w, k0, k1):
+    def work(w, k0, k1, timed=False):
         try:
             for k in range(k0, k1):
-                one(w, k)
+                one(w, k, timed)
         except Exception as e:  # noqa: BLE001
             err.append(e)
 
@@ -325,7 +333,7 @@ def measure_fresh(idx, host_batches, local, min_len, min_occ, flags, steps, sync
     if err:
         raise err[0]
     share = [steps // workers + (1 if w < steps % workers else 0) for w in range(workers)]
-    th = [threading.Thread(target=work, args=(w, warm, warm + share[w])) for w in range(workers)]
+    th = [threading.Thread(target=work, args=(w, warm, warm + share[w], True)) for w in range(workers)]
     t0 = time.perf_counter()
     for t in th:
         t.start()
@@ -335,6 +343,7 @@ def measure_fresh(idx, host_batches, local, min_len, min_occ, flags, steps, sync
     dt = time.perf_counter() - t0
     if err:
         raise err[0]
+    measure_fresh.phase_ms = [1e3 * sum(p[i] for p in phase) / max(steps, 1) for i in range(3)]  # mean host ms per step inside each call
     return dt, last, dbs
 
 
@@ -346,10 +355,11 @@ def fresh_record(P, idx, host_batches, local, args, flags, sync, resident_result
     out = {"what": "K steps that each pgx_batch_upload[_packed] a batch different from the one before (three batches resident in pinned host memory, rotating), "
                    "pgx_batch_run it and pgx_batch_result it into pinned host arrays; three device batches / host threads / streams, so H2D, kernels and D2H of "
                    "consecutive steps overlap; whole batches of %d reads, tags included" % n,
-           "unit": "reads/s", "steps": K, "workers": 3}
+           "unit": "reads/s", "steps": K, "workers": args.fresh_workers}
     for key, packed in (("packed", True), ("bytes", False)):
-        dt, last, dbs = measure_fresh(idx, host_batches, local, args.min_len, args.min_occ, flags, K, sync, packed)
+        dt, last, dbs = measure_fresh(idx, host_batches, local, args.min_len, args.min_occ, flags, K, sync, packed, workers=args.fresh_workers)
         rec = {"value": n * K / dt, "ms_per_step": 1e3 * dt / K,
+               "host_ms_per_step_inside": dict(zip(("upload", "run", "result"), measure_fresh.phase_ms)),
                "h2d_MB_per_step": (host_batches[0].h2d_bytes_packed if packed else host_batches[0].h2d_bytes_plain) / 1e6}
         # a step that uploaded host batch 0 must give exactly what the resident (measured) batch gave: full arrays, device vs device
         ident = None
