@@ -103,6 +103,7 @@ struct PgxHeavyResult { // find_mems_function(x) of one start position
     uint32_t next_x, n_ext, has_mem, pad;
 };
 #define PGX_FM_HEAVY_EXT 2048u    // extensions spent on one read before the rest is handed on (ordinary 150-bp reads: ~200)
+#define PGX_FM_SIDE_HEAVY_EXT 2048u // the same for the launch on the second stream (reads with a byte outside A C G T); see pgx_batch_run
 #define PGX_FM_HEAVY_MAXLEN 4096u // reads up to this length take part (per-start results live in scratch)
 #define PGX_FM_HEAVY_CAP 8192u    // heavy reads per launch; beyond that lanes simply continue sequentially
 #define PGX_FM_HEAVY_GRID 64u

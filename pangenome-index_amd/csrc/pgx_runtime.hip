@@ -1083,16 +1083,38 @@ static void batch_take_offsets(pgx_batch *b, const uint64_t *offsets, uint64_t n
     HostBuf &hb = b->h_off[b->h_off_cur ^ 1]; // (swapped in once the offsets have proved valid: a refused upload leaves the batch as it was)
     hb.ensure((n_reads + 1) * 8);
     uint64_t *ho = hb.as<uint64_t>();
-    uint64_t longest = 0, prev = lo;
     ho[0] = 0;
-    for (uint64_t i = 1; i <= n_reads; i++) {
-        const uint64_t o = offsets[i];
-        if (o < prev) throw Error(PGX_ERR_ARG, std::string(who) + ": offsets must be non-decreasing");
-        longest = std::max(longest, o - prev);
-        ho[i] = o - lo;
-        prev = o;
+    // ten million offsets are ~15 ms of one core: slices on a few host threads (a fresh batch per step is bound by what its host thread does
+    // between the device's work: bench.py fresh_batch)
+    const unsigned nt = n_reads >= (1u << 20) ? 4u : 1u;
+    uint64_t longest[4] = {0, 0, 0, 0};
+    bool bad[4] = {false, false, false, false};
+    auto slice = [&](unsigned t) {
+        const uint64_t i0 = 1 + n_reads * t / nt, i1 = 1 + n_reads * (t + 1) / nt;
+        uint64_t prev = offsets[i0 - 1], mx = 0;
+        bool b_ = false;
+        for (uint64_t i = i0; i < i1; i++) {
+            const uint64_t o = offsets[i];
+            b_ |= o < prev;
+            mx = std::max(mx, o - prev);
+            ho[i] = o - lo;
+            prev = o;
+        }
+        longest[t] = mx; bad[t] = b_;
+    };
+    if (nt == 1) slice(0);
+    else {
+        std::thread th[3];
+        for (unsigned t = 1; t < nt; t++) th[t - 1] = std::thread(slice, t);
+        slice(0);
+        for (unsigned t = 1; t < nt; t++) th[t - 1].join();
     }
-    if (longest >= (1ull << 31)) throw Error(PGX_ERR_UNSUPPORTED, "read longer than 2^31 bytes");
+    uint64_t mx = 0;
+    for (unsigned t = 0; t < nt; t++) {
+        if (bad[t]) throw Error(PGX_ERR_ARG, std::string(who) + ": offsets must be non-decreasing");
+        mx = std::max(mx, longest[t]);
+    }
+    if (mx >= (1ull << 31)) throw Error(PGX_ERR_UNSUPPORTED, "read longer than 2^31 bytes");
     b->h_off_cur ^= 1;
     b->n_reads = n_reads;
     b->ran = b->ran_tags = false;
@@ -1100,7 +1122,7 @@ static void batch_take_offsets(pgx_batch *b, const uint64_t *offsets, uint64_t n
     b->slot_off_valid = false;
     b->class_valid = false;
     b->ms_upload_passes = 0;
-    b->max_read_len = longest;
+    b->max_read_len = mx;
     b->read_bytes = offsets[n_reads] - lo;
     b->offsets.ensure((n_reads + 1) * 8);
     HIPCHECK(hipMemcpyAsync(b->offsets.p, ho, (n_reads + 1) * 8, hipMemcpyHostToDevice, b->own));
@@ -1456,8 +1478,12 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                     const pgx_heavy_item *s_list = b->side_list.as<pgx_heavy_item>();
                     const unsigned long long *s_count = b->side_count.as<unsigned long long>();
                     unsigned long long *s_cur = d_next + PGX_CTR_SIDE_CURSOR;
+                    // (a lane of this launch walks its read alone, one dependent extension after the other next to the pairs kernel: the launch lasts as long
+                    //  as its longest chain, so its reads go to the heavy-read kernel -- every start position at once -- earlier than the main launch's)
+                    uint32_t s_hext = heavy_ext ? std::min<uint32_t>(heavy_ext, PGX_FM_SIDE_HEAVY_EXT) : 0u;
+                    if (const char *e = std::getenv("PGX_FM_SIDE_HEAVY_EXT")) s_hext = (uint32_t)std::strtoul(e, nullptr, 10);
                     void *sargs[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &s_cur, &a_first, &a_base,
-                                     &a_hext, &a_hcap, &a_hlist, &a_hcount, &s_list, &s_count, &a_ovf, &a_ovf_cap};
+                                     &s_hext, &a_hcap, &a_hlist, &a_hcount, &s_list, &s_count, &a_ovf, &a_ovf_cap};
                     HIPCHECK(hipLaunchKernel(kf, dim3(std::min<unsigned>(grid, (unsigned)cus)), dim3(PGX_FM_THREADS), sargs, b->dimg->lds_bytes, b->side));
                     HIPCHECK(hipEventRecord(b->ev_side[1], b->side));
                     side_running = true;

@@ -17,7 +17,7 @@ print("workers $w: resident %.1f M/s (%.2f ms); fresh packed %.1f M/s (%.2f ms) 
 PY
 done
 for wg in 5 4 3; do
-  PGX_FM_WG_PER_CU=$wg python bench.py --workdir $W --no-cpu-baseline --no-secondary --no-parity --no-fresh --steps 20 > gpurun_out/r4_ov_wg$wg.json 2> gpurun_out/r4_ov_wg$wg.err
+  PGX_FM_WG_PER_CU=$wg python bench.py --workdir $W --no-cpu-baseline --no-secondary --no-parity --no-fresh --overlap --steps 20 > gpurun_out/r4_ov_wg$wg.json 2> gpurun_out/r4_ov_wg$wg.err
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/r4_ov_wg$wg.json").read().strip().splitlines()[-1])
