@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 for H in ${@:-32 64 96}; do
   B=$((320000000 / H)); W=/tmp/pgxwd_h$H; mkdir -p $W
   python bench.py --workdir $W --haps $H --base-len $B --no-secondary --no-fresh --no-overlap --cpu-seconds 4 --steps 10 $HAPS_EXTRA > gpurun_out/r4_haps_$H.json 2> gpurun_out/r4_haps_$H.err || { tail -5 gpurun_out/r4_haps_$H.err; exit 1; }
-  WLS=chr22 bash scripts/fm_stats.sh --workdir $W --haps $H --base-len $B > gpurun_out/r4_haps_${H}_stats.txt 2>&1 || true
+  WLS=chr22 PGX_STATS_KEEP=1 bash scripts/fm_stats.sh --workdir $W --haps $H --base-len $B > gpurun_out/r4_haps_${H}_stats.txt 2>&1 || true
   python - <<PY
 import json, re
 d = json.loads(open("gpurun_out/r4_haps_$H.json").read().strip().splitlines()[-1])
