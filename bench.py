@@ -72,7 +72,7 @@ def parse(argv=None):
     ap.add_argument("--overlap", action="store_true", help="extra measurement with two resident batches in flight (two_batches_in_flight); off by default since round 4: "
                                                           "measured three ways it is within +-3 %% of the bench value (profiles/r04_overlap_by_occupancy.txt)")
     ap.add_argument("--no-fresh", action="store_true", help="skip the fresh-batch measurement (fresh_batch: every step uploads a different batch from pinned host memory, runs it and downloads its results)")
-    ap.add_argument("--fresh-workers", type=int, default=3, help="fresh_batch: device batches / host threads / streams in flight")
+    ap.add_argument("--fresh-workers", type=int, default=4, help="fresh_batch: device batches / host threads / streams in flight")
     ap.add_argument("--batch-sweep", action="store_true", help="also report reads/s against the batch size (64 k ... --reads), resident and fresh (batch_size_sweep)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --reads per GPU; strong (BASELINE configs[3] as worded): ONE batch of --reads cut into --gpus contiguous slices, one per rank")
@@ -294,7 +294,7 @@ class HostBatch:
         self.h2d_bytes_plain = len(cat) + 8 * (self.n + 1)
 
 
-def measure_fresh(idx, host_batches, local, min_len, min_occ, flags, steps, sync, packed, workers=3, warm=2):
+def measure_fresh(idx, host_batches, local, min_len, min_occ, flags, steps, sync, packed, workers=4, warm=2):
     """NOT the bench value: K steps that each upload a batch DIFFERENT from the one the device batch held (rotating over the pinned host
     batches), run it and download its results into pinned host arrays -- `workers` device batches, a host thread and a stream each, so that the
     upload of one, the kernels of another and the download of a third overlap (what the find_mems CLI's device workers do).  Returns
@@ -355,8 +355,8 @@ def fresh_record(P, idx, host_batches, local, args, flags, sync, resident_result
 
     n, K = host_batches[0].n, args.steps
     out = {"what": "K steps that each pgx_batch_upload[_packed] a batch different from the one before (three batches resident in pinned host memory, rotating), "
-                   "pgx_batch_run it and pgx_batch_result it into pinned host arrays; three device batches / host threads / streams, so H2D, kernels and D2H of "
-                   "consecutive steps overlap; whole batches of %d reads, tags included" % n,
+                   "pgx_batch_run it and pgx_batch_result it into pinned host arrays; %d device batches / host threads / streams, so H2D, kernels and D2H of "
+                   "consecutive steps overlap (chr22 scale, 3 / 4 / 5 workers: 281-288 / 322 / 257 M reads/s); whole batches of %d reads, tags included" % (args.fresh_workers, n),
            "unit": "reads/s", "steps": K, "workers": args.fresh_workers}
     for key, packed in (("packed", True), ("bytes", False)):
         dt, last, dbs = measure_fresh(idx, host_batches, local, args.min_len, args.min_occ, flags, K, sync, packed, workers=args.fresh_workers)

@@ -729,7 +729,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
         // what the wave asks of the memory system in this trip (wave-uniform sums in scalar registers; images in global memory): seed / end table
         // entries -- one per first trip of a backward stage, an upper bound: windows that hold a byte outside A C G T and stages with fewer than
         // K extensions to go read the shared entry 0 -- and, counted behind the block, the lines holding the blocks of the two probes
-        if (SEED && !LDS_IMAGE) ln_seed += (unsigned long long)__popcll(__ballot(ph > 0 && fresh != 0u));
+        if (SEED) ln_seed += (unsigned long long)__popcll(__ballot(ph > 0 && fresh != 0u)); // (the seed table is in global memory whether or not the image is staged in LDS)
         bool c_blk = false, c_blk2 = false;
         if (ph > 0) {
             // ---- k-mer seed of a backward stage that starts now: the entry is loaded next to the block loads of the ordinary
@@ -918,7 +918,7 @@ pgx_find_mems_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const u
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
     if (lane == 0 && tot) atomicAdd(n_ext_total + PGX_CTR_EXT, tot);
-    if (lane == 0 && ln_blk && !LDS_IMAGE) { atomicAdd(n_ext_total + PGX_CTR_FM_LINES, ln_blk); atomicAdd(n_ext_total + PGX_CTR_FM_SEEDS, ln_seed); }
+    if (lane == 0 && (ln_blk | ln_seed)) { atomicAdd(n_ext_total + PGX_CTR_FM_LINES, ln_blk); atomicAdd(n_ext_total + PGX_CTR_FM_SEEDS, ln_seed); }
 #ifdef PGX_FM_STATS // wave trips, live lane-trips, longest wave (stats runs are made without tags)
     if (lane == 0) { atomicAdd(n_ext_total + PGX_CTR_ST_TRIPS, st_trips); atomicAdd(n_ext_total + PGX_CTR_ST_LIVE, st_live); atomicMax(n_ext_total + PGX_CTR_ST_LONGEST, st_trips); }
 #endif
