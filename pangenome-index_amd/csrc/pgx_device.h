@@ -182,7 +182,7 @@ __global__ void pgx_tag_dedup_kernel(const uint64_t *list, uint64_t n_list, cons
                                      const uint64_t *run_nums, unsigned long long *table, uint64_t table_mask, uint64_t *reps, unsigned long long *n_rep,
                                      uint64_t *pairs, unsigned long long *n_dup);
 __global__ void pgx_tag_copy_dups_kernel(const uint64_t *pairs, uint64_t n_pairs, const uint64_t *n_dev, const uint64_t *abort, uint64_t n_tag_items,
-                                         const uint64_t *first_item, const uint64_t *run_nums, const uint64_t *seg_off, uint64_t *buf, uint64_t *ucount,
+                                         const uint64_t *first_item, const uint64_t *run_nums, uint64_t *seg_off, uint64_t *buf, uint64_t *ucount,
                                          unsigned long long *n_overflow);
 __global__ void pgx_tag_compact_kernel(const uint64_t *list, uint64_t n, const uint64_t *n_dev, const uint64_t *abort, const uint64_t *ucount,
                                        const uint64_t *seg_off, const uint64_t *buf, const uint64_t *pos_off, uint64_t *positions, uint64_t max_count);

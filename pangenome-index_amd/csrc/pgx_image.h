@@ -74,8 +74,15 @@
  * in order, onto the interval after the first extension, and BWT there is c2 -- from the same cache line that answers one:
  * find_mems performs half the dependent line fetches.  96 symbols per 128-byte block, 4 n / 3 bytes in all:
  *   dw 4 y + x   (y, x in A C G T = 0..3) number of positions q < 96 b with c1(q) = y, c2(q) = x
- *   dw 16 + y    bits 0..30: number of positions q < 96 b with c1(q) = y and c2(q) SPECIAL (\n or N) -- what the pair counts of row y do
- *                not see of the symbol y; bit 31 of dw 16: the block holds a special position (c1 or c2 is \n or N)
+ *   dw 16 + y    bits 0..23: number of positions q < 96 b with c1(q) = y and c2(q) SPECIAL (\n or N) -- what the pair counts of row y do
+ *                not see of the symbol y (such positions exist only where a sequence starts or an N run ends: an index with 2^24 of them
+ *                gets no PAIRS image); bit 31 of dw 16: the block holds a special position (c1 or c2 is \n or N);
+ *                RUN CONTINUATION (round 4): bits 24..31 of dw 17 = number of positions right behind the block (at most 255) that carry the same
+ *                regular PAIR as the block's last position; bits 24..31 of dw 18 = the same for the first symbol alone (any second symbol).
+ *                In a pangenome of H haplotypes an interval is ~H positions wide and mostly ONE run (the haplotypes agree): where it runs on
+ *                behind the block, its far end usually lies inside that run, and the counts of the part behind the block follow from the last
+ *                position's pair -- no second line (H = 96 at n = 640 M: 44 % of the lane trips fetched one before).  PGX_PAIRS_EXT=0 builds
+ *                the image without (fields zero).
  *   dw 20..22 / 23..25   bit planes of c1 (bit 0, bit 1);  dw 26..28 / 29..31  bit planes of c2
  * A kernel probe reads the row of its first symbol (16 bytes), dw 16..19 and the planes (48 bytes).  A kernel uses unflagged blocks
  * only, and two neighbouring blocks together only when neither is flagged: every count that involves \n or N then cancels out of the

@@ -635,7 +635,11 @@ static bool build_pairs_image(const RiFile &ri, HostImage &img, bool wide, uint3
         uint64_t special = 0;
         for (const Special &sr : runs) special += sr.cnt[0];
         if (special >> 31) return false; // (the header counts of special positions are 31-bit)
+        uint64_t half[4] = {0, 0, 0, 0}; // positions with c2 special and c1 = A, C, G, T: 24-bit header fields (pgx_image.h)
+        for (const Special &sr : runs) for (int i = 0; i < 4; i++) half[i] += sr.cnt[1 + i];
+        for (int i = 0; i < 4; i++) if (half[i] >> 24) return false;
     }
+    const bool with_ext = !(std::getenv("PGX_PAIRS_EXT") && std::getenv("PGX_PAIRS_EXT")[0] == '0');
     // positions with c2 special and c1 = A, C, G, T in every chunk (the blocks carry their running sums)
     std::vector<std::array<uint64_t, 4>> spec_cnt(nt, std::array<uint64_t, 4>{});
     for (size_t t = 0; t < nt; t++)
@@ -694,6 +698,17 @@ static bool build_pairs_image(const RiFile &ri, HostImage &img, bool wide, uint3
                 if (v & 1) h[26 + w] |= bit;
                 if (v & 2) h[29 + w] |= bit;
                 if (p < adv) pc[v]++;
+            }
+            // run continuation (pgx_image.h): how far the pair / the first symbol of the block's last position goes on behind the block
+            const uint64_t e0 = s0 + PGX_PAIRS_SYMS;
+            if (with_ext && e0 < n && !(pr[e0 - 1] & 0x80)) {
+                const uint8_t last = pr[e0 - 1];
+                uint32_t xp = 0, x1 = 0;
+                while (xp < 255u && e0 + xp < n && pr[e0 + xp] == last) xp++;
+                auto c1_of = [](uint8_t v) { return v == 0x80 ? 0xFFu : (v > 0x80 ? (uint32_t)(v - 0x81) : (uint32_t)(v >> 2)); };
+                while (x1 < 255u && e0 + x1 < n && c1_of(pr[e0 + x1]) == (uint32_t)(last >> 2)) x1++;
+                h[17] |= xp << 24;
+                h[18] |= x1 << 24;
             }
         }
         (void)p0; (void)p1;

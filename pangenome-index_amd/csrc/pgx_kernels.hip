@@ -1372,7 +1372,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
 #endif
             }
             const bool flagged = (hs.x >> 31) != 0u;
-            const uint32_t pts = t1 == 0u ? (hs.x & 0x7FFFFFFFu) : (t1 == 1u ? hs.y : (t1 == 2u ? hs.z : hs.w));
+            const uint32_t pts = (t1 == 0u ? hs.x : (t1 == 1u ? hs.y : (t1 == 2u ? hs.z : hs.w))) & 0x00FFFFFFu; // (24-bit counts: pgx_image.h)
             // masks that turn "code == t" / "code > t" into plane expressions: (x ^ i0) & (y ^ i1) and (y & ua) | (x & (y | va) & wa)
             const uint32_t i0 = (t1 & 1u) ? 0u : 0xFFFFFFFFu, i1 = (t1 & 2u) ? 0u : 0xFFFFFFFFu, j0 = (t2 & 1u) ? 0u : 0xFFFFFFFFu, j1 = (t2 & 2u) ? 0u : 0xFFFFFFFFu;
             const uint32_t ua = t1 < 2u ? 0xFFFFFFFFu : 0u, va = t1 == 0u ? 0xFFFFFFFFu : 0u, wa = (t1 & 1u) ? 0u : 0xFFFFFFFFu;
@@ -1420,8 +1420,22 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 a02 += (pos_t)pb[4u * t1 + t2];
             }
             const bool straddle = endrel > SYMS, far = endrel > STRIDE + SYMS;
-            const bool bail = !fr && (flagged || far); // (a second block is used only when it is not flagged either: nothing special between the two ends)
-            const bool wait = !fr && !pend && straddle && !bail; // the interval runs on into the next block: next trip
+            // Run continuation (pgx_image.h): the pair of the block's last position goes on for hs.y >> 24 positions behind the block, its first symbol
+            // alone for hs.z >> 24.  An interval that ends inside that stretch is answered from THIS line -- both extensions, or the first one --: the
+            // positions behind the block all count like the last one.  (Intervals are ~#haplotypes wide and mostly one run: with 96 haplotypes 44 % of
+            // the lane trips fetched a second block before, profiles/r04_haps_sweep.txt.)
+            const uint32_t over = endrel - SYMS; // (meaningful where straddle)
+            const bool cont2 = !pend && straddle && over <= (hs.y >> 24), cont1 = !pend && straddle && !cont2 && over <= (hs.z >> 24);
+            const bool cont = cont1 || cont2;
+            if (cont) {
+                const uint32_t l1 = (PX[2] >> 31) | ((PY[2] >> 31) << 1), l2 = (PU[2] >> 31) | ((PV[2] >> 31) << 1); // the pair at position 95
+                e1r += l1 == t1 ? over : 0u;
+                g1r += l1 > t1 ? over : 0u;
+                e2r += (cont2 && l1 == t1 && l2 == t2) ? over : 0u;
+                g2r += (cont2 && l1 == t1 && l2 > t2) ? over : 0u;
+            }
+            const bool bail = !fr && (flagged || (far && !cont)); // (a second block is used only when it is not flagged either: nothing special between the two ends)
+            const bool wait = !fr && !pend && straddle && !bail && !cont; // the interval runs on into the next block: next trip
 #ifdef PGX_FM_STATS
             st_wait += wait ? 1ull : 0ull;
 #endif
@@ -1474,7 +1488,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 const pos_t se_s = ent_s(se);
                 const bool seed_alive = SEED && seed_lane && se_s != 0u && se_s >= mo && !mo_huge;
                 const bool seed_dead = SEED && seed_lane && se_s == 0u && sdepth != PGX_SEED_UNUSABLE && min_occ <= 1;
-                const bool do2 = (fr ? (at_end && rem2 && have2 && !seed_alive && !seed_dead) : (two && !bail)) && !small1;
+                const bool do2 = (fr ? (at_end && rem2 && have2 && !seed_alive && !seed_dead) : (two && !bail && !cont1)) && !small1;
                 pos_t s2 = (pos_t)c2, k2 = r2 + s_C[PGX_EXT_V(e2)] + s_t2[8u * t1 + cv2], q2v = q1v + (pos_t)w2;
                 if (fr) { const uint4 f = s_fe[PACKED ? 5u + ((byte2 >> 1) & 3u) : 256u + byte2]; k2 = ent_k(f); q2v = ent_q(f); s2 = ent_s(f); }
                 pos_t ns = do2 ? s2 : s1, nk = do2 ? k2 : k1, nq = do2 ? q2v : q1v;

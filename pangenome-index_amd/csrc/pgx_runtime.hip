@@ -544,7 +544,7 @@ static void tag_pipeline(const PgxDevImage &img, const pgx_mem *d_mems, const ui
                                w.scratch_off.as<uint64_t>(), w.ucount.as<uint64_t>());
         }
         if (ndup)
-            hipLaunchKernelGGL(pgx_tag_copy_dups_kernel, dim3(spec ? fixed_grid(ndup, 1, 4096) : grid_for(ndup, 1)), dim3(256), 0, s, (const uint64_t *)d_pairs, ndup,
+            hipLaunchKernelGGL(pgx_tag_copy_dups_kernel, dim3(spec ? fixed_grid(ndup, 256, 4096) : grid_for(ndup, 256)), dim3(256), 0, s, (const uint64_t *)d_pairs, ndup,
                                dn_dup, ab, img.n_tag_items, w.first_item.as<uint64_t>(), w.run_nums.as<uint64_t>(), w.seg_off.as<uint64_t>(),
                                w.gbuf.as<uint64_t>(), w.ucount.as<uint64_t>(), d_nover);
         HIPCHECK(hipGetLastError());
@@ -1019,6 +1019,7 @@ struct pgx_batch {
     hipStream_t side = nullptr;
     hipEvent_t ev_side[2] = {nullptr, nullptr};
     bool class_valid = false, class_ok = false; // read_flags / side_list / side_count describe the uploaded reads (ok: few enough such reads to list)
+    uint64_t side_reads_est = 0;                 // about how many reads the second-stream launch serves (sizes its grid)
     uint64_t n_reads = 0, read_bytes = 0;
     HostBuf h_off[2];                // rebased host copy of the offsets (chunk planning; pinned: its upload runs at link speed), and the one being filled
     int h_off_cur = 0;
@@ -1192,6 +1193,7 @@ static void batch_upload_packed(pgx_batch *b, const uint32_t *packed, const uint
     HIPCHECK(hipEventElapsedTime(&b->ms_upload_passes, b->ev_up[0], b->ev_up[1]));
     b->class_valid = true; // what pgx_batch_run would otherwise find out with two passes over the bytes and a read-back
     b->class_ok = true;
+    b->side_reads_est = n_side;
 }
 
 extern "C" pgx_status pgx_batch_create(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets,
@@ -1462,6 +1464,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                         unsigned long long n_bad = 0;
                         read_scalars(&n_bad, d_bad, sizeof n_bad, s);
                         b->class_ok = n_bad <= cap;
+                        b->side_reads_est = n_bad / 4; // (a read that overlaps an N run holds a handful of such 16-byte chunks)
                         if (b->class_ok && n_bad) {
                             hipLaunchKernelGGL(pgx_classify_reads_kernel, dim3(grid_for(n_bad, 256)), dim3(256), 0, s, a_reads, a_off, cn, (const uint64_t *)b->scan_tmp.as<uint64_t>(),
                                                (const unsigned long long *)d_bad, cap, b->read_flags.as<uint32_t>(), b->side_list.as<pgx_heavy_item>(),
@@ -1484,7 +1487,11 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                     if (const char *e = std::getenv("PGX_FM_SIDE_HEAVY_EXT")) s_hext = (uint32_t)std::strtoul(e, nullptr, 10);
                     void *sargs[] = {&a_img, &a_reads, &a_off, &a_n, &a_min_len, &a_min_occ, &a_slot_off, &a_slots, &a_cnt, &a_next, &s_cur, &a_first, &a_base,
                                      &s_hext, &a_hcap, &a_hlist, &a_hcount, &s_list, &s_count, &a_ovf, &a_ovf_cap};
-                    HIPCHECK(hipLaunchKernel(kf, dim3(std::min<unsigned>(grid, (unsigned)cus)), dim3(PGX_FM_THREADS), sargs, b->dimg->lds_bytes, b->side));
+                    // one workgroup per CU next to the pairs kernel while these reads are few (0.4 % of the chr22 workload: 43 k reads, less than one per lane);
+                    // with many of them the launch was the longest thing in the step (5 % = 500 k reads, 7.6 per lane one after the other: 21.8 ms next
+                    // to a 17 ms pairs kernel): up to four per CU, two reads per lane
+                    const unsigned side_wgs = (unsigned)std::min<uint64_t>(4ull * (uint64_t)cus, std::max<uint64_t>((uint64_t)cus, b->side_reads_est / (2ull * PGX_FM_THREADS) + 1));
+                    HIPCHECK(hipLaunchKernel(kf, dim3(std::min<unsigned>(grid, side_wgs)), dim3(PGX_FM_THREADS), sargs, b->dimg->lds_bytes, b->side));
                     HIPCHECK(hipEventRecord(b->ev_side[1], b->side));
                     side_running = true;
                   }

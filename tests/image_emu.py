@@ -51,13 +51,21 @@ class PairsLayout:
 
     def rank_before(self, h, y):
         """positions before the block whose first symbol is y (second symbol regular or special)"""
-        return sum(int(h[4 * y + x]) for x in range(4)) + (int(h[16 + y]) & 0x7FFFFFFF)
+        return sum(int(h[4 * y + x]) for x in range(4)) + self.half_before(h, y)
 
     def pair_before(self, h, y, x):
         return int(h[4 * y + x])
 
     def half_before(self, h, y):
-        return int(h[16 + y]) & 0x7FFFFFFF
+        return int(h[16 + y]) & 0xFFFFFF  # 24-bit counts; the bits above hold the flag (dw 16) and the run continuation (dw 17, 18)
+
+    def ext_pair(self, h):
+        """positions right behind the block (<= 255) that carry the same regular pair as the block's last position"""
+        return int(h[17]) >> 24
+
+    def ext_first(self, h):
+        """the same for the first symbol alone"""
+        return int(h[18]) >> 24
 
     def plane_word(self, h, plane, w):
         return int(h[20 + 3 * plane + w])

@@ -269,3 +269,45 @@ def test_automatic_layout_on_random_small_indexes(workdir, monkeypatch, seed):
     """the same texts under the automatic layout: the image staged in LDS with its seed table of depth 10 and the end table (the smaller
     ones), the 64-byte image in global memory + the pairs image (the larger ones)"""
     _random_index_case(workdir, monkeypatch, seed, 0)
+
+
+@pytest.mark.parametrize("haps", [24, 48, 80])
+def test_wide_intervals_and_the_run_continuation(workdir, monkeypatch, haps):
+    """Pangenomes of many haplotypes (the reference's README pipeline targets ~90: /root/reference/README.md:76-100): intervals are ~#haplotypes
+    positions wide, wider than the 32 a block every 64 positions always covers.  The PAIRS block says how far the pair / the first symbol of its last
+    position goes on behind it (pgx_image.h "run continuation"): an interval that ends inside that stretch is answered from ONE line.  Same bytes as the
+    oracle with and without the fields, narrow / 64-bit / cooperative fetches, both strides; and fewer lines with them."""
+    text = os.path.join(workdir, "wide_iv_%d.txt" % haps)
+    W.synth_pangenome_text(text, base_len=3_000_000 // haps, n_hap=haps, seed=50 + haps, n_runs=2, n_run_len=(100, 1500))
+    ri_path, tags_path = W.build_index_from_text(text, workdir, "wide_iv_%d" % haps)[:2]
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    seqs = W.load_sequences(text)
+    cat, offs = W.sample_reads(seqs, 30_000, 150, seed=9)
+    extra = [bytes(seqs[0][-150:]), bytes(seqs[1][:150]), b"ACGT" * 30, b"", b"N" * 20]
+    ecat, eoffs = O.pack_reads(extra)
+    cat = np.concatenate([cat, ecat]); offs = np.concatenate([offs, eoffs[1:] + offs[-1]])
+    monkeypatch.setenv("PGX_SB_SHIFT", "6")
+    refs = {pr: O.find_mems_batch(ri, tags, cat, offs, pr[0], pr[1], threads=O.lib().orc_max_threads()) for pr in ((20, 1), (13, 5))}
+    lines = {}
+    for ext, stride, wide, coop in (("0", "64", 0, None), (None, "64", 0, None), (None, "96", 0, None), (None, "64", 1, None), (None, "64", 0, "1"), (None, "96", 1, "1")):
+        for k, v in (("PGX_PAIRS_EXT", ext), ("PGX_PAIRS_STRIDE", stride), ("PGX_FM_COOP", coop)):
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, v)
+        idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | P.MODE_IMAGE_PAIRS | (P.MODE_IMAGE_WIDE if wide else 0))
+        pv = idx.image_view(20).view(np.uint32).reshape(-1, 32)
+        assert bool((pv[:, 17] >> 24).any()) == (ext is None)
+        for pr, ref in refs.items():
+            b = idx.batch(cat, offs)
+            b.run(pr[0], pr[1], P.RUN_TAGS | P.RUN_TIMING)
+            t = b.timing()
+            assert t.pairs_reads == (3 if coop else 2)
+            _same(b.result(), ref)
+            if pr == (20, 1):
+                lines[(ext, stride, wide, coop)] = int(t.main_lines)
+            b.free()
+        idx.close()
+    with_ext, without = lines[(None, "64", 0, None)], lines[("0", "64", 0, None)]
+    assert lines[(None, "64", 1, None)] == with_ext == lines[(None, "64", 0, "1")]  # the same trips in every variant
+    assert with_ext < (0.97 if haps == 24 else 0.85) * without, (haps, with_ext, without)
