@@ -148,7 +148,7 @@ int main(int argc, char **argv) {
     const size_t min_occ = (size_t)std::stoi(argv[5]);
     std::vector<int> devices(1, 0);
     uint32_t mode = PGX_MODE_COMPAT, tfmt = PGX_TAGS_AUTO;
-    size_t batch_reads = 1u << 18;
+    size_t batch_reads = 1u << 20; // (reads per batch: the fresh-batch rate by batch size, profiles/r04_batch_size_sweep.txt: 177 M reads/s at 2^18, 278 M at 2^20, no more beyond)
     unsigned streams = 3;
     bool quiet = false;
     int first_opt = 6;
