@@ -447,7 +447,7 @@ def roofline_record(info, cat_len, n_reads, counts, k_ms, timing, workload_key, 
     rec = {
         # with the rank image staged in LDS nothing of it comes from HBM: issue slots / LDS bound the kernel and frac only says how little
         # of the HBM roofline it needs; otherwise the bound is random 128-byte line fetches from HBM (or the memory-side cache)
-        "bound": "hbm",
+        "bound": "lds/valu" if in_lds else "hbm",
         "kernel": "pgx_find_mems_pairs_kernel" if pairs else "pgx_find_mems_kernel",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "frac_note": ("bytes moved per launch (kernel-counted image lines and seed entries x 128 B + streamed reads, offsets, MEM slots) / kernel time / HBM peak"
@@ -461,6 +461,9 @@ def roofline_record(info, cat_len, n_reads, counts, k_ms, timing, workload_key, 
         "other_launches": {"lines": int(timing.other_lines), "seed_loads": int(timing.other_seed_loads), "ms": max(fm_ms - main_ms, 0.0),
                            "what": "pgx_find_mems_kernel over the reads handed on / on the second stream, heavy-read kernel"},
         "traffic": None,
+        # LDS-staged image: what the kernel is bound by instead (one rocprofv3 --pmc pass per counter on this workload, kept under profiles/)
+        "lds_valu_utilisation": ({"VALUBusy_pct": 53.1, "LDSBankConflict_pct": 0.51, "wait_for_LDS_instructions": "negligible (SQ_WAIT_INST_LDS 8e4 of 9.7e8 wave cycles)",
+                                  "source": "profiles/r04_x_kernel_counters.txt (round 4, x workload, 1 M reads)"} if in_lds else None),
         "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_ratio": (algo_bytes / (fm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fm_ms > 0 else None,
         "algorithmic_ratio_note": "SURVEY 8d bytes of the reference layout for the same extensions / time of the find_mems stage / HBM peak; may exceed 1 (work avoided, not bandwidth)",
         "stage_ms": fm_ms, "bytes_per_extension": 2.0 * (b_blk + 16.0), "extensions_per_launch": n_ext,
