@@ -2,7 +2,7 @@
 # round 4, experiment 4: run continuation + tag-stage changes: tests, haplotype sweep again, N-read share again
 set -e
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_pairs.py tests/test_wide_image.py tests/test_gpu_tags_large.py tests/test_gpu_parity.py::test_tag_queries_all_sort_paths tests/test_gpu_fullsize.py::test_synth_pangenome_one_million_reads tests/test_gpu_spec.py -m gpu -x -q --durations=6 > gpurun_out/r4_t5.log 2>&1 || { tail -30 gpurun_out/r4_t5.log; exit 1; }
+timeout -k 10 900 python -m pytest tests/test_gpu_pairs.py::test_wide_intervals_and_the_run_continuation tests/test_wide_image.py tests/test_gpu_tags_large.py tests/test_gpu_parity.py::test_tag_queries_all_sort_paths tests/test_gpu_fullsize.py::test_synth_pangenome_one_million_reads tests/test_gpu_spec.py -m gpu -x -q --durations=6 > gpurun_out/r4_t5.log 2>&1 || { tail -30 gpurun_out/r4_t5.log; exit 1; }
 tail -12 gpurun_out/r4_t5.log
 HAPS_EXTRA="--no-cpu-baseline" bash scripts/haps_sweep.sh 64 96 2>&1 | grep -E "^haps|rror" || true
 W=/tmp/pgxwd; mkdir -p $W
