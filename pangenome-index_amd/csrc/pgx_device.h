@@ -88,6 +88,12 @@ struct PgxDevImage {
     uint32_t d2_sb_shift, pairs_sb_shift, n_sb2, n_sbp;
     uint32_t wide;
     uint32_t pairs_stride; // positions between PAIRS block starts: PGX_PAIRS_SYMS or PGX_PAIRS_STRIDE64 (pgx_image.h)
+    // suffix array + text (NULL without; narrow images with a PAIRS image only: pgx_image.h "LCE image"): the forward stage of a MEM whose interval is
+    // narrow is finished by comparing the read with the text at the interval's occurrences, one occurrence per trip, instead of two symbols per trip
+    const uint32_t *lce_sa;    // n entries: position of suffix i in lce_text
+    const uint32_t *lce_text;  // two bits per symbol (A C T G = 0 1 2 3, the order of the packed reads), 16 symbols per word, sequences with their endmarkers
+    const uint32_t *lce_flags; // one bit per 128-byte line of lce_text: the line holds a symbol outside A C G T or lies behind the text
+    uint32_t lce_max;          // widest interval that goes this way
 };
 #define PGX_SEED_UNUSABLE 255u // depth value of entries the kernels must not use (a coordinate does not fit the entry)
 #define PGX_SEED_MAX_K 16
@@ -122,7 +128,7 @@ __global__ void pgx_find_mems_kernel(PgxDevImage img, const uint8_t *reads, cons
                                      uint64_t slot_base, uint32_t heavy_ext, uint32_t heavy_cap, pgx_heavy_item *heavy_list, unsigned long long *heavy_count,
                                      const pgx_heavy_item *rid_list, const unsigned long long *rid_count, uint32_t *ovf_base, uint64_t ovf_cap);
 // PAIRS image (pgx_image.h): two extensions per loop trip; an extension its blocks cannot answer (special positions) goes through the other image
-template <bool SEED, bool WIDE, bool PACKED, bool COOP, bool S64>
+template <bool SEED, bool WIDE, bool PACKED, bool COOP, bool S64, bool LCE>
 __global__ void pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *reads, const uint64_t *offsets, uint64_t n_reads,
                                            uint64_t min_len, uint64_t min_occ, const uint64_t *slot_off, pgx_mem *slots,
                                            uint32_t *mem_count, unsigned long long *n_ext_total, unsigned long long *cursor, uint64_t first_read,
@@ -204,6 +210,12 @@ struct PgxLocImage {
     uint32_t rdir_shift, ldir_shift;
 };
 __global__ void pgx_locate_next_kernel(PgxLocImage loc, const uint64_t *prev, uint64_t n, uint64_t *out);
+// LCE image (pgx_image.h): sequence lengths from the suffixes that start with an endmarker, suffix array in text coordinates + the text's symbols
+// (the first symbol of suffix i is the one whose C-bucket holds i), text packed to two bits + line flags
+__global__ void pgx_lce_seqlen_kernel(const uint64_t *sa, uint64_t n_seq, uint64_t max_length, unsigned long long *seq_len);
+__global__ void pgx_lce_scatter_kernel(const uint64_t *sa, uint64_t n, uint64_t max_length, const uint64_t *seq_start, uint64_t n_seq, uint64_t c1, uint64_t c2, uint64_t c3,
+                                       uint64_t c4, uint64_t c5, uint32_t *sa32, uint8_t *text8, unsigned long long *bad);
+__global__ void pgx_lce_pack_kernel(const uint8_t *text8, uint64_t n, uint64_t n_words, uint32_t *text32, uint32_t *flags);
 __global__ void pgx_locate_plan_kernel(PgxLocImage loc, const uint64_t *qs, const uint64_t *qe, uint64_t n, uint64_t *run0,
                                        uint64_t *n_pieces);
 __global__ void pgx_locate_walk_kernel(PgxLocImage loc, const uint64_t *qs, const uint64_t *qe, uint64_t n_queries,

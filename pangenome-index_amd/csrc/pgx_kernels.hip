@@ -1079,8 +1079,15 @@ __device__ __forceinline__ uint32_t pgx_window_byte(uint64_t w0, uint64_t w1, ui
 // probe sat on the 5.8 GB image of the 4.35e9-symbol index (17 G lines/s).
 // S64: the image with a block every 64 positions (pgx_image.h): block b covers [64 b, 64 b + 96), so an interval of up to 32 positions
 // never needs a second block; the second block of one that does overlaps the first by 32 positions and is read from position 32 on.
-template <bool SEED, bool WIDE, bool PACKED, bool COOP, bool S64>
-__global__ void __launch_bounds__(PGX_FM_THREADS, (PACKED && !WIDE && !COOP) ? PGX_PAIRS_PACKED_WAVES : PGX_FM_WAVES_PER_SIMD) // (<= 96 VGPRs: five waves per SIMD fit and are what the launch uses; four are as fast -- 20.7 against 20.6-21.0 ms at chr22 scale --, three 21.8)
+// LCE (needs PACKED; narrow images without COOP): the forward stage of a MEM whose interval has become narrow (s <= img.lce_max occurrences) is finished
+// from the suffix array and the text (pgx_image.h "LCE image") instead of two symbols per line: every trip the lane compares what is left of its read with
+// the text behind ONE occurrence of the interval (SA[k + i], three 16-byte loads from one or two lines of the 2-bit text) and keeps the longest match and
+// the occurrences that reach it -- consecutive in suffix order, so they ARE the interval the stepwise extension would end with: MEM end = j + longest
+// match, bwt_start = k + index of the first of them, size = their number; the extensions count as if made one by one (the failing one included).  A MEM over
+// 8 haplotypes costs 9 trips and ~11 lines this way instead of ~33 and 33.  min_occ <= 1 only (the longest match decides); a window that touches a line
+// with an N or an endmarker sends the lane back to the stepwise path for that stage.  Results are bit-identical (tests run both ways).
+template <bool SEED, bool WIDE, bool PACKED, bool COOP, bool S64, bool LCE>
+__global__ void __launch_bounds__(PGX_FM_THREADS, (PACKED && !WIDE && !COOP && !LCE) ? PGX_PAIRS_PACKED_WAVES : PGX_FM_WAVES_PER_SIMD) // (<= 96 VGPRs: five waves per SIMD fit and are what the launch uses; four are as fast -- 20.7 against 20.6-21.0 ms at chr22 scale --, three 21.8)
 pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                            uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
                            pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
@@ -1096,6 +1103,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     __shared__ uint4 s_fe[PACKED ? 16 : 512];
     extern __shared__ __align__(16) unsigned char pgx_dyn_lds[];
     static_assert(!COOP || PACKED, "the cooperative loads come with the packed reads");
+    static_assert(!LCE || (PACKED && !WIDE && !COOP), "the text comparison reads the packed reads and 32-bit suffix array entries");
     constexpr uint32_t SYMS = PGX_PAIRS_SYMS, STRIDE = S64 ? PGX_PAIRS_STRIDE64 : PGX_PAIRS_SYMS;
     uint32_t *s_rd = reinterpret_cast<uint32_t *>(pgx_dyn_lds); // PACKED: word w of this thread's read at s_rd[w * blockDim.x + threadIdx.x] (pk_words words per thread)
     const uint32_t rd_stride = blockDim.x;
@@ -1134,6 +1142,9 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     bool exhausted = false;
     unsigned long long ln_blk = 0, ln_seed = 0, ln_two = 0; // wave-uniform (scalar registers): block lines / seed entries the wave asked for, trips with two extensions (PGX_CTR_PAIRS_*)
     uint32_t did2 = 0; // this lane's last trip performed two extensions (summed at the top of the next trip, where the wave is converged)
+    // LCE: bit 0 = the lane compares with the text (ph == 2), bit 1 = this stage must not (a flagged text line), bits 8..15 occurrence index, 16..23 index of
+    // the first occurrence with the longest match, 24..31 how many reach it; the longest match; the text position of the occurrence of the next trip
+    uint32_t lce_st = 0, lce_best = 0, lce_pos = 0;
 #ifdef PGX_FM_STATS
     unsigned long long st_trips = 0, st_live = 0, st_wait = 0, st_fresh = 0; // diagnostics build only (scripts/fm_stats.sh)
     unsigned long long st_t_refill = 0, st_refills = 0, st_t_seed = 0, st_t_line = 0;
@@ -1153,6 +1164,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             }
         }
         k = 0; kp = 0; s = n;
+        if (LCE) lce_st = 0u;
         if (min_len == 0) { Jk = 0; Js = n; j = x; ph = 2; }
         else { j = x + (int32_t)min_len - 1; ph = 1; fresh = 1u; }
     };
@@ -1164,6 +1176,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         slots[pgx_slot_index((uint64_t)rid - first_read, n_reads - first_read, slot, nm)] = m;
         nm++;
         k = 0; kp = 0; s = n;
+        if (LCE) lce_st = 0u;
         const bool more = j > x;
         ph = more ? 3 : ph;
         fresh = more ? 1u : fresh;
@@ -1266,7 +1279,28 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
-        if (ph > 0) {
+        // the five 16-byte pieces a lane loads in a trip: its block's row, counts and planes -- or, for a lane that compares with the text, three pieces of the
+        // text, the flag words of the lines they lie in and the next occurrence's suffix array entry (the same registers: nothing added to the trip's pressure)
+        uint4 row = make_uint4(0u, 0u, 0u, 0u), hs = row, d0 = row, d1 = row, d2 = row;
+        const bool lce_lane = LCE && ph == 2 && (lce_st & 1u) != 0u;
+        uint32_t lce_g0 = 0u;
+        bool em_now = false; // this trip ends with a MEM (set by either kind of lane); `restart`: with the next start position of the read
+        restart = 0u;
+        if (LCE && lce_lane) {
+            lce_g0 = lce_pos + (uint32_t)(j - x);           // text position that faces read symbol j
+            const uint32_t w0 = lce_g0 >> 4;                // its word (16 symbols); the window: words w0 .. w0 + 11
+            const uint32_t *tp = img.lce_text + w0;
+            typedef struct __attribute__((packed, aligned(4))) { uint32_t x, y, z, w; } u4_t; // (dword-aligned 16-byte pieces)
+            const u4_t a = *reinterpret_cast<const u4_t *>(tp), b = *reinterpret_cast<const u4_t *>(tp + 4), c = *reinterpret_cast<const u4_t *>(tp + 8);
+            row = make_uint4(a.x, a.y, a.z, a.w); hs = make_uint4(b.x, b.y, b.z, b.w); d0 = make_uint4(c.x, c.y, c.z, c.w);
+            const uint32_t l0 = w0 >> 5, l1 = (w0 + 11u) >> 5; // the lines of the window
+            d1.x = img.lce_flags[l0 >> 5] >> (l0 & 31u);
+            d1.y = img.lce_flags[l1 >> 5] >> (l1 & 31u);
+            const uint32_t i1 = ((lce_st >> 8) & 0xFFu) + 1u;
+            d1.z = img.lce_sa[(uint32_t)k + (i1 < (uint32_t)s ? i1 : 0u)];
+        }
+        if (LCE) ln_blk += (unsigned long long)__popcll(__ballot(lce_lane && ((lce_g0 >> 4) >> 5) != (((lce_g0 >> 4) + 11u) >> 5))); // a window over two lines
+        if (ph > 0 && !lce_lane) {
             const bool fr = fresh != 0u; // first extension of a backward stage: from first_ext / the seed table
             bool seed_lane = false;
             uint32_t kuse = 0u; // extensions the seed entry stands for
@@ -1349,7 +1383,6 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             // the second block starts STRIDE positions after the first and the first has answered up to its position SYMS
             const uint32_t relA = pend ? SYMS - STRIDE : p0 - bfirst * STRIDE;
             const uint32_t relB = pend ? endrel - STRIDE : (endrel < SYMS ? endrel : SYMS);
-            uint4 row, hs, d0, d1, d2;
             if (COOP) { // the line of this lane's probe is in LDS (fetched by the whole wave above)
                 const uint4 *mine = s_stage + (uint32_t)lane * 8u;
                 const uint32_t sw = (uint32_t)lane & 7u;
@@ -1527,10 +1560,51 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 x = rs_small ? j + 1 : (rs_end ? x + 1 : x);
                 ph = to2 ? 2 : ph;
                 j = jn;
-                if (em) emit();
-                if (restart) begin();
+                em_now = em;
+                // a forward stage over a narrow interval goes on through the text: from the next trip on one occurrence per trip (its first suffix array entry
+                // is asked for now); only where that is fewer trips than two symbols per trip, and where the window of three pieces holds what is left
+                if (LCE && img.lce_sa && ph == 2 && !em && !restart && !(lce_st & 2u) && s >= 1u && (uint32_t)s <= img.lce_max && mo <= 1u && j < len &&
+                    (uint32_t)(len - j) >= 2u * (uint32_t)s && (uint32_t)(len - j) <= 144u) {
+                    lce_st = 1u;
+                    lce_best = 0u;
+                    lce_pos = img.lce_sa[(uint32_t)k];
+                }
             }
         }
+        if (LCE && lce_lane) { // the text behind occurrence i of the interval against the read from symbol j on
+            const uint32_t T[12] = {row.x, row.y, row.z, row.w, hs.x, hs.y, hs.z, hs.w, d0.x, d0.y, d0.z, d0.w};
+            if ((d1.x | d1.y) & 1u) lce_st = 2u; // a line with an N / an endmarker / behind the text: this stage goes on stepwise (nothing has changed yet)
+            else {
+                const uint32_t rem = (uint32_t)(len - j), q0 = (uint32_t)(base & 15ull) + (uint32_t)j;
+                const uint32_t tsh = 2u * (lce_g0 & 15u), rsh = 2u * (q0 & 15u), rw0 = q0 >> 4;
+                uint32_t R[10];
+#pragma unroll
+                for (uint32_t u = 0; u < 10; u++) { const uint32_t wi = rw0 + u; R[u] = s_rd[(wi < pk_words ? wi : pk_words - 1u) * rd_stride + threadIdx.x]; }
+                uint32_t l = 144u;
+#pragma unroll
+                for (int u = 8; u >= 0; u--) { // (from the last unit down: the first differing one wins)
+                    const uint32_t df = __builtin_amdgcn_alignbit(R[u + 1], R[u], rsh) ^ __builtin_amdgcn_alignbit(T[u + 1], T[u], tsh);
+                    l = df ? 16u * (uint32_t)u + ((uint32_t)__builtin_ctz(df) >> 1) : l;
+                }
+                l = l < rem ? l : rem;
+                const uint32_t i = (lce_st >> 8) & 0xFFu;
+                uint32_t a = (lce_st >> 16) & 0xFFu, cnt = lce_st >> 24;
+                const bool better = i == 0u || l > lce_best;
+                cnt = better ? 1u : (l == lce_best ? cnt + 1u : cnt);
+                a = better ? i : a;
+                lce_best = better ? l : lce_best;
+                if (i + 1u < (uint32_t)s) { lce_st = 1u | ((i + 1u) << 8) | (a << 16) | (cnt << 24); lce_pos = d1.z; }
+                else { // every occurrence seen: the MEM ends where the longest match ends; the occurrences that reach it are its interval
+                    Jk = k + (pos_t)a; Js = (pos_t)cnt;
+                    next += lce_best + (lce_best < rem ? 1u : 0u); // (the extension that fails counts, as in the stepwise stage)
+                    j += (int32_t)lce_best;
+                    lce_st = 0u;
+                    em_now = true;
+                }
+            }
+        }
+        if (em_now) emit();
+        if (restart) begin();
     }
     unsigned long long tot = next;
 #pragma unroll
@@ -1551,18 +1625,20 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                                                                      pgx_mem *, uint32_t *, unsigned long long *, unsigned long long *, uint64_t, uint64_t, uint32_t, \
                                                                      uint32_t, pgx_heavy_item *, unsigned long long *, const uint8_t *, const uint32_t *, uint32_t,  \
                                                                      uint32_t *, uint64_t);
-PGX_PAIRS_INSTANTIATE(true, false, false, false, false)
-PGX_PAIRS_INSTANTIATE(true, true, false, false, false)
-PGX_PAIRS_INSTANTIATE(true, false, true, false, false)
-PGX_PAIRS_INSTANTIATE(true, true, true, false, false)
-PGX_PAIRS_INSTANTIATE(true, false, true, true, false)
-PGX_PAIRS_INSTANTIATE(true, true, true, true, false)
-PGX_PAIRS_INSTANTIATE(true, false, false, false, true)
-PGX_PAIRS_INSTANTIATE(true, true, false, false, true)
-PGX_PAIRS_INSTANTIATE(true, false, true, false, true)
-PGX_PAIRS_INSTANTIATE(true, true, true, false, true)
-PGX_PAIRS_INSTANTIATE(true, false, true, true, true)
-PGX_PAIRS_INSTANTIATE(true, true, true, true, true)
+PGX_PAIRS_INSTANTIATE(true, false, false, false, false, false)
+PGX_PAIRS_INSTANTIATE(true, true, false, false, false, false)
+PGX_PAIRS_INSTANTIATE(true, false, true, false, false, false)
+PGX_PAIRS_INSTANTIATE(true, true, true, false, false, false)
+PGX_PAIRS_INSTANTIATE(true, false, true, true, false, false)
+PGX_PAIRS_INSTANTIATE(true, true, true, true, false, false)
+PGX_PAIRS_INSTANTIATE(true, false, false, false, true, false)
+PGX_PAIRS_INSTANTIATE(true, true, false, false, true, false)
+PGX_PAIRS_INSTANTIATE(true, false, true, false, true, false)
+PGX_PAIRS_INSTANTIATE(true, true, true, false, true, false)
+PGX_PAIRS_INSTANTIATE(true, false, true, true, true, false)
+PGX_PAIRS_INSTANTIATE(true, true, true, true, true, false)
+PGX_PAIRS_INSTANTIATE(true, false, true, false, false, true)
+PGX_PAIRS_INSTANTIATE(true, false, true, false, true, true)
 
 // first extension of every backward stage: the full interval extended by each byte value
 __global__ void __launch_bounds__(256) pgx_first_ext_kernel(PgxDevImage img, uint4 *__restrict__ out) { // out[512]

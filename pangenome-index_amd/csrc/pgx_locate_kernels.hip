@@ -82,3 +82,44 @@ pgx_locate_walk_kernel(PgxLocImage loc, const uint64_t *__restrict__ qs, const u
         v = pgx_locate_next(loc, v);
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// LCE image (pgx_image.h): the suffix array in text coordinates, the text at two bits per symbol, one flag per 128-byte line of it.
+// `sa` = the packed values pgx_locate_walk_kernel writes (sequence * max_length + offset, r-index.hpp:429-431).  The text is the collection as
+// the index sees it: sequence q at [seq_start[q], seq_start[q] + len_q), its endmarker behind it.
+__global__ void __launch_bounds__(256)
+pgx_lce_seqlen_kernel(const uint64_t *__restrict__ sa, uint64_t n_seq, uint64_t max_length, unsigned long long *__restrict__ seq_len) {
+    // BWT positions [0, n_seq) are the suffixes that start with an endmarker: the one of sequence q sits at offset len_q
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_seq) return;
+    const uint64_t v = sa[i], q = v / max_length;
+    if (q < n_seq) seq_len[q] = v % max_length + 1; // (with its endmarker)
+}
+__global__ void __launch_bounds__(256)
+pgx_lce_scatter_kernel(const uint64_t *__restrict__ sa, uint64_t n, uint64_t max_length, const uint64_t *__restrict__ seq_start, uint64_t n_seq, uint64_t c1, uint64_t c2,
+                       uint64_t c3, uint64_t c4, uint64_t c5, uint32_t *__restrict__ sa32, uint8_t *__restrict__ text8, unsigned long long *__restrict__ bad) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t v = sa[i], q = v / max_length;
+        const uint64_t g = q < n_seq ? seq_start[q] + v % max_length : n;
+        if (g >= n) { atomicAdd(bad, 1ull); sa32[i] = 0; continue; } // (a sample outside the collection: the image is not built)
+        sa32[i] = (uint32_t)g;
+        // first symbol of suffix i: the C-bucket of i (\n A C G N T); codes of the packed reads: A C T G = 0 1 2 3, anything else 0xFF
+        text8[g] = i < c1 ? 0xFFu : (i < c2 ? 0u : (i < c3 ? 1u : (i < c4 ? 3u : (i < c5 ? 0xFFu : 2u))));
+    }
+}
+__global__ void __launch_bounds__(256)
+pgx_lce_pack_kernel(const uint8_t *__restrict__ text8, uint64_t n, uint64_t n_words, uint32_t *__restrict__ text32, uint32_t *__restrict__ flags) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = 0;
+        bool special = false;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) {
+            const uint64_t g = 16 * w + k;
+            const uint32_t c = g < n ? (uint32_t)text8[g] : 0xFFu;
+            special |= c > 3u;
+            v |= (c & 3u) << (2u * k);
+        }
+        text32[w] = v;
+        if (special) atomicOr(flags + (w >> 10), 1u << ((w >> 5) & 31u)); // word w lies in line w / 32 (128 bytes = 32 words); 32 lines per flag word
+    }
+}

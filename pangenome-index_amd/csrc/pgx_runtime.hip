@@ -84,6 +84,8 @@ struct pgx_device_image {
     PgxDevImage img{};
     DevBuf blocks, dir, blow, consts, tstart, tvals, tdir, tpair, tbucket, seed, seed_small, seed_end, exc, pairs, first_ext, sbase2, pbase;
     DevBuf rstart, rsamp, rdir, lpos, lnext, ldir; // locate image, uploaded on first use
+    DevBuf lce_sa, lce_text, lce_flags;            // LCE image (ensure_lce), built on the first batch
+    int lce_state = 0;                             // 0 not tried, 1 built, 2 not available for this index / device
     DevBuf lit_bstart, lit_cum, lit_runs, lit_roff, lit_tabs; // literal count image (quirk 3), uploaded on first use
     PgxLitImage lit{};
     bool has_lit = false;
@@ -100,6 +102,7 @@ void pgx_release_device_images(pgx_index *h) {
             d->tstart.release(); d->tvals.release(); d->tdir.release(); d->tpair.release(); d->tbucket.release(); d->seed.release(); d->seed_small.release(); d->seed_end.release(); d->exc.release(); d->pairs.release(); d->first_ext.release(); d->sbase2.release(); d->pbase.release();
             d->lit_bstart.release(); d->lit_cum.release(); d->lit_runs.release(); d->lit_roff.release(); d->lit_tabs.release();
             d->rstart.release(); d->rsamp.release(); d->rdir.release(); d->lpos.release(); d->lnext.release(); d->ldir.release();
+            d->lce_sa.release(); d->lce_text.release(); d->lce_flags.release();
         }
         delete d;
     }
@@ -243,6 +246,7 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
     g.seed_k_main = g.seed_k_small = 0;
     g.seed_main = g.seed_small = nullptr;
     g.pairs = nullptr; g.first_ext = nullptr; g.pair_runs = 0;
+    g.lce_sa = nullptr; g.lce_text = nullptr; g.lce_flags = nullptr; g.lce_max = 0;
     if (g.dense && h->has_rank) build_seed_table(d.get());
     if (m.consts.has_pairs && !m.pairs.empty() && h->has_rank) { // the two-step image next to dense2 (pgx_image.h)
         upload(d->pairs, m.pairs.data(), m.pairs.size());
@@ -1196,6 +1200,79 @@ static void batch_upload_packed(pgx_batch *b, const uint32_t *packed, const uint
     b->side_reads_est = n_side;
 }
 
+// LCE image (pgx_image.h): suffix array in text coordinates + the text at two bits per symbol, for the pairs kernel's forward stages over narrow intervals.
+// Built once per device image, on the device: the suffix array by the locate kernels (every BWT run is an independent chain from its sample), the text from
+// it (the first symbol of suffix i is the one whose C-bucket holds i).  Only next to a narrow PAIRS image (textbook tables, n < 2^32); PGX_FM_LCE=0: never.
+static std::mutex g_lce_mutex;
+static void ensure_lce(pgx_index *h, pgx_device_image *d) {
+    std::lock_guard<std::mutex> lock(g_lce_mutex);
+    if (d->lce_state) return;
+    d->lce_state = 2;
+    const char *env = std::getenv("PGX_FM_LCE");
+    const uint64_t n = d->img.n;
+    if ((env && env[0] == '0') || !d->img.pairs || d->img.wide || n < 4096 || n >= (1ull << 32) - (1ull << 20) || h->ri.max_length == 0) return;
+    uint64_t tot[6] = {0, 0, 0, 0, 0, 0}; // symbol counts of the BWT = bucket bounds of the first column
+    for (const auto &blk : h->ri.blocks)
+        for (const auto &ru : blk.runs) if (ru.first < 6) tot[ru.first] += ru.second;
+    const uint64_t n_seq = tot[0];
+    if (tot[0] + tot[1] + tot[2] + tot[3] + tot[4] + tot[5] != n || n_seq == 0 || n_seq > (1ull << 24)) return;
+    {
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); return; }
+        if ((double)mem_free < 16.0 * (double)n + (double)(2ull << 30)) return; // 8 n (suffix array as the locate kernels write it) + n (text bytes) + 4.25 n (the image) + room
+    }
+    DevBuf vals, seq_len, seq_start, text8, bad;
+    try {
+        pgx_device_image *dl = locate_image(h, d->device);
+        if (!dl->loc.n || dl->loc.n != n) throw Error(PGX_ERR_UNSUPPORTED, "no locate image");
+        const uint64_t first = 0, last = n - 1;
+        std::vector<uint64_t> off;
+        uint64_t nv = 0;
+        locate_core(h, dl, &first, &last, 1, 0, off, vals, nv);
+        if (nv != n) throw Error(PGX_ERR_UNSUPPORTED, "suffix array incomplete");
+        const uint64_t ml = h->ri.max_length;
+        seq_len.ensure(n_seq * 8); seq_start.ensure((n_seq + 1) * 8); bad.ensure(16);
+        HIPCHECK(hipMemset(seq_len.p, 0, n_seq * 8));
+        HIPCHECK(hipMemset(bad.p, 0, 16));
+        hipLaunchKernelGGL(pgx_lce_seqlen_kernel, dim3(grid_for(n_seq, 256)), dim3(256), 0, nullptr, vals.as<uint64_t>(), n_seq, ml, seq_len.as<unsigned long long>());
+        HIPCHECK(hipGetLastError());
+        std::vector<uint64_t> hl(n_seq), hs(n_seq + 1, 0);
+        HIPCHECK(hipMemcpy(hl.data(), seq_len.p, n_seq * 8, hipMemcpyDeviceToHost));
+        for (uint64_t q = 0; q < n_seq; q++) { if (hl[q] == 0) throw Error(PGX_ERR_UNSUPPORTED, "a sequence without an endmarker suffix"); hs[q + 1] = hs[q] + hl[q]; }
+        if (hs[n_seq] != n) throw Error(PGX_ERR_UNSUPPORTED, "sequence lengths do not add up to the BWT size");
+        HIPCHECK(hipMemcpy(seq_start.p, hs.data(), (n_seq + 1) * 8, hipMemcpyHostToDevice));
+        const uint64_t n_words = (n + 15) / 16 + 64, n_flag_words = n_words / 1024 + 2; // (64 words = two lines of padding behind the text, flagged)
+        text8.ensure(n);
+        d->lce_sa.ensure(n * 4);
+        d->lce_text.ensure(n_words * 4);
+        d->lce_flags.ensure(n_flag_words * 4);
+        HIPCHECK(hipMemset(d->lce_flags.p, 0, n_flag_words * 4));
+        const uint64_t c1 = tot[0], c2 = c1 + tot[1], c3 = c2 + tot[2], c4 = c3 + tot[3], c5 = c4 + tot[4];
+        hipLaunchKernelGGL(pgx_lce_scatter_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 20)), dim3(256), 0, nullptr, vals.as<uint64_t>(), n, ml,
+                           seq_start.as<uint64_t>(), n_seq, c1, c2, c3, c4, c5, d->lce_sa.as<uint32_t>(), text8.as<uint8_t>(), bad.as<unsigned long long>());
+        HIPCHECK(hipGetLastError());
+        unsigned long long n_bad = 0;
+        HIPCHECK(hipMemcpy(&n_bad, bad.p, 8, hipMemcpyDeviceToHost));
+        if (n_bad) throw Error(PGX_ERR_UNSUPPORTED, "suffix array values outside the collection");
+        vals.release();
+        hipLaunchKernelGGL(pgx_lce_pack_kernel, dim3((unsigned)std::min<uint64_t>((n_words + 255) / 256, 1u << 20)), dim3(256), 0, nullptr, text8.as<uint8_t>(), n, n_words,
+                           d->lce_text.as<uint32_t>(), d->lce_flags.as<uint32_t>());
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipDeviceSynchronize());
+        d->img.lce_sa = d->lce_sa.as<uint32_t>();
+        d->img.lce_text = d->lce_text.as<uint32_t>();
+        d->img.lce_flags = d->lce_flags.as<uint32_t>();
+        d->img.lce_max = 16;
+        if (const char *e = std::getenv("PGX_FM_LCE_MAX")) d->img.lce_max = (uint32_t)std::min<unsigned long>(std::strtoul(e, nullptr, 10), 31ul);
+        d->lce_state = 1;
+    } catch (...) { // (no LCE image: the search runs on the PAIRS image alone, as before)
+        (void)hipGetLastError();
+        d->lce_sa.release(); d->lce_text.release(); d->lce_flags.release();
+        d->img.lce_sa = nullptr; d->img.lce_text = nullptr; d->img.lce_flags = nullptr;
+    }
+    vals.release(); seq_len.release(); seq_start.release(); text8.release(); bad.release();
+}
+
 extern "C" pgx_status pgx_batch_create(pgx_index *h, int device, const uint8_t *reads, const uint64_t *offsets,
                                        uint64_t n_reads, pgx_batch **out) {
     PGX_GUARD_BEGIN
@@ -1204,6 +1281,7 @@ extern "C" pgx_status pgx_batch_create(pgx_index *h, int device, const uint8_t *
     if (!h->has_rank) throw Error(PGX_ERR_ARG, "pgx_batch_create: index opened without an r-index");
     *out = nullptr;
     pgx_device_image *dimg = device_image(h, device);
+    ensure_lce(h, dimg);
     std::unique_ptr<pgx_batch, void (*)(pgx_batch *)> b(new pgx_batch(), batch_release);
     b->h = h;
     b->dimg = dimg;
@@ -1361,8 +1439,8 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
         if (img.pairs && seeded && !(n >> 32) && b->read_bytes < (1ull << 35) && !(pv && pv[0] == '0'))
         {
             const bool s64 = img.pairs_stride == PGX_PAIRS_STRIDE64;
-            kfn_pairs = img.wide ? (s64 ? (const void *)pgx_find_mems_pairs_kernel<true, true, false, false, true> : (const void *)pgx_find_mems_pairs_kernel<true, true, false, false, false>)
-                                 : (s64 ? (const void *)pgx_find_mems_pairs_kernel<true, false, false, false, true> : (const void *)pgx_find_mems_pairs_kernel<true, false, false, false, false>);
+            kfn_pairs = img.wide ? (s64 ? (const void *)pgx_find_mems_pairs_kernel<true, true, false, false, true, false> : (const void *)pgx_find_mems_pairs_kernel<true, true, false, false, false, false>)
+                                 : (s64 ? (const void *)pgx_find_mems_pairs_kernel<true, false, false, false, true, false> : (const void *)pgx_find_mems_pairs_kernel<true, false, false, false, false, false>);
         }
         pairs_lds = img.wide ? (size_t)img.n_sbp * 192 : 0; // (superblock bases of the wide form, behind the other dynamic LDS)
         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn_pairs ? kfn_pairs : kfn, PGX_FM_THREADS, kfn_pairs ? pairs_lds : b->dimg->lds_bytes));
@@ -1512,13 +1590,19 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                         const bool s64 = img.pairs_stride == PGX_PAIRS_STRIDE64;
                         bool coop = b->h->img.pairs.size() > (3ull << 30);
                         if (const char *ce = std::getenv("PGX_FM_COOP")) coop = ce[0] == '1';
-#define PGX_PK(W, C) (s64 ? (const void *)pgx_find_mems_pairs_kernel<true, W, true, C, true> : (const void *)pgx_find_mems_pairs_kernel<true, W, true, C, false>)
+#define PGX_PK(W, C) (s64 ? (const void *)pgx_find_mems_pairs_kernel<true, W, true, C, true, false> : (const void *)pgx_find_mems_pairs_kernel<true, W, true, C, false, false>)
                         kp = coop ? (img.wide ? PGX_PK(true, true) : PGX_PK(false, true)) : (img.wide ? PGX_PK(true, false) : PGX_PK(false, false));
 #undef PGX_PK
+                        // forward stages over narrow intervals through the suffix array and the text (pgx_image.h "LCE image"; min_occ <= 1: the longest match decides)
+                        const char *le = std::getenv("PGX_FM_LCE");
+                        if (img.lce_sa && !coop && !img.wide && min_occ <= 1 && !(le && le[0] == '0')) {
+                            kp = s64 ? (const void *)pgx_find_mems_pairs_kernel<true, false, true, false, true, true> : (const void *)pgx_find_mems_pairs_kernel<true, false, true, false, false, true>;
+                            b->timing.pairs_reads = 4u;
+                        }
                         a_packed = b->packed.as<uint32_t>();
                         a_pkw = pkw;
                         plds = (size_t)pkw * PGX_FM_THREADS * 4 + (coop ? (size_t)(PGX_FM_THREADS / 64) * 8192 : 0) + (img.wide ? (size_t)img.n_sbp * 192 : 0);
-                        b->timing.pairs_reads = coop ? 3u : 2u;
+                        if (b->timing.pairs_reads != 4u) b->timing.pairs_reads = coop ? 3u : 2u;
                         int occ_p = 0;
                         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_p, kp, PGX_FM_THREADS, plds));
                         if (occ_p < 1) occ_p = 1;

@@ -65,7 +65,7 @@ def test_chr22_scale_automatic_layout(workdir):
     b1 = idx.batch(cat1, offs1)
     b1.run(20, 1, P.RUN_TAGS | P.RUN_TIMING)
     t = b1.timing()
-    assert t.pairs_reads == 2 and t.main_lines > 0 and t.main_seed_loads > 0  # the two-step kernel behind the seed table ran, reads packed in LDS
+    assert t.pairs_reads == 4 and t.main_lines > 0 and t.main_seed_loads > 0  # the two-step kernel behind the seed table ran, reads packed in LDS, narrow forward stages through the text
     assert t.seed_depth == 15 and t.find_mems_launches == 1
     res = b1.result()
     b1.free()

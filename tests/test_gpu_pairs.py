@@ -178,7 +178,7 @@ def test_pairs_kernel_read_lengths(pan, read_len, variant):
         b = idx.batch(cat, offs)
         b.run(min_len, min_occ, flags=P.RUN_TAGS | P.RUN_TIMING)
         _same(b.result(), ref)
-        assert b.timing().pairs_reads == variant
+        assert b.timing().pairs_reads == (4 if (variant == 2 and min_occ <= 1) else variant)  # (4: packed reads + narrow forward stages through the text, min_occ <= 1)
         b.free()
     idx.close()
 
@@ -302,7 +302,7 @@ def test_wide_intervals_and_the_run_continuation(workdir, monkeypatch, haps):
             b = idx.batch(cat, offs)
             b.run(pr[0], pr[1], P.RUN_TAGS | P.RUN_TIMING)
             t = b.timing()
-            assert t.pairs_reads == (3 if coop else 2)
+            assert t.pairs_reads == (3 if coop else (2 if wide else 4))  # (4: packed reads + forward stages through the text, narrow images only)
             _same(b.result(), ref)
             if pr == (20, 1):
                 lines[(ext, stride, wide, coop)] = int(t.main_lines)
@@ -312,3 +312,51 @@ def test_wide_intervals_and_the_run_continuation(workdir, monkeypatch, haps):
     assert lines[(None, "64", 1, None)] == with_ext == lines[(None, "64", 0, "1")]  # the same trips in every variant
     # (24 haplotypes: intervals stay below the 32 positions a block every 64 always covers -- nothing to gain, nothing lost; 48 and 80: second lines saved)
     assert with_ext <= without and (haps == 24 or with_ext < 0.9 * without), (haps, with_ext, without)
+
+
+@pytest.mark.parametrize("haps,stride", [(4, "64"), (12, "64"), (12, "96"), (40, "64")])
+def test_forward_stages_through_the_text(workdir, monkeypatch, haps, stride):
+    """pgx_find_mems_pairs_kernel<.., LCE>: where a forward stage's interval is narrow (<= 16 occurrences) the kernel finishes it from the suffix array and
+    the text -- one occurrence per trip, longest match and the occurrences that reach it -- instead of two symbols per trip (algorithm.hpp:676-700 is the
+    loop it replaces: the forward extensions of find_mems_function).  Same bytes as the oracle and as the stepwise kernel (PGX_FM_LCE=0), extension counts
+    included, for min_occ 0 / 1 (min_occ > 1 never takes this path); reads that end / start a sequence, reads over N runs (flagged text lines), short reads,
+    reads longer than the 144 symbols a text window holds; 40 haplotypes: intervals too wide, the path is not taken; and fewer lines where it is."""
+    text = os.path.join(workdir, "lce_%d.txt" % haps)
+    W.synth_pangenome_text(text, base_len=1_200_000 // haps, n_hap=haps, seed=70 + haps, n_runs=3, n_run_len=(60, 900))
+    ri_path, tags_path = W.build_index_from_text(text, workdir, "lce_%d" % haps)[:2]
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    seqs = W.load_sequences(text)
+    cat, offs = W.sample_reads(seqs, 25_000, 150, seed=11, n_frac=0.03)
+    rng = np.random.default_rng(5)
+    extra = [bytes(seqs[0][-150:]), bytes(seqs[1][:150]), bytes(seqs[-1][-150:]), b"ACGT" * 30, b"", b"A", b"N" * 30]
+    for _ in range(400):  # ragged lengths, some longer than a text window
+        sq = seqs[int(rng.integers(0, len(seqs)))]
+        ln = int(rng.integers(1, 340))
+        a = int(rng.integers(0, len(sq) - ln))
+        extra.append(bytes(sq[a:a + ln]))
+    ecat, eoffs = O.pack_reads(extra)
+    cat = np.concatenate([cat, ecat]); offs = np.concatenate([offs, eoffs[1:] + offs[-1]])
+    monkeypatch.setenv("PGX_PAIRS_STRIDE", stride)
+    refs = {pr: O.find_mems_batch(ri, tags, cat, offs, pr[0], pr[1], threads=O.lib().orc_max_threads()) for pr in ((20, 1), (12, 1), (25, 0), (20, 3))}
+    lines = {}
+    for lce in ("0", None):
+        if lce is None:
+            monkeypatch.delenv("PGX_FM_LCE", raising=False)
+        else:
+            monkeypatch.setenv("PGX_FM_LCE", lce)
+        idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | P.MODE_IMAGE_PAIRS)
+        for pr, ref in refs.items():
+            b = idx.batch(cat, offs)
+            for _ in range(2):
+                b.run(pr[0], pr[1], P.RUN_TAGS | P.RUN_TIMING)
+                t = b.timing()
+                assert t.pairs_reads == (4 if (lce is None and pr[1] <= 1) else 2), (lce, pr, t.pairs_reads)
+                _same(b.result(), ref)
+            if pr == (20, 1):
+                lines[lce] = int(t.main_lines)
+            b.free()
+        idx.close()
+    if haps <= 12:
+        assert lines[None] < 0.8 * lines["0"], (haps, lines)
+    else:
+        assert lines[None] <= 1.02 * lines["0"], (haps, lines)
