@@ -99,6 +99,16 @@
  * (Round 3 also tried blocks of 64 positions read as three 16-byte pieces instead of five: fewer requests per line changed nothing, the extra
  * lines of the shorter blocks did -- profiles/r03_pairs64_layout.json -- and the layout was dropped.) */
 #define PGX_PAIRS_STRIDE64 64u
+/* LCE image (round 4; device only, built on the device next to a narrow PAIRS image: pgx_runtime.hip ensure_lce):
+ *   lce_sa[i]     u32: where suffix i of the BWT order starts in lce_text (the r-index's samples expanded to the whole suffix array by the locate
+ *                 kernels, sequence * max_length + offset -> start of the sequence + offset)
+ *   lce_text      the collection itself, two bits per symbol, 16 symbols per u32, A C T G = 0 1 2 3 (the order of the packed reads: XOR compares
+ *                 16 symbols at once); every sequence followed by its endmarker; N and endmarkers read as 0 and are covered by
+ *   lce_flags     one bit per 128-byte line of lce_text (512 symbols): the line holds an N, an endmarker, or lies behind the text
+ * 4.25 n bytes (chr22 scale: 2.7 GB).  The forward stage of find_mems_function (algorithm.hpp:676-700: forward_extend until the interval is "small") over
+ * an interval of s <= 16 occurrences is finished by comparing the read with the text at SA[k] .. SA[k + s - 1] -- the occurrences that match longest are
+ * consecutive and ARE the interval the extensions would end with -- in s trips of ~1.3 lines instead of (match length) / 2 trips of one line.  The text
+ * is recovered from the index alone: the first symbol of suffix i is the symbol whose C-bucket holds i. */
 /* WIDE variants of DENSE2 and PAIRS (BWTs of 2^32 symbols or more, up to PGX_SB_MAX superblocks; FastLocate is size_t end to end,
  * r-index.hpp:118-130): the same 128-byte blocks, but every count in a block header is a 32-bit DELTA against its superblock --
  * 2^sb_shift consecutive blocks, at most 2^31 symbols -- whose 64-bit bases sit in a small table the kernels stage in LDS:
