@@ -216,6 +216,7 @@ __global__ void pgx_lce_seqlen_kernel(const uint64_t *sa, uint64_t n_seq, uint64
 __global__ void pgx_lce_scatter_kernel(const uint64_t *sa, uint64_t n, uint64_t max_length, const uint64_t *seq_start, uint64_t n_seq, uint64_t c1, uint64_t c2, uint64_t c3,
                                        uint64_t c4, uint64_t c5, uint32_t *sa32, uint8_t *text8, unsigned long long *bad);
 __global__ void pgx_lce_pack_kernel(const uint8_t *text8, uint64_t n, uint64_t n_words, uint32_t *text32, uint32_t *flags);
+__global__ void pgx_lce_rc_check_kernel(const uint8_t *text8, const uint64_t *seq_start, uint64_t n_seq, uint64_t n, unsigned long long *bad);
 __global__ void pgx_locate_plan_kernel(PgxLocImage loc, const uint64_t *qs, const uint64_t *qe, uint64_t n, uint64_t *run0,
                                        uint64_t *n_pieces);
 __global__ void pgx_locate_walk_kernel(PgxLocImage loc, const uint64_t *qs, const uint64_t *qe, uint64_t n_queries,

@@ -123,3 +123,23 @@ pgx_lce_pack_kernel(const uint8_t *__restrict__ text8, uint64_t n, uint64_t n_wo
         if (special) atomicOr(flags + (w >> 10), 1u << ((w >> 5) & 31u)); // word w lies in line w / 32 (128 bytes = 32 words); 32 lines per flag word
     }
 }
+
+// The text comparison stands for FORWARD extensions, and the FMD index answers those through the reverse complement (src/r-index.cpp:758-764): the two agree
+// only where the collection holds every sequence in both orientations.  Checked here for the layout the reference's pipeline and the synthetic workloads
+// write -- sequence 2 i + 1 is the reverse complement of sequence 2 i --; any position that disagrees raises the flag and the image is not built.
+__global__ void __launch_bounds__(256)
+pgx_lce_rc_check_kernel(const uint8_t *__restrict__ text8, const uint64_t *__restrict__ seq_start, uint64_t n_seq, uint64_t n, unsigned long long *__restrict__ bad) {
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t lo = 0, hi = n_seq; // the sequence holding g: the last one whose start is <= g
+        while (lo + 1 < hi) { const uint64_t mid = (lo + hi) >> 1; if (seq_start[mid] <= g) lo = mid; else hi = mid; }
+        const uint64_t q = lo, t = g - seq_start[q], L = seq_start[q + 1] - seq_start[q] - 1; // (without the endmarker)
+        if (t >= L) continue;
+        const uint64_t p = q ^ 1ull;
+        bool ok = p < n_seq && seq_start[p + 1] - seq_start[p] - 1 == L;
+        if (ok) {
+            const uint32_t c = text8[g], o = text8[seq_start[p] + (L - 1 - t)];
+            ok = c > 3u ? o > 3u : o == (c ^ 2u); // A C T G = 0 1 2 3: the complement flips bit 1; N faces N
+        }
+        if (!ok) { atomicAdd(bad, 1ull); return; }
+    }
+}

@@ -1255,6 +1255,13 @@ static void ensure_lce(pgx_index *h, pgx_device_image *d) {
         HIPCHECK(hipMemcpy(&n_bad, bad.p, 8, hipMemcpyDeviceToHost));
         if (n_bad) throw Error(PGX_ERR_UNSUPPORTED, "suffix array values outside the collection");
         vals.release();
+        // both orientations of every sequence (pgx_lce_rc_check_kernel): a forward-only collection is searched stepwise, as the reference's arithmetic has it
+        if (n_seq & 1) throw Error(PGX_ERR_UNSUPPORTED, "odd number of sequences");
+        hipLaunchKernelGGL(pgx_lce_rc_check_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 20)), dim3(256), 0, nullptr, text8.as<uint8_t>(),
+                           seq_start.as<uint64_t>(), n_seq, n, bad.as<unsigned long long>());
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpy(&n_bad, bad.p, 8, hipMemcpyDeviceToHost));
+        if (n_bad) throw Error(PGX_ERR_UNSUPPORTED, "the collection does not hold every sequence next to its reverse complement");
         hipLaunchKernelGGL(pgx_lce_pack_kernel, dim3((unsigned)std::min<uint64_t>((n_words + 255) / 256, 1u << 20)), dim3(256), 0, nullptr, text8.as<uint8_t>(), n, n_words,
                            d->lce_text.as<uint32_t>(), d->lce_flags.as<uint32_t>());
         HIPCHECK(hipGetLastError());

@@ -360,3 +360,34 @@ def test_forward_stages_through_the_text(workdir, monkeypatch, haps, stride):
         assert lines[None] < 0.8 * lines["0"], (haps, lines)
     else:
         assert lines[None] <= 1.02 * lines["0"], (haps, lines)
+
+
+def test_no_text_comparison_on_a_forward_only_collection(workdir, monkeypatch):
+    """the FMD index answers forward extensions through the reverse complement (src/r-index.cpp:758-764): on a collection that does not hold its sequences in
+    both orientations that is NOT "the occurrences of the longer pattern", so the text comparison must not stand in for it -- the LCE image is not built and
+    the kernel runs stepwise (the reference's arithmetic, whatever it means there), same bytes as the oracle"""
+    rng = np.random.default_rng(77)
+    base = "".join("ACGT"[i] for i in rng.integers(0, 4, 20000))
+    text = os.path.join(workdir, "fwd_only.txt")
+    with open(text, "w") as f:
+        for h in range(4):
+            s = list(base)
+            for i in rng.integers(0, len(s), 200):
+                s[i] = "ACGT"[rng.integers(0, 4)]
+            if h == 1:
+                s[5000:5040] = "N" * 40
+            f.write("".join(s) + "\n")
+    ri_path, tags_path = W.build_index_from_text(text, workdir, "fwd_only")[:2]
+    ri, tags = O.RIndex(ri_path), O.Tags(tags_path, O.TAGS_COMPACT)
+    seqs = W.load_sequences(text)
+    cat, offs = W.sample_reads(seqs, 8000, 150, seed=3, rc_frac=0.0)
+    monkeypatch.setenv("PGX_SEED_K", "7")
+    idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | P.MODE_IMAGE_PAIRS)
+    for min_len, min_occ in ((20, 1), (10, 1)):
+        ref = O.find_mems_batch(ri, tags, cat, offs, min_len, min_occ, threads=O.lib().orc_max_threads())
+        b = idx.batch(cat, offs)
+        b.run(min_len, min_occ, P.RUN_TAGS | P.RUN_TIMING)
+        assert b.timing().pairs_reads == 2  # packed reads, no text comparison
+        _same(b.result(), ref)
+        b.free()
+    idx.close()
