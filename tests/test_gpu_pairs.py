@@ -302,7 +302,7 @@ def test_wide_intervals_and_the_run_continuation(workdir, monkeypatch, haps):
             b = idx.batch(cat, offs)
             b.run(pr[0], pr[1], P.RUN_TAGS | P.RUN_TIMING)
             t = b.timing()
-            assert t.pairs_reads == (3 if coop else (2 if wide else 4))  # (4: packed reads + forward stages through the text, narrow images only)
+            assert t.pairs_reads == (3 if coop else (4 if (not wide and pr[1] <= 1) else 2))  # (4: packed reads + forward stages through the text: narrow images, min_occ <= 1)
             _same(b.result(), ref)
             if pr == (20, 1):
                 lines[(ext, stride, wide, coop)] = int(t.main_lines)
