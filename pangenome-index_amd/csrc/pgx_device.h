@@ -94,6 +94,7 @@ struct PgxDevImage {
     const uint32_t *lce_text;  // two bits per symbol (A C T G = 0 1 2 3, the order of the packed reads), 16 symbols per word, sequences with their endmarkers
     const uint32_t *lce_flags; // one bit per 128-byte line of lce_text: the line holds a symbol outside A C G T or lies behind the text
     uint32_t lce_max;          // widest interval that goes this way
+    uint32_t refill_min;       // LCE kernel: idle lanes of a wave wait for this many before the wave fetches new reads
 };
 #define PGX_SEED_UNUSABLE 255u // depth value of entries the kernels must not use (a coordinate does not fit the entry)
 #define PGX_SEED_MAX_K 16

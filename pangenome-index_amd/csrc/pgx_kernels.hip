@@ -1191,6 +1191,10 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         // (profiles/r03_wave_priority.txt; the same priority for every wave, or the opposite order, is slower).
         __builtin_amdgcn_s_setprio(3);
         unsigned long long idle = __ballot(ph == 0);
+        // (LCE: a read is ~28 lane trips now instead of ~73, so two or three lanes of a wave finish one in EVERY trip and a refill round -- two memory
+        //  latencies in front of the trip's own -- ran in nine trips out of ten, a quarter of the waves' time: idle lanes now wait until img.refill_min of
+        //  them have gathered, or until no lane of the wave is live)
+        if (LCE && idle && (uint32_t)__popcll(idle) < img.refill_min && __popcll(idle) != 64) idle = 0ull;
 #ifdef PGX_FM_STATS
         const unsigned long long st_r0 = __builtin_readcyclecounter();
         if (idle) st_refills++;

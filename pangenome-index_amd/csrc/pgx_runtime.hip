@@ -246,7 +246,7 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
     g.seed_k_main = g.seed_k_small = 0;
     g.seed_main = g.seed_small = nullptr;
     g.pairs = nullptr; g.first_ext = nullptr; g.pair_runs = 0;
-    g.lce_sa = nullptr; g.lce_text = nullptr; g.lce_flags = nullptr; g.lce_max = 0;
+    g.lce_sa = nullptr; g.lce_text = nullptr; g.lce_flags = nullptr; g.lce_max = 0; g.refill_min = 1;
     if (g.dense && h->has_rank) build_seed_table(d.get());
     if (m.consts.has_pairs && !m.pairs.empty() && h->has_rank) { // the two-step image next to dense2 (pgx_image.h)
         upload(d->pairs, m.pairs.data(), m.pairs.size());
@@ -1271,6 +1271,8 @@ static void ensure_lce(pgx_index *h, pgx_device_image *d) {
         d->img.lce_flags = d->lce_flags.as<uint32_t>();
         d->img.lce_max = 16;
         if (const char *e = std::getenv("PGX_FM_LCE_MAX")) d->img.lce_max = (uint32_t)std::min<unsigned long>(std::strtoul(e, nullptr, 10), 31ul);
+        d->img.refill_min = 6;
+        if (const char *e = std::getenv("PGX_FM_REFILL_MIN")) d->img.refill_min = (uint32_t)std::max<unsigned long>(1ul, std::min<unsigned long>(std::strtoul(e, nullptr, 10), 64ul));
         d->lce_state = 1;
     } catch (...) { // (no LCE image: the search runs on the PAIRS image alone, as before)
         (void)hipGetLastError();
