@@ -1271,7 +1271,7 @@ static void ensure_lce(pgx_index *h, pgx_device_image *d) {
         d->img.lce_flags = d->lce_flags.as<uint32_t>();
         d->img.lce_max = 16;
         if (const char *e = std::getenv("PGX_FM_LCE_MAX")) d->img.lce_max = (uint32_t)std::min<unsigned long>(std::strtoul(e, nullptr, 10), 31ul);
-        d->img.refill_min = 6;
+        d->img.refill_min = 12; // (chr22 scale, 1 / 3 / 6 / 10 / 16 / 24: main kernel 10.76 / 10.44 / 10.24 / 10.15 / 10.10 / 10.08 ms, step 13.16 / 12.87 / 12.62 / 12.59 / 12.56 / 12.65)
         if (const char *e = std::getenv("PGX_FM_REFILL_MIN")) d->img.refill_min = (uint32_t)std::max<unsigned long>(1ul, std::min<unsigned long>(std::strtoul(e, nullptr, 10), 64ul));
         d->lce_state = 1;
     } catch (...) { // (no LCE image: the search runs on the PAIRS image alone, as before)
