@@ -1144,7 +1144,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     uint32_t did2 = 0; // this lane's last trip performed two extensions (summed at the top of the next trip, where the wave is converged)
     // LCE: bit 0 = the lane compares with the text (ph == 2), bit 1 = this stage must not (a flagged text line), bits 8..15 occurrence index, 16..23 index of
     // the first occurrence with the longest match, 24..31 how many reach it; the longest match; the text position of the occurrence of the next trip
-    uint32_t lce_st = 0, lce_best = 0, lce_pos = 0, lce_pos2 = 0; // (two occurrences per trip: the text positions of occurrence i and i + 1)
+    uint32_t lce_st = 0, lce_best = 0, lce_pos = 0;
 #ifdef PGX_FM_STATS
     unsigned long long st_trips = 0, st_live = 0, st_wait = 0, st_fresh = 0; // diagnostics build only (scripts/fm_stats.sh)
     unsigned long long st_t_refill = 0, st_refills = 0, st_t_seed = 0, st_t_line = 0;
@@ -1287,41 +1287,23 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         // text, the flag words of the lines they lie in and the next occurrence's suffix array entry (the same registers: nothing added to the trip's pressure)
         uint4 row = make_uint4(0u, 0u, 0u, 0u), hs = row, d0 = row, d1 = row, d2 = row;
         const bool lce_lane = LCE && ph == 2 && (lce_st & 1u) != 0u;
-        uint32_t lce_g0 = 0u, lce_g1 = 0u;
-        uint4 ex = make_uint4(0u, 0u, 0u, 0u); // (LCE: the tenth / ninth words of the second window, the two flag words)
+        uint32_t lce_g0 = 0u;
         bool em_now = false; // this trip ends with a MEM (set by either kind of lane); `restart`: with the next start position of the read
         restart = 0u;
-        if (LCE && lce_lane) { // two occurrences per trip: ten words (40 bytes) of text each, one flag word each, the suffix array entries of the next two
-            typedef struct __attribute__((packed, aligned(4))) { uint32_t x, y, z, w; } u4_t; // (dword-aligned pieces)
-            typedef struct __attribute__((packed, aligned(4))) { uint32_t x, y; } u2_t;
-            const uint32_t i0 = (lce_st >> 8) & 0xFFu;
-            lce_g0 = lce_pos + (uint32_t)(j - x);            // text position that faces read symbol j, occurrence i
-            lce_g1 = lce_pos2 + (uint32_t)(j - x);           // ... occurrence i + 1 (the same position again where there is none: nothing new is fetched)
-            if (i0 + 1u >= (uint32_t)s) lce_g1 = lce_g0;
-            {
-                const uint32_t *tp = img.lce_text + (lce_g0 >> 4);
-                const u4_t a = *reinterpret_cast<const u4_t *>(tp), b = *reinterpret_cast<const u4_t *>(tp + 4);
-                const u2_t c = *reinterpret_cast<const u2_t *>(tp + 8);
-                row = make_uint4(a.x, a.y, a.z, a.w); hs = make_uint4(b.x, b.y, b.z, b.w); d0.x = c.x; d0.y = c.y;
-                ex.z = img.lce_flags[(lce_g0 >> 4) >> 10];
-            }
-            {
-                const uint32_t *tp = img.lce_text + (lce_g1 >> 4);
-                const u4_t a = *reinterpret_cast<const u4_t *>(tp), b = *reinterpret_cast<const u4_t *>(tp + 4);
-                const u2_t c = *reinterpret_cast<const u2_t *>(tp + 8);
-                d1 = make_uint4(a.x, a.y, a.z, a.w); d2 = make_uint4(b.x, b.y, b.z, b.w); ex.x = c.x; ex.y = c.y;
-                ex.w = img.lce_flags[(lce_g1 >> 4) >> 10];
-            }
-            const uint32_t i2 = i0 + 2u, i3 = i0 + 3u;
-            d0.z = img.lce_sa[(uint32_t)k + (i2 < (uint32_t)s ? i2 : 0u)];
-            d0.w = img.lce_sa[(uint32_t)k + (i3 < (uint32_t)s ? i3 : 0u)];
+        if (LCE && lce_lane) {
+            lce_g0 = lce_pos + (uint32_t)(j - x);           // text position that faces read symbol j
+            const uint32_t w0 = lce_g0 >> 4;                // its word (16 symbols); the window: words w0 .. w0 + 11
+            const uint32_t *tp = img.lce_text + w0;
+            typedef struct __attribute__((packed, aligned(4))) { uint32_t x, y, z, w; } u4_t; // (dword-aligned 16-byte pieces)
+            const u4_t a = *reinterpret_cast<const u4_t *>(tp), b = *reinterpret_cast<const u4_t *>(tp + 4), c = *reinterpret_cast<const u4_t *>(tp + 8);
+            row = make_uint4(a.x, a.y, a.z, a.w); hs = make_uint4(b.x, b.y, b.z, b.w); d0 = make_uint4(c.x, c.y, c.z, c.w);
+            const uint32_t l0 = w0 >> 5, l1 = (w0 + 11u) >> 5; // the lines of the window
+            d1.x = img.lce_flags[l0 >> 5] >> (l0 & 31u);
+            d1.y = img.lce_flags[l1 >> 5] >> (l1 & 31u);
+            const uint32_t i1 = ((lce_st >> 8) & 0xFFu) + 1u;
+            d1.z = img.lce_sa[(uint32_t)k + (i1 < (uint32_t)s ? i1 : 0u)];
         }
-        if (LCE) { // (the windows' lines: one each -- the lane's trip is counted above --, two where a window crosses a line border; wave-uniform sums)
-            const bool two_occ = lce_lane && lce_g1 != lce_g0;
-            const uint32_t wa = lce_g0 >> 4, wb = lce_g1 >> 4;
-            ln_blk += (unsigned long long)(__popcll(__ballot(lce_lane && (wa >> 5) != ((wa + 9u) >> 5))) + __popcll(__ballot(two_occ)) +
-                                           __popcll(__ballot(two_occ && (wb >> 5) != ((wb + 9u) >> 5))));
-        }
+        if (LCE) ln_blk += (unsigned long long)__popcll(__ballot(lce_lane && ((lce_g0 >> 4) >> 5) != (((lce_g0 >> 4) + 11u) >> 5))); // a window over two lines
         if (ph > 0 && !lce_lane) {
             const bool fr = fresh != 0u; // first extension of a backward stage: from first_ext / the seed table
             bool seed_lane = false;
@@ -1590,60 +1572,36 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                     lce_st = 1u;
                     lce_best = 0u;
                     lce_pos = img.lce_sa[(uint32_t)k];
-                    lce_pos2 = img.lce_sa[(uint32_t)k + ((uint32_t)s > 1u ? 1u : 0u)];
                 }
             }
         }
-        if (LCE && lce_lane) { // the text behind occurrences i and i + 1 of the interval against the read from symbol j on
-            // flag of the line(s) a ten-word window lies in (one word of 32 line flags per window: where the second line's flag sits in the next word the
-            // window counts as flagged -- one window in a hundred --: the stage then goes on stepwise)
-            auto flagged_window = [](uint32_t fw, uint32_t g) {
-                const uint32_t w = g >> 4, l0 = w >> 5, l1 = (w + 9u) >> 5, b = l0 & 31u;
-                return (((fw >> b) & 1u) | (l1 != l0 ? (b == 31u ? 1u : (fw >> (b + 1u)) & 1u) : 0u)) != 0u;
-            };
-            const uint32_t i = (lce_st >> 8) & 0xFFu;
-            const bool has2 = i + 1u < (uint32_t)s;
-            if (flagged_window(ex.z, lce_g0) || (has2 && flagged_window(ex.w, lce_g1))) lce_st = 2u; // an N / an endmarker / the end of the text in reach: this stage goes on stepwise (nothing has changed yet)
+        if (LCE && lce_lane) { // the text behind occurrence i of the interval against the read from symbol j on
+            const uint32_t T[12] = {row.x, row.y, row.z, row.w, hs.x, hs.y, hs.z, hs.w, d0.x, d0.y, d0.z, d0.w};
+            if ((d1.x | d1.y) & 1u) lce_st = 2u; // a line with an N / an endmarker / behind the text: this stage goes on stepwise (nothing has changed yet)
             else {
                 const uint32_t rem = (uint32_t)(len - j), q0 = (uint32_t)(base & 15ull) + (uint32_t)j;
-                const uint32_t rsh = 2u * (q0 & 15u), rw0 = q0 >> 4;
+                const uint32_t tsh = 2u * (lce_g0 & 15u), rsh = 2u * (q0 & 15u), rw0 = q0 >> 4;
                 uint32_t R[10];
 #pragma unroll
                 for (uint32_t u = 0; u < 10; u++) { const uint32_t wi = rw0 + u; R[u] = s_rd[(wi < pk_words ? wi : pk_words - 1u) * rd_stride + threadIdx.x]; }
+                uint32_t l = 144u;
 #pragma unroll
-                for (uint32_t u = 0; u < 9; u++) R[u] = __builtin_amdgcn_alignbit(R[u + 1], R[u], rsh); // the read from symbol j on, 16 symbols per word
-                auto match = [&](const uint32_t (&T)[10], uint32_t g) { // symbols of the read (from j) the text at g matches
-                    const uint32_t tsh = 2u * (g & 15u);
-                    uint32_t l = 144u;
-#pragma unroll
-                    for (int u = 8; u >= 0; u--) { // (from the last unit down: the first differing one wins)
-                        const uint32_t df = R[u] ^ __builtin_amdgcn_alignbit(T[u + 1], T[u], tsh);
-                        l = df ? 16u * (uint32_t)u + ((uint32_t)__builtin_ctz(df) >> 1) : l;
-                    }
-                    return l < rem ? l : rem;
-                };
-                const uint32_t TA[10] = {row.x, row.y, row.z, row.w, hs.x, hs.y, hs.z, hs.w, d0.x, d0.y};
-                const uint32_t TB[10] = {d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, d2.z, d2.w, ex.x, ex.y};
-                const uint32_t la = match(TA, lce_g0), lb = match(TB, lce_g1);
-                uint32_t a = (lce_st >> 16) & 0xFFu, cnt = lce_st >> 24, best = lce_best;
-                {
-                    const bool better = i == 0u || la > best;
-                    cnt = better ? 1u : (la == best ? cnt + 1u : cnt);
-                    a = better ? i : a;
-                    best = better ? la : best;
+                for (int u = 8; u >= 0; u--) { // (from the last unit down: the first differing one wins)
+                    const uint32_t df = __builtin_amdgcn_alignbit(R[u + 1], R[u], rsh) ^ __builtin_amdgcn_alignbit(T[u + 1], T[u], tsh);
+                    l = df ? 16u * (uint32_t)u + ((uint32_t)__builtin_ctz(df) >> 1) : l;
                 }
-                if (has2) {
-                    const bool better = lb > best;
-                    cnt = better ? 1u : (lb == best ? cnt + 1u : cnt);
-                    a = better ? i + 1u : a;
-                    best = better ? lb : best;
-                }
-                lce_best = best;
-                if (i + 2u < (uint32_t)s) { lce_st = 1u | ((i + 2u) << 8) | (a << 16) | (cnt << 24); lce_pos = d0.z; lce_pos2 = d0.w; }
+                l = l < rem ? l : rem;
+                const uint32_t i = (lce_st >> 8) & 0xFFu;
+                uint32_t a = (lce_st >> 16) & 0xFFu, cnt = lce_st >> 24;
+                const bool better = i == 0u || l > lce_best;
+                cnt = better ? 1u : (l == lce_best ? cnt + 1u : cnt);
+                a = better ? i : a;
+                lce_best = better ? l : lce_best;
+                if (i + 1u < (uint32_t)s) { lce_st = 1u | ((i + 1u) << 8) | (a << 16) | (cnt << 24); lce_pos = d1.z; }
                 else { // every occurrence seen: the MEM ends where the longest match ends; the occurrences that reach it are its interval
                     Jk = k + (pos_t)a; Js = (pos_t)cnt;
-                    next += best + (best < rem ? 1u : 0u); // (the extension that fails counts, as in the stepwise stage)
-                    j += (int32_t)best;
+                    next += lce_best + (lce_best < rem ? 1u : 0u); // (the extension that fails counts, as in the stepwise stage)
+                    j += (int32_t)lce_best;
                     lce_st = 0u;
                     em_now = true;
                 }
