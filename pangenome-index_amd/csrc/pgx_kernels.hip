@@ -1087,7 +1087,10 @@ __device__ __forceinline__ uint32_t pgx_window_byte(uint64_t w0, uint64_t w1, ui
 // 8 haplotypes costs 9 trips and ~11 lines this way instead of ~33 and 33.  min_occ <= 1 only (the longest match decides); a window that touches a line
 // with an N or an endmarker sends the lane back to the stepwise path for that stage.  Results are bit-identical (tests run both ways).
 template <bool SEED, bool WIDE, bool PACKED, bool COOP, bool S64, bool LCE>
-__global__ void __launch_bounds__(PGX_FM_THREADS, (PACKED && !WIDE && !COOP && !LCE) ? PGX_PAIRS_PACKED_WAVES : PGX_FM_WAVES_PER_SIMD) // (<= 96 VGPRs: five waves per SIMD fit and are what the launch uses; four are as fast -- 20.7 against 20.6-21.0 ms at chr22 scale --, three 21.8)
+#ifndef PGX_LCE_WAVES
+#define PGX_LCE_WAVES PGX_FM_WAVES_PER_SIMD // (the text path holds its three pieces of text across the trip's body: 110 VGPRs; bounded to 96 it spills 56 bytes per lane: scripts/r4_exp7.sh)
+#endif
+__global__ void __launch_bounds__(PGX_FM_THREADS, LCE ? PGX_LCE_WAVES : ((PACKED && !WIDE && !COOP) ? PGX_PAIRS_PACKED_WAVES : PGX_FM_WAVES_PER_SIMD)) // (<= 96 VGPRs: five waves per SIMD fit and are what the launch uses; four are as fast -- 20.7 against 20.6-21.0 ms at chr22 scale --, three 21.8)
 pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                            uint64_t n_reads, uint64_t min_len, uint64_t min_occ, const uint64_t *__restrict__ slot_off,
                            pgx_mem *__restrict__ slots, uint32_t *__restrict__ mem_count, unsigned long long *__restrict__ n_ext_total,
