@@ -1306,7 +1306,8 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             const uint32_t i1 = ((lce_st >> 8) & 0xFFu) + 1u;
             d1.z = img.lce_sa[(uint32_t)k + (i1 < (uint32_t)s ? i1 : 0u)];
         }
-        if (LCE) ln_blk += (unsigned long long)__popcll(__ballot(lce_lane && ((lce_g0 >> 4) >> 5) != (((lce_g0 >> 4) + 11u) >> 5))); // a window over two lines
+        if (LCE) ln_blk += (unsigned long long)(__popcll(__ballot(lce_lane && ((lce_g0 >> 4) >> 5) != (((lce_g0 >> 4) + 11u) >> 5))) +  // a window over two lines
+                                                __popcll(__ballot(lce_lane && ((lce_st >> 8) & 0xFFu) == 0u)));                     // the line of the interval's suffix array entries
         if (ph > 0 && !lce_lane) {
             const bool fr = fresh != 0u; // first extension of a backward stage: from first_ext / the seed table
             bool seed_lane = false;
@@ -1322,7 +1323,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                         if (PACKED) { // the window's 2 K bits of the packed read are the index
                             const uint32_t q = (uint32_t)(base & 15ull) + (uint32_t)((endw ? len - 1 : j) - K + 1);
                             const uint32_t w0 = s_rd[(q >> 4) * rd_stride + threadIdx.x], w1 = s_rd[((q >> 4) + 1u) * rd_stride + threadIdx.x]; // (one word of padding per thread)
-                            const uint32_t sidx = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (2u * (q & 15u))) & ((1u << (2 * K)) - 1u);
+                            const uint32_t sidx = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (2u * (q & 15u))) & (uint32_t)((1ull << (2 * K)) - 1ull); // (K = 16: all 32 bits)
                             seed_lane = true; sp = (endw ? img.seed_end : img.seed) + sidx; kuse = (uint32_t)K + (endw ? 1u : 0u);
                         } else {
                         const uint64_t a = base + (uint64_t)((endw ? len - 1 : j) - K + 1);
