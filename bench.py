@@ -449,6 +449,8 @@ def roofline_record(info, cat_len, n_reads, counts, k_ms, timing, workload_key, 
         # of the HBM roofline it needs; otherwise the bound is random 128-byte line fetches from HBM (or the memory-side cache)
         "bound": "lds/valu" if in_lds else "hbm",
         "kernel": "pgx_find_mems_pairs_kernel" if pairs else "pgx_find_mems_kernel",
+        "kernel_variant": {0: "one extension per trip", 1: "two-step, byte windows", 2: "two-step, packed reads", 3: "two-step, packed reads, cooperative line fetches",
+                           4: "two-step, packed reads, narrow forward stages through the suffix array and the text (LCE)"}.get(int(timing.pairs_reads), "?"),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "frac_note": ("bytes moved per launch (kernel-counted image lines and seed entries x 128 B + streamed reads, offsets, MEM slots) / kernel time / HBM peak"
                       + ("; the rank image is staged in LDS, so the kernel is bound by LDS / issue slots, not by HBM" if in_lds else "")),
