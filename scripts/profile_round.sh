@@ -9,9 +9,9 @@ export TMPDIR=/tmp
 R=$PWD/gpurun_out/prof_$tag; mkdir -p $R
 for wl in $WLS; do
   steps=10; [ $wl = chr22 ] && steps=5
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/${wl}_stats -- python3 bench.py --workload $wl --steps $steps --warmup 2 --no-cpu-baseline --no-secondary --no-parity --workdir /tmp/wd > $R/${wl}_bench_under_rocprof.json 2> $R/${wl}_stats.err || echo FAIL stats $wl
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/${wl}_stats -- python3 bench.py --workload $wl --steps $steps --warmup 2 --no-cpu-baseline --no-secondary --no-parity --no-fresh --workdir /tmp/wd > $R/${wl}_bench_under_rocprof.json 2> $R/${wl}_stats.err || echo FAIL stats $wl
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/${wl}_$C -- python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-parity --workdir /tmp/wd > $R/${wl}_$C.json 2> $R/${wl}_$C.err || echo FAIL $C $wl
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/${wl}_$C -- python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-parity --no-fresh --workdir /tmp/wd > $R/${wl}_$C.json 2> $R/${wl}_$C.err || echo FAIL $C $wl
   done
 done
 python3 - $R $WLS <<'PY'
@@ -38,7 +38,7 @@ for wl in wls:
     # this kernel moves a whole 128-byte line (MI355X_MICROARCH.md "HBM": FETCH_SIZE tallies 128-B requests at 64 B; confirmed
     # for THIS access pattern by profiles/r01_ubench_random_gather.txt: random 64-B and 128-B records are served at the same
     # record rate), so the read side is doubled.  WRITE_SIZE is exact.
-    rec = {"workload": wl, "recorded": "round 3 (" + sys.argv[1].rsplit("prof_", 1)[-1] + ")", "kernel": fm, "bwt_size": cfg["bwt_size"], "reads": cfg["reads_per_gpu"], "min_len": cfg["min_len"], "tags": cfg["tags"],
+    rec = {"workload": wl, "recorded": "round 4 (" + sys.argv[1].rsplit("prof_", 1)[-1] + ")", "kernel": fm, "bwt_size": cfg["bwt_size"], "reads": cfg["reads_per_gpu"], "min_len": cfg["min_len"], "tags": cfg["tags"],
            "image_kind": cfg["image_kind"], "image_pairs": cfg.get("image_pairs", 0), "pairs_stride": cfg.get("pairs_stride", 0),
            "rank_image": cfg["rank_image"],
            "FETCH_SIZE_KB_per_launch": out["FETCH_SIZE"][fm], "WRITE_SIZE_KB_per_launch": out["WRITE_SIZE"].get(fm, 0.0),  # per step of 1 batch
