@@ -1,0 +1,62 @@
+"""The formulation behind pgx_find_mems_pairs_kernel<.., LCE> (pgx_image.h "LCE image"), CPU tier, oracle only: on a collection that holds every sequence
+next to its reverse complement, the FORWARD stage of find_mems_function (algorithm.hpp:676-700: forward_extend until the interval is "small") ends where the
+longest match of the read with the text behind any occurrence of the stage's first interval ends, and the interval it ends with is the (consecutive) run of
+occurrences that reach that far: MEM end = j + max LCE, bwt_start = k + first such occurrence, size = their number.  Checked against the oracle's
+find_mems_function on reads with substitutions, short reads, reads over N runs and sequence ends, for min_occ 1 (the only case the kernel takes this way).
+Also: the text can be recovered from the index alone -- the first symbol of suffix i is the symbol whose C-bucket holds i (what pgx_lce_scatter_kernel does)."""
+import os
+
+import numpy as np
+
+import oracle_ffi as O
+import pgx_workload as W
+
+
+def test_forward_stage_equals_longest_match_over_the_occurrences(workdir):
+    text = os.path.join(workdir, "lce_math.txt")
+    W.synth_pangenome_text(text, base_len=30_000, n_hap=5, seed=3, n_runs=3, n_run_len=(30, 300))
+    ri_path = W.build_index_from_text(text, workdir, "lce_math", with_tags=False)[0]
+    ri = O.RIndex(ri_path)
+    seqs = W.load_sequences(text)
+    ml = ri.max_length
+    sa = ri.decompress_sa()
+    seq_start = np.concatenate([[0], np.cumsum([len(s) + 1 for s in seqs])])
+    T = np.concatenate([np.concatenate([s, [10]]) for s in seqs]).astype(np.uint8)
+    assert len(T) == ri.n
+    gpos = seq_start[(sa // ml).astype(np.int64)] + (sa % ml).astype(np.int64)  # the suffix array in text coordinates
+    # first column: suffix i starts with the symbol whose bucket holds i (nuc order \n A C G N T)
+    nuc = [10, 65, 67, 71, 78, 84]
+    cum = np.concatenate([[0], np.cumsum([int((T == c).sum()) for c in nuc])])
+    for b, c in enumerate(nuc):
+        assert (T[gpos[cum[b]:cum[b + 1]]] == c).all()
+    cat, offs = W.sample_reads(seqs, 1500, 150, seed=8, n_frac=0.05)
+    rng = np.random.default_rng(1)
+    checked = 0
+    for r in range(1500):
+        rd = bytes(cat[offs[r]:offs[r + 1]])
+        if r % 5 == 0:
+            rd = rd[: int(rng.integers(25, 150))]
+        if r % 11 == 0:
+            rd = bytes(seqs[r % len(seqs)][-len(rd):])  # a read that ends its sequence
+        for min_len in (20, 12):
+            for x in (0, int(rng.integers(0, max(1, len(rd) - min_len)))):
+                nx, mem, _ = ri.find_mems_function(rd, min_len, 1, x)
+                if mem is None or any(ch not in b"ACGT" for ch in rd[x:]):  # (reads with other bytes never reach the two-step kernel)
+                    continue
+                k, _, s = ri.bwd_pattern(rd[x:x + min_len])
+                assert s > 0
+                j = x + min_len
+                rem = len(rd) - j
+                best, first, cnt = -1, 0, 0
+                for i in range(s):
+                    p = int(gpos[k + i]) + min_len
+                    l = 0
+                    while l < rem and T[p + l] == rd[j + l]:
+                        l += 1
+                    if l > best:
+                        best, first, cnt = l, i, 1
+                    elif l == best:
+                        cnt += 1
+                assert (x, j + best, k + first, cnt) == tuple(mem), (rd, x, min_len)
+                checked += 1
+    assert checked > 3000
