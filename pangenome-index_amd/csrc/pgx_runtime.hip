@@ -122,12 +122,15 @@ static void build_seed_table(pgx_device_image *d) {
     PgxDevImage &g = d->img;
     // depth: one more than the first at which a random window is expected in the index less than once (4^K >= n), at most 15 (16 GiB): a seed that dies
     // inside the table ends a stage without another trip (n = 640 M: K = 14 / 15 / 16: 20.8 / 19.4-20.5 / 20.1 ms; n = 64 M: K = 12 / 13 / 14: 2.47 / 2.43 / 2.37 ms)
+    // Round 4: at most 16 (64 GiB) and three tenths of the device's memory -- with the forward stages through the text a read is ~28 lane trips and the
+    // two-step trips behind the seed are a third of them: depth 16 leaves 4 symbols = 2 trips of a 20-symbol step 1 instead of 5 = 3
+    // (n = 640 M, K = 15 / 16: main kernel 10.26 / 9.44 ms, 791 / 830 M reads/s, 3.6 s more to build)
     int K = 0;
-    while (K < 15 && (K == 0 || (1ull << (2 * (K - 1))) < g.n)) K++;
+    while (K < 16 && (K == 0 || (1ull << (2 * (K - 1))) < g.n)) K++;
     {
         size_t mem_free = 0, mem_total = 0;
         if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = mem_total = (size_t)16 << 30; }
-        while (K > 2 && (((size_t)1 << (2 * K)) * sizeof(uint4)) * 5 / 4 > std::min(mem_total / 8, mem_free / 2)) K--; // table + the level below it while building
+        while (K > 2 && (((size_t)1 << (2 * K)) * sizeof(uint4)) * 5 / 4 > std::min(mem_total * 3 / 10, mem_free / 2)) K--; // table + the level below it while building
     }
     // an image small enough for LDS leaves the loop bound by instruction issue, and every extension a seed replaces is a gain: depth 10
     // (16 MiB of table, hot in L2) whatever n is (x index, 1 M reads, min_len 10, K = 0 / 4 / 6 / 8 / 10: 1.22 / 1.03 / 0.81 / 0.72 / 0.59 ms)

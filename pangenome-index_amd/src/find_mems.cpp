@@ -148,7 +148,7 @@ int main(int argc, char **argv) {
     const size_t min_occ = (size_t)std::stoi(argv[5]);
     std::vector<int> devices(1, 0);
     uint32_t mode = PGX_MODE_COMPAT, tfmt = PGX_TAGS_AUTO;
-    size_t batch_reads = 1u << 20; // (reads per batch: the fresh-batch rate by batch size, profiles/r04_batch_size_sweep.txt: 177 M reads/s at 2^18, 278 M at 2^20, no more beyond)
+    size_t batch_reads = 1u << 18; // (reads per batch.  The device alone would like 2^20 -- fresh batches 177 M reads/s at 2^18, 278 M at 2^20, profiles/r04_batch_size_sweep.txt --, but this program is bound by its own host stages: 16 M reads take 0.5-0.7 s with 2^18 and 2.7-2.9 s with 2^20, pinned buffers of 150 MB per job and the formatting of the first and last batch: profiles/r04_cli_e2e.txt)
     unsigned streams = 3;
     bool quiet = false;
     int first_opt = 6;

@@ -44,7 +44,7 @@ def test_synth_pangenome_one_million_reads(workdir):
 
 def test_chr22_scale_automatic_layout(workdir):
     """BASELINE configs[2] at its own size (the bench default; reference unit: src/find_mems.cpp:94-139): n = 640 M, automatic layout
-    (dense2 + two-step pairs image, seed table of depth 15 = 16 GiB + the depth-10 table + end table), 1 M reads bit-identical to the
+    (dense2 + two-step pairs image, seed table of depth 16 = 64 GiB + the depth-10 table + end table), 1 M reads bit-identical to the
     oracle; then the bench batch shape -- 10 M reads in ONE chunk -- whose first 1 M reads are those reads: same results inside the bigger batch."""
     text = os.path.join(workdir, "chr22_synth.txt")
     W.synth_pangenome_text(text, base_len=40_000_000, n_hap=8, seed=45)  # bench.py's chr22 workload
@@ -66,7 +66,7 @@ def test_chr22_scale_automatic_layout(workdir):
     b1.run(20, 1, P.RUN_TAGS | P.RUN_TIMING)
     t = b1.timing()
     assert t.pairs_reads == 4 and t.main_lines > 0 and t.main_seed_loads > 0  # the two-step kernel behind the seed table ran, reads packed in LDS, narrow forward stages through the text
-    assert t.seed_depth == 15 and t.find_mems_launches == 1
+    assert t.seed_depth == 16 and t.find_mems_launches == 1
     res = b1.result()
     b1.free()
 
@@ -84,7 +84,7 @@ def test_chr22_scale_automatic_layout(workdir):
     del res
     b10 = idx.batch(cat, offs)
     b10.run(20, 1, P.RUN_TAGS | P.RUN_TIMING)
-    assert b10.timing().find_mems_launches == 1 and b10.timing().seed_depth == 15  # one chunk, as bench.py measures it
+    assert b10.timing().find_mems_launches == 1 and b10.timing().seed_depth == 16  # one chunk, as bench.py measures it
     res10 = b10.result()
     b10.free()
     same(res10, m, npos)
@@ -148,7 +148,7 @@ def _whole_genome_case(workdir, name, chroms, base_len, haps, n_reads, n1, full)
     t = b1.timing()
     assert t.find_mems_launches == 1 and t.main_lines > 0 and t.seed_depth > 0
     if full:
-        assert t.pairs_reads == 3 and t.seed_depth == 15  # cooperative line fetches + packed reads, seed table of depth 15 (40-bit fields)
+        assert t.pairs_reads == 3 and t.seed_depth == 16  # cooperative line fetches + packed reads, seed table of depth 16 (64 GiB, 40-bit fields)
     else:
         assert t.pairs_reads == 2
     res = b1.result()
@@ -192,7 +192,7 @@ def test_whole_genome_scale_wide_layout(workdir):
     """BASELINE configs[4]'s single-GPU ingredient at its own size (the reference is size_t end to end: include/pangenome_index/r-index.hpp:118-130,
     src/r-index.cpp:713-756): one merged index of n = 4 351 996 034 > 2^32 symbols (bench.py --workload wg: 8 chromosomes x 8.5 Mbp x 32 haplotypes
     x 2 strands, 512 sequences) built by pgx_build_index_from_texts; the automatic layout must be the 64-bit one (WIDE dense2 + WIDE PAIRS at
-    stride 64 behind cooperative line fetches, seed table of depth 15 with 40-bit fields).  100 k sampled reads plus reads that end / start a
+    stride 64 behind cooperative line fetches, seed table of depth 16 with 40-bit fields).  100 k sampled reads plus reads that end / start a
     sequence, an all-N read, lower case, and reads whose BWT intervals lie across the superblock borders of both images (their 64-bit bases
     change there) bit-identical to the oracle incl. tags and n_extensions; then the bench batch shape -- 10 M reads in one chunk -- whose first
     100 k reads give the same bytes."""
