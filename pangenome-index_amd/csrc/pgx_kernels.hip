@@ -1114,6 +1114,10 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     uint4 *s_stage = reinterpret_cast<uint4 *>(pgx_dyn_lds + (size_t)pk_words * PGX_FM_THREADS * 4) + (size_t)(threadIdx.x >> 6) * 512;
     // WIDE: behind those, per superblock the sixteen pair-count bases and their four row sums (24 words each, img.n_sbp superblocks)
     uint64_t *s_pb = reinterpret_cast<uint64_t *>(pgx_dyn_lds + (size_t)pk_words * PGX_FM_THREADS * 4 + (COOP ? (size_t)(PGX_FM_THREADS / 64) * 8192 : 0));
+    // LCE (never with COOP / WIDE): behind the packed reads, the suffix array entries of a lane's interval: entry t at s_sa[t * blockDim.x + threadIdx.x]
+    // (PGX_LCE_MAX_OCC entries per thread).  Fetched ONCE when the lane enters the text path, straight into LDS (global_load_lds): re-read from memory every
+    // trip the line of those entries did not stay in L2 between two trips of the lane -- a fifth of the kernel's memory-side traffic by the counters
+    uint32_t *s_sa = reinterpret_cast<uint32_t *>(pgx_dyn_lds + (size_t)pk_words * PGX_FM_THREADS * 4);
     for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) s_ext[i] = img.consts->ext_tab[i];
     if (threadIdx.x < 8) s_C[threadIdx.x] = (pos_t)img.consts->C[threadIdx.x];
     if (threadIdx.x < 32) s_t2[threadIdx.x] = (pos_t)img.consts->pair_t2w[threadIdx.x];
@@ -1293,7 +1297,9 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         uint32_t lce_g0 = 0u;
         bool em_now = false; // this trip ends with a MEM (set by either kind of lane); `restart`: with the next start position of the read
         restart = 0u;
+        if (LCE && __any(lce_lane && ((lce_st >> 8) & 0xFFu) == 0u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the entries asked for at the end of the last trip are in LDS)
         if (LCE && lce_lane) {
+            lce_pos = s_sa[((lce_st >> 8) & 0xFFu) * rd_stride + threadIdx.x];
             lce_g0 = lce_pos + (uint32_t)(j - x);           // text position that faces read symbol j
             const uint32_t w0 = lce_g0 >> 4;                // its word (16 symbols); the window: words w0 .. w0 + 11
             const uint32_t *tp = img.lce_text + w0;
@@ -1303,8 +1309,6 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             const uint32_t l0 = w0 >> 5, l1 = (w0 + 11u) >> 5; // the lines of the window
             d1.x = img.lce_flags[l0 >> 5] >> (l0 & 31u);
             d1.y = img.lce_flags[l1 >> 5] >> (l1 & 31u);
-            const uint32_t i1 = ((lce_st >> 8) & 0xFFu) + 1u;
-            d1.z = img.lce_sa[(uint32_t)k + (i1 < (uint32_t)s ? i1 : 0u)];
         }
         if (LCE) ln_blk += (unsigned long long)(__popcll(__ballot(lce_lane && ((lce_g0 >> 4) >> 5) != (((lce_g0 >> 4) + 11u) >> 5))) +  // a window over two lines
                                                 __popcll(__ballot(lce_lane && ((lce_st >> 8) & 0xFFu) == 0u)));                     // the line of the interval's suffix array entries
@@ -1575,7 +1579,13 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                     (uint32_t)(len - j) >= 2u * (uint32_t)s && (uint32_t)(len - j) <= 144u) {
                     lce_st = 1u;
                     lce_best = 0u;
-                    lce_pos = img.lce_sa[(uint32_t)k];
+                    // SA[k .. k + s) into this thread's LDS column, no registers in between: instruction t of the wave writes the dword of lane l to
+                    // s_sa[t * blockDim.x + (wave's first thread) + l]
+#pragma unroll
+                    for (uint32_t t = 0; t < PGX_LCE_MAX_OCC; t++)
+                        if (t < (uint32_t)s)
+                            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(img.lce_sa + (uint32_t)k + t),
+                                                             (void __attribute__((address_space(3))) *)(s_sa + t * rd_stride + (threadIdx.x & ~63u)), 4, 0, 0);
                 }
             }
         }
@@ -1601,7 +1611,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 cnt = better ? 1u : (l == lce_best ? cnt + 1u : cnt);
                 a = better ? i : a;
                 lce_best = better ? l : lce_best;
-                if (i + 1u < (uint32_t)s) { lce_st = 1u | ((i + 1u) << 8) | (a << 16) | (cnt << 24); lce_pos = d1.z; }
+                if (i + 1u < (uint32_t)s) lce_st = 1u | ((i + 1u) << 8) | (a << 16) | (cnt << 24);
                 else { // every occurrence seen: the MEM ends where the longest match ends; the occurrences that reach it are its interval
                     Jk = k + (pos_t)a; Js = (pos_t)cnt;
                     next += lce_best + (lce_best < rem ? 1u : 0u); // (the extension that fails counts, as in the stepwise stage)

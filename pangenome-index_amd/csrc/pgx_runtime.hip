@@ -1273,7 +1273,7 @@ static void ensure_lce(pgx_index *h, pgx_device_image *d) {
         d->img.lce_text = d->lce_text.as<uint32_t>();
         d->img.lce_flags = d->lce_flags.as<uint32_t>();
         d->img.lce_max = 16;
-        if (const char *e = std::getenv("PGX_FM_LCE_MAX")) d->img.lce_max = (uint32_t)std::min<unsigned long>(std::strtoul(e, nullptr, 10), 31ul);
+        if (const char *e = std::getenv("PGX_FM_LCE_MAX")) d->img.lce_max = (uint32_t)std::min<unsigned long>(std::strtoul(e, nullptr, 10), (unsigned long)PGX_LCE_MAX_OCC);
         d->img.refill_min = 12; // (chr22 scale, 1 / 3 / 6 / 10 / 16 / 24: main kernel 10.76 / 10.44 / 10.24 / 10.15 / 10.10 / 10.08 ms, step 13.16 / 12.87 / 12.62 / 12.59 / 12.56 / 12.65)
         if (const char *e = std::getenv("PGX_FM_REFILL_MIN")) d->img.refill_min = (uint32_t)std::max<unsigned long>(1ul, std::min<unsigned long>(std::strtoul(e, nullptr, 10), 64ul));
         d->lce_state = 1;
@@ -1600,6 +1600,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                         // cooperative line fetches (one address translation per line instead of five) for PAIRS images beyond the reach of the
                         // translation caches, ~3 GB (profiles/r03_ubench_gather_loads_per_line.txt); PGX_FM_COOP=0 / 1 overrides
                         const bool s64 = img.pairs_stride == PGX_PAIRS_STRIDE64;
+                        size_t lce_lds = 0;
                         bool coop = b->h->img.pairs.size() > (3ull << 30);
                         if (const char *ce = std::getenv("PGX_FM_COOP")) coop = ce[0] == '1';
 #define PGX_PK(W, C) (s64 ? (const void *)pgx_find_mems_pairs_kernel<true, W, true, C, true, false> : (const void *)pgx_find_mems_pairs_kernel<true, W, true, C, false, false>)
@@ -1610,10 +1611,11 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                         if (img.lce_sa && !coop && !img.wide && min_occ <= 1 && !(le && le[0] == '0')) {
                             kp = s64 ? (const void *)pgx_find_mems_pairs_kernel<true, false, true, false, true, true> : (const void *)pgx_find_mems_pairs_kernel<true, false, true, false, false, true>;
                             b->timing.pairs_reads = 4u;
+                            lce_lds = (size_t)PGX_LCE_MAX_OCC * PGX_FM_THREADS * 4; // the suffix array entries of every thread's interval
                         }
                         a_packed = b->packed.as<uint32_t>();
                         a_pkw = pkw;
-                        plds = (size_t)pkw * PGX_FM_THREADS * 4 + (coop ? (size_t)(PGX_FM_THREADS / 64) * 8192 : 0) + (img.wide ? (size_t)img.n_sbp * 192 : 0);
+                        plds = (size_t)pkw * PGX_FM_THREADS * 4 + (coop ? (size_t)(PGX_FM_THREADS / 64) * 8192 : 0) + (img.wide ? (size_t)img.n_sbp * 192 : 0) + lce_lds;
                         if (b->timing.pairs_reads != 4u) b->timing.pairs_reads = coop ? 3u : 2u;
                         int occ_p = 0;
                         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_p, kp, PGX_FM_THREADS, plds));
