@@ -263,7 +263,11 @@ int main(int argc, char **argv) {
 
     // a range -> the reads it holds, concatenated, with offsets; empty lines are skipped (:97); a last line without a newline counts (std::getline)
     ReadBufPool pool;
-    const bool use_packed = !(std::getenv("PGX_CLI_PACKED") && std::getenv("PGX_CLI_PACKED")[0] == '0');
+    // PGX_CLI_PACKED=1: the parse threads also pack the reads to two bits per symbol (pgx_pack_reads) and the batch travels packed (pgx_batch_upload_packed).
+    // Off by default: this program is bound by its host stages, not by the link -- 16 M reads, three device workers, same box: pipeline 0.65 s with byte
+    // uploads, 0.88 s with packed ones (the extra pass over the bytes in the parse threads: profiles/r04_cli_e2e.txt).  A caller whose batches are already
+    // packed, or whose pipeline is bound by the device, gains: bench.py fresh_batch 366 against 220 M reads/s.
+    const bool use_packed = std::getenv("PGX_CLI_PACKED") && std::getenv("PGX_CLI_PACKED")[0] == '1';
     auto parse_range = [&](uint64_t id) {
         std::unique_ptr<Job> j(new Job());
         const char *q = mf.p + ranges[id].first, *end = mf.p + ranges[id].second;
