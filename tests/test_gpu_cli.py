@@ -19,8 +19,8 @@ DEMO = os.path.join(ROOT, "pangenome-index_amd", "compat_demo")
 BT = os.path.join(O.GOLDEN, "bidirectional_test")
 
 
-def _run(exe, *args):
-    return subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+def _run(exe, *args, env=None):
+    return subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
 
 
 @pytest.mark.parametrize("reads_file,ml,mo", [("reads.txt", 5, 1), ("reads.txt", 3, 1), ("test_reads.txt", 3, 1)])
@@ -53,6 +53,11 @@ def test_cli_many_reads_small_batches(built, x_index, workdir):
                   ["--devices", "0,0", "--streams", "2", "--batch", "300"], ["--gpus", "1", "--streams", "1", "--batch", "5000"],
                   ["--devices", "0,0,0", "--streams", "1", "--batch", "64", "--quiet"]):
         r = _run(CLI, ri, tags, path, 10, 1, *extra)
+        assert r.returncode == 0, r.stderr
+        assert strip_timing(r.stdout) == exp
+    # PGX_CLI_PACKED=1: the parse threads pack the reads (pgx_pack_reads) and the batches travel packed (pgx_batch_upload_packed): the same text
+    for extra in (["--batch", "777", "--quiet"], ["--devices", "0,0", "--streams", "2", "--batch", "300"]):
+        r = _run(CLI, ri, tags, path, 10, 1, *extra, env={"PGX_CLI_PACKED": "1"})
         assert r.returncode == 0, r.stderr
         assert strip_timing(r.stdout) == exp
 
