@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, final measurements: the driver's bench command, seed depth 16, rocprofv3 kernel stats + PMC traffic, the n = 4.35e9 workload, the CLI end to end
+# round 4, final measurements: the driver's bench command, rocprofv3 kernel stats + PMC traffic, the n = 4.35e9 workload
 set -e
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -12,18 +12,7 @@ print("default: %.1f M reads/s, step %.2f ms, main %.2f, frac %.3f, lines %.1f M
       % (d["value"]/1e6, d["ms_per_step"], k["find_mems_main"], r["frac"], r["probes_issued"]/1e6, r["seed_loads"]/1e6, r.get("traffic_over_model"), d["parity_sample"]["identical"], f["packed"]["value"]/1e6, f["packed"]["ms_per_step"],
          f["packed"]["per_upload_ms"], f["bytes"]["value"]/1e6, d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], d["secondary"]["value"]/1e6))
 PY
-W=/tmp/wd; mkdir -p $W
-PGX_SEED_K=16 python bench.py --workdir $W --no-cpu-baseline --no-secondary --no-fresh --parity-reads 30000 --steps 10 > gpurun_out/r4_final_k16.json 2> gpurun_out/r4_final_k16.err || echo K16 FAILED
-python - <<'PY'
-import json
-try:
-    d=json.loads(open("gpurun_out/r4_final_k16.json").read().strip().splitlines()[-1])
-    print("seed depth 16: %.1f M reads/s, step %.2f ms, main %.2f, parity %s, prep %.1f s" % (d["value"]/1e6, d["ms_per_step"], d["kernel_ms_per_step"]["find_mems_main"], d["parity_sample"]["identical"], d["config"]["prep_s"]))
-except Exception as e: print("k16:", e)
-PY
 bash scripts/profile_round.sh r04 chr22 x 2>&1 | tail -16
-python scripts/cli_e2e.py synth 16000000 > gpurun_out/r4_cli_e2e.txt 2>&1 || echo CLI FAILED
-tail -6 gpurun_out/r4_cli_e2e.txt
 python bench.py --workload wg > gpurun_out/r4_final_wg.json 2> gpurun_out/r4_final_wg.err || { tail -5 gpurun_out/r4_final_wg.err; echo WG FAILED; }
 python - <<'PY'
 import json
