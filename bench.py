@@ -442,7 +442,10 @@ def roofline_record(info, cat_len, n_reads, counts, k_ms, timing, workload_key, 
     pairs = bool(getattr(info, "image_pairs", 0)) and bool(timing.pairs_reads)
     lines, seeds = int(timing.main_lines), int(timing.main_seed_loads)
     all_lines = lines + int(timing.other_lines)
-    moved = 128.0 * (lines + seeds) + float(cat_len) + 8.0 * (n_reads + 1) + 32.0 * n_mems + 4.0 * n_reads
+    # (a seed entry is 16 bytes of a random line: a 128-byte line from HBM where the table is gigabytes; the 16 MiB table of an LDS-staged image stays in
+    #  the caches and the fabric moves 64-byte sectors for it -- PMC record of the x workload: 55 B per entry)
+    seed_bytes = 64.0 if in_lds else 128.0
+    moved = 128.0 * lines + seed_bytes * seeds + float(cat_len) + 8.0 * (n_reads + 1) + 32.0 * n_mems + 4.0 * n_reads
     achieved = moved / (main_ms * 1e-3) / 1e9 if main_ms > 0 else 0.0
     rec = {
         # with the rank image staged in LDS nothing of it comes from HBM: issue slots / LDS bound the kernel and frac only says how little
@@ -484,7 +487,7 @@ def roofline_record(info, cat_len, n_reads, counts, k_ms, timing, workload_key, 
                 rec["traffic_source"] = ("profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, recorded %s; all find_mems launches of a step)"
                                          % (workload_key, t.get("recorded", "in round 2")))
                 if rec["traffic"]:
-                    total_model = moved + 128.0 * (int(timing.other_lines) + int(timing.other_seed_loads))
+                    total_model = moved + 128.0 * int(timing.other_lines) + seed_bytes * int(timing.other_seed_loads)
                     rec["traffic_over_model"] = rec["traffic"] / total_model
         except Exception:
             pass
