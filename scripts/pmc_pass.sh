@@ -6,7 +6,7 @@ tag=$1; wl=$2; shift 2
 export TMPDIR=/tmp
 R=$PWD/gpurun_out/pmc_$tag; mkdir -p $R
 for C in "$@"; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/$C -- python3 bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-parity --workdir /tmp/wd > $R/$C.json 2> $R/$C.err || echo FAIL $C
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/$C -- python3 bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-parity --no-fresh --workdir /tmp/wd > $R/$C.json 2> $R/$C.err || echo FAIL $C
 done
 python3 - $R "$@" <<'PY'
 import csv, glob, sys, collections
