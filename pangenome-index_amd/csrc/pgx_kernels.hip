@@ -1114,10 +1114,11 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     uint4 *s_stage = reinterpret_cast<uint4 *>(pgx_dyn_lds + (size_t)pk_words * PGX_FM_THREADS * 4) + (size_t)(threadIdx.x >> 6) * 512;
     // WIDE: behind those, per superblock the sixteen pair-count bases and their four row sums (24 words each, img.n_sbp superblocks)
     uint64_t *s_pb = reinterpret_cast<uint64_t *>(pgx_dyn_lds + (size_t)pk_words * PGX_FM_THREADS * 4 + (COOP ? (size_t)(PGX_FM_THREADS / 64) * 8192 : 0));
-    // LCE (never with COOP / WIDE): behind the packed reads, the suffix array entries of a lane's interval: entry t at s_sa[t * blockDim.x + threadIdx.x]
-    // (PGX_LCE_MAX_OCC entries per thread).  Fetched ONCE when the lane enters the text path, straight into LDS (global_load_lds): re-read from memory every
-    // trip the line of those entries did not stay in L2 between two trips of the lane -- a fifth of the kernel's memory-side traffic by the counters
-    uint32_t *s_sa = reinterpret_cast<uint32_t *>(pgx_dyn_lds + (size_t)pk_words * PGX_FM_THREADS * 4);
+    // LCE (never with COOP / WIDE): behind the packed reads, the suffix array entries of a lane's interval, fetched ONCE when the lane enters the text path,
+    // straight into LDS (global_load_lds_dwordx4: no registers in between, nothing to wait for in that trip) -- re-read from memory every trip the line of those
+    // entries did not stay in L2 between two trips of the lane: a fifth of the kernel's memory-side traffic by the counters.  Five 16-byte pieces per lane (the
+    // aligned window from k & ~3 on holds k .. k + 15 in at most five), piece t of lane l of wave w at s_sa4[(5 w + t) * 64 + l]
+    uint4 *s_sa4 = reinterpret_cast<uint4 *>(pgx_dyn_lds + (size_t)pk_words * PGX_FM_THREADS * 4);
     for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) s_ext[i] = img.consts->ext_tab[i];
     if (threadIdx.x < 8) s_C[threadIdx.x] = (pos_t)img.consts->C[threadIdx.x];
     if (threadIdx.x < 32) s_t2[threadIdx.x] = (pos_t)img.consts->pair_t2w[threadIdx.x];
@@ -1299,7 +1300,10 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         restart = 0u;
         if (LCE && __any(lce_lane && ((lce_st >> 8) & 0xFFu) == 0u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the entries asked for at the end of the last trip are in LDS)
         if (LCE && lce_lane) {
-            lce_pos = s_sa[((lce_st >> 8) & 0xFFu) * rd_stride + threadIdx.x];
+            {
+                const uint32_t e = ((uint32_t)k & 3u) + ((lce_st >> 8) & 0xFFu); // entry i of the interval inside the aligned window
+                lce_pos = reinterpret_cast<const uint32_t *>(s_sa4 + ((threadIdx.x >> 6) * 5u + (e >> 2)) * 64u + (uint32_t)lane)[e & 3u];
+            }
             lce_g0 = lce_pos + (uint32_t)(j - x);           // text position that faces read symbol j
             const uint32_t w0 = lce_g0 >> 4;                // its word (16 symbols); the window: words w0 .. w0 + 11
             const uint32_t *tp = img.lce_text + w0;
@@ -1579,13 +1583,13 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                     (uint32_t)(len - j) >= 2u * (uint32_t)s && (uint32_t)(len - j) <= 144u) {
                     lce_st = 1u;
                     lce_best = 0u;
-                    // SA[k .. k + s) into this thread's LDS column, no registers in between: instruction t of the wave writes the dword of lane l to
-                    // s_sa[t * blockDim.x + (wave's first thread) + l]
+                    // SA[k .. k + s) into LDS: piece t = the four entries from (k & ~3) + 4 t on, while it holds one of them (16 entries: five pieces at most)
+                    const uint32_t kb = (uint32_t)k & ~3u, need = ((uint32_t)k & 3u) + (uint32_t)s;
 #pragma unroll
-                    for (uint32_t t = 0; t < PGX_LCE_MAX_OCC; t++)
-                        if (t < (uint32_t)s)
-                            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(img.lce_sa + (uint32_t)k + t),
-                                                             (void __attribute__((address_space(3))) *)(s_sa + t * rd_stride + (threadIdx.x & ~63u)), 4, 0, 0);
+                    for (uint32_t t = 0; t < 5u; t++)
+                        if (4u * t < need)
+                            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(img.lce_sa + kb + 4u * t),
+                                                             (void __attribute__((address_space(3))) *)(s_sa4 + ((threadIdx.x >> 6) * 5u + t) * 64u), 16, 0, 0);
                 }
             }
         }

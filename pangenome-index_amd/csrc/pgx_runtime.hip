@@ -1246,7 +1246,7 @@ static void ensure_lce(pgx_index *h, pgx_device_image *d) {
         HIPCHECK(hipMemcpy(seq_start.p, hs.data(), (n_seq + 1) * 8, hipMemcpyHostToDevice));
         const uint64_t n_words = (n + 15) / 16 + 64, n_flag_words = n_words / 1024 + 2; // (64 words = two lines of padding behind the text, flagged)
         text8.ensure(n);
-        d->lce_sa.ensure(n * 4);
+        d->lce_sa.ensure(n * 4 + 128); // (the kernel reads aligned windows of up to 20 entries from an interval's first entry on)
         d->lce_text.ensure(n_words * 4);
         d->lce_flags.ensure(n_flag_words * 4);
         HIPCHECK(hipMemset(d->lce_flags.p, 0, n_flag_words * 4));
@@ -1611,7 +1611,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                         if (img.lce_sa && !coop && !img.wide && min_occ <= 1 && !(le && le[0] == '0')) {
                             kp = s64 ? (const void *)pgx_find_mems_pairs_kernel<true, false, true, false, true, true> : (const void *)pgx_find_mems_pairs_kernel<true, false, true, false, false, true>;
                             b->timing.pairs_reads = 4u;
-                            lce_lds = (size_t)PGX_LCE_MAX_OCC * PGX_FM_THREADS * 4; // the suffix array entries of every thread's interval
+                            lce_lds = (size_t)5 * PGX_FM_THREADS * 16; // the suffix array entries of every thread's interval: five 16-byte pieces each
                         }
                         a_packed = b->packed.as<uint32_t>();
                         a_pkw = pkw;
