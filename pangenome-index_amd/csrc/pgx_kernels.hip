@@ -1153,6 +1153,11 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     // LCE: bit 0 = the lane compares with the text (ph == 2), bit 1 = this stage must not (a flagged text line), bits 8..15 occurrence index, 16..23 index of
     // the first occurrence with the longest match, 24..31 how many reach it; the longest match; the text position of the occurrence of the next trip
     uint32_t lce_st = 0, lce_best = 0, lce_pos = 0;
+    // FUSE: a stage's first trip (no line of the image: the seed / first_ext entry, then the transitions) is not a trip of its own.  The entry is asked for
+    // at the END of the trip in which the stage starts (`fresh` 1 -> 2 | extensions the entry stands for << 8, the entry into se_pre) and applied at the top
+    // of the next one, after which the lane takes part in that trip like any other: 6.7 of a 150-symbol read's 25 lane trips were such first trips.
+    constexpr bool FUSE = LCE;
+    uint4 se_pre = make_uint4(0u, 0u, 0u, 0u);
 #ifdef PGX_FM_STATS
     unsigned long long st_trips = 0, st_live = 0, st_wait = 0, st_fresh = 0; // diagnostics build only (scripts/fm_stats.sh)
     unsigned long long st_t_refill = 0, st_refills = 0, st_t_seed = 0, st_t_line = 0;
@@ -1271,10 +1276,10 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         // what the wave asks of the memory system in this trip (wave-uniform sums in scalar registers): a live lane fetches one block line, except in a
         // stage's first trip, which reads block 0 like every other such lane and takes its result from first_ext / the seed table
         // (seed / end table entries: one per first trip -- an upper bound: a stage with fewer than K extensions to go reads the shared entry 0)
-        ln_blk += (unsigned long long)__popcll(__ballot(ph > 0 && fresh == 0u));
+        if (!FUSE) ln_blk += (unsigned long long)__popcll(__ballot(ph > 0 && fresh == 0u));
         ln_two += (unsigned long long)__popcll(__ballot(did2 != 0u));
         did2 = 0u;
-        if (SEED) ln_seed += (unsigned long long)__popcll(__ballot(ph > 0 && fresh != 0u));
+        if (SEED && !FUSE) ln_seed += (unsigned long long)__popcll(__ballot(ph > 0 && fresh != 0u));
         if (COOP) { // every lane names the block it is about to probe (idle lanes: block 0, like the first trip of a stage), the wave fetches all 64 lines
             const pos_t kk_c = (ph == 2) ? kp : k;
             const uint32_t myblk = ph > 0 ? (S64 ? (uint32_t)(kk_c >> 6) : (uint32_t)(((uint64_t)(kk_c >> 5) * 0xAAAAAAABull) >> 33)) + pend : 0u;
@@ -1299,6 +1304,52 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         bool em_now = false; // this trip ends with a MEM (set by either kind of lane); `restart`: with the next start position of the read
         restart = 0u;
         if (LCE && __any(lce_lane && ((lce_st >> 8) & 0xFFu) == 0u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the entries asked for at the end of the last trip are in LDS)
+        if (FUSE && ph > 0 && fresh >= 2u) { // the first extension(s) of a stage that started in the last trip: what the stage's first trip does in the other variants
+            const uint32_t kuse = fresh >> 8; // extensions the seed entry stands for (0: none was asked for)
+            fresh = 0u;
+            const bool at_end = j >= len, q1 = ph == 1;
+            const uint32_t qa = (uint32_t)(base & 15ull) + (uint32_t)(at_end ? len : j);
+            const uint32_t qs1 = at_end ? qa - 1u : qa, qs2 = qa ? qa - 1u : 0u;
+            const uint32_t wa = s_rd[(qs1 >> 4) * rd_stride + threadIdx.x], wb = s_rd[(qs2 >> 4) * rd_stride + threadIdx.x];
+            const uint4 f1 = s_fe[at_end ? 4u : ((wa >> (2u * (qs1 & 15u))) & 3u)], f2 = s_fe[5u + ((wb >> (2u * (qs2 & 15u))) & 3u)];
+            const bool small1 = f1.z == 0u || f1.z < mo || mo_huge;
+            const uint32_t sdepth = se_pre.w >> 24, se_s = se_pre.z;
+            const bool seed_alive = kuse != 0u && se_s != 0u && se_s >= mo && !mo_huge;
+            const bool seed_dead = kuse != 0u && se_s == 0u && sdepth != PGX_SEED_UNUSABLE && min_occ <= 1;
+            const bool rem2 = q1 ? (j - 1 >= x) : (j - 1 > x);
+            const bool do2 = at_end && rem2 && !seed_alive && !seed_dead && !small1; // (by 0, then by the last symbol of the read: quirk 4)
+            uint32_t ns = do2 ? f2.z : f1.z, nk = do2 ? f2.x : f1.x, nq = do2 ? f2.y : f1.y;
+            if (ns == 0u) { nk = 0u; nq = 0u; }
+            j -= do2 ? 1 : 0;
+            next += do2 ? 2u : 1u;
+            did2 = do2 ? 1u : 0u;
+            s = ns; k = nk; kp = nq;
+            bool small = ns == 0u || ns < mo || mo_huge;
+            if (seed_alive) {
+                k = se_pre.x; kp = se_pre.y; s = se_s;
+                small = false;
+                j -= (int32_t)kuse - 1;
+                next += kuse - 1u;
+            } else if (seed_dead) {
+                k = 0u; kp = 0u; s = 0u;
+                small = true;
+                j -= (int32_t)sdepth - 1;
+                next += sdepth - 1u;
+            }
+            const bool adv = !small, at_x = j == x;
+            const bool to2 = q1 && adv && at_x;
+            Jk = to2 ? k : Jk;
+            Js = to2 ? s : Js;
+            const int32_t jn = adv ? (q1 ? (at_x ? x + (int32_t)min_len : j - 1) : j - 1) : j;
+            const bool rs_end = !q1 && adv && jn <= x;
+            restart = (small || rs_end) ? 1u : 0u;
+            x = small ? j + 1 : (rs_end ? x + 1 : x);
+            ph = to2 ? 2 : ph;
+            j = jn;
+            em_now = to2 && jn >= len;
+        }
+        const bool sit_out = FUSE && (fresh != 0u || em_now || restart != 0u); // no line of the image for this lane in this trip
+        if (FUSE) ln_blk += (unsigned long long)__popcll(__ballot(ph > 0 && !sit_out));
         if (LCE && lce_lane) {
             {
                 const uint32_t e = ((uint32_t)k & 3u) + ((lce_st >> 8) & 0xFFu); // entry i of the interval inside the aligned window
@@ -1316,12 +1367,12 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         }
         if (LCE) ln_blk += (unsigned long long)(__popcll(__ballot(lce_lane && ((lce_g0 >> 4) >> 5) != (((lce_g0 >> 4) + 11u) >> 5))) +  // a window over two lines
                                                 __popcll(__ballot(lce_lane && ((lce_st >> 8) & 0xFFu) == 0u)));                     // the line of the interval's suffix array entries
-        if (ph > 0 && !lce_lane) {
-            const bool fr = fresh != 0u; // first extension of a backward stage: from first_ext / the seed table
+        if (ph > 0 && !lce_lane && !sit_out) {
+            const bool fr = !FUSE && fresh != 0u; // first extension of a backward stage: from first_ext / the seed table
             bool seed_lane = false;
             uint32_t kuse = 0u; // extensions the seed entry stands for
             uint4 se = make_uint4(0u, 0u, 0u, 0u);
-            if (SEED) {
+            if (SEED && !FUSE) {
                 const uint4 *sp = img.seed;
                 if (fr) {
                     const bool endw = j >= len; // (the end table: see pgx_find_mems_kernel)
@@ -1353,7 +1404,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 st_t_seed += __builtin_readcyclecounter() - st_s0;
 #endif
             }
-            fresh = 0u;
+            if (!FUSE) fresh = 0u;
             const bool fwd = (ph == 2);
             const uint64_t at = base + (uint64_t)j;
             // pattern[len] reads as 0 (quirk 4): step 3 of a MEM that reaches the end of its read starts there, from the full interval;
@@ -1627,6 +1678,26 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         }
         if (em_now) emit();
         if (restart) begin();
+        if (FUSE) { // the stages that have just started (here or in the refill round): their seed entries are on the way while the wave loops
+            const bool ask = ph > 0 && fresh == 1u;
+            bool asked = false;
+            if (ask) {
+                const bool endw = j >= len; // (the end table: see pgx_find_mems_kernel)
+                const int32_t K = endw ? (int32_t)img.seed_end_k : (int32_t)img.seed_k;
+                const int32_t avail = (ph == 1) ? (j - x + 1) : (j - x);
+                uint32_t kuse = 0u;
+                if (K && avail >= K + (endw ? 1 : 0)) { // the window's 2 K bits of the packed read are the index
+                    const uint32_t q = (uint32_t)(base & 15ull) + (uint32_t)((endw ? len - 1 : j) - K + 1);
+                    const uint32_t w0 = s_rd[(q >> 4) * rd_stride + threadIdx.x], w1 = s_rd[((q >> 4) + 1u) * rd_stride + threadIdx.x]; // (one word of padding per thread)
+                    const uint32_t sidx = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (2u * (q & 15u))) & (uint32_t)((1ull << (2 * K)) - 1ull); // (K = 16: all 32 bits)
+                    se_pre = (endw ? img.seed_end : img.seed)[sidx];
+                    kuse = (uint32_t)K + (endw ? 1u : 0u);
+                    asked = true;
+                }
+                fresh = 2u | (kuse << 8);
+            }
+            ln_seed += (unsigned long long)__popcll(__ballot(asked));
+        }
     }
     unsigned long long tot = next;
 #pragma unroll

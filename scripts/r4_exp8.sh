@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 4, experiment 8: a stage's first trip folded into the trip after it (FUSE): the parity tests of the kernel, then the default workload
+set -e
+mkdir -p gpurun_out
+W=/tmp/pgxwd; mkdir -p $W
+python -m pytest tests/test_gpu_pairs.py tests/test_gpu_parity.py tests/test_wide_image.py -m gpu -x -q > gpurun_out/r4_fuse_tests.log 2>&1 || { tail -30 gpurun_out/r4_fuse_tests.log; exit 1; }
+tail -2 gpurun_out/r4_fuse_tests.log
+for t in a b; do
+python bench.py --workdir $W --no-cpu-baseline --no-secondary --no-fresh --parity-reads 30000 --steps 10 > gpurun_out/r4_fuse_$t.json 2> gpurun_out/r4_fuse_$t.err
+python - <<PY
+import json
+d=json.loads(open("gpurun_out/r4_fuse_$t.json").read().strip().splitlines()[-1])
+k=d["kernel_ms_per_step"]; r=d["roofline"]
+print("$t: %.1f M reads/s, step %.2f ms, main %.2f ms, lines %.1f M, seeds %.1f M, frac %.3f, parity %s" % (d["value"]/1e6, d["ms_per_step"], k["find_mems_main"], r["probes_issued"]/1e6, r["seed_loads"]/1e6, r["frac"], d["parity_sample"]["identical"]))
+PY
+done
