@@ -94,9 +94,12 @@ struct PgxDevImage {
     const uint32_t *lce_sa;    // n entries: position of suffix i in lce_text
     const uint32_t *lce_text;  // two bits per symbol (A C T G = 0 1 2 3, the order of the packed reads), 16 symbols per word, sequences with their endmarkers
     const uint32_t *lce_flags; // one bit per 128-byte line of lce_text: the line holds a symbol outside A C G T or lies behind the text
+    const uint8_t *lce_lcp;    // n entries (NULL without): symbols suffix i shares with suffix i - 1, capped at PGX_LCP_CAP; PGX_LCP_UNKNOWN where the comparison met a flagged line
     uint32_t lce_max;          // widest interval that goes this way
     uint32_t refill_min;       // LCE kernel: idle lanes of a wave wait for this many before the wave fetches new reads
 };
+#define PGX_LCP_CAP 254u     // lce_lcp: "this many symbols or more"
+#define PGX_LCP_UNKNOWN 255u // lce_lcp: not known (the comparison touched a flagged line of the text)
 #define PGX_SEED_UNUSABLE 255u // depth value of entries the kernels must not use (a coordinate does not fit the entry)
 #define PGX_SEED_MAX_K 16
 #define PGX_SEED_SMALL_K 10 // depth of the second table (searches whose min_len is below the depth of the first)
@@ -218,6 +221,7 @@ __global__ void pgx_lce_seqlen_kernel(const uint64_t *sa, uint64_t n_seq, uint64
 __global__ void pgx_lce_scatter_kernel(const uint64_t *sa, uint64_t n, uint64_t max_length, const uint64_t *seq_start, uint64_t n_seq, uint64_t c1, uint64_t c2, uint64_t c3,
                                        uint64_t c4, uint64_t c5, uint32_t *sa32, uint8_t *text8, unsigned long long *bad);
 __global__ void pgx_lce_pack_kernel(const uint8_t *text8, uint64_t n, uint64_t n_words, uint32_t *text32, uint32_t *flags);
+__global__ void pgx_lce_lcp_kernel(const uint32_t *sa32, const uint32_t *text32, const uint32_t *flags, uint64_t n, uint8_t *lcp);
 __global__ void pgx_lce_rc_check_kernel(const uint8_t *text8, const uint64_t *seq_start, uint64_t n_seq, uint64_t n, unsigned long long *bad);
 __global__ void pgx_locate_plan_kernel(PgxLocImage loc, const uint64_t *qs, const uint64_t *qe, uint64_t n, uint64_t *run0,
                                        uint64_t *n_pieces);

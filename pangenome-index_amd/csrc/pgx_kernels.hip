@@ -1304,6 +1304,13 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         bool em_now = false; // this trip ends with a MEM (set by either kind of lane); `restart`: with the next start position of the read
         restart = 0u;
         if (LCE && __any(lce_lane && ((lce_st >> 8) & 0xFFu) == 0u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the entries asked for at the end of the last trip are in LDS)
+#ifdef PGX_FM_STATS
+        if (FUSE && __any(ph > 0 && fresh >= 2u)) {
+            const unsigned long long st_s0 = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_t_seed += __builtin_readcyclecounter() - st_s0;
+        }
+#endif
         if (FUSE && ph > 0 && fresh >= 2u) { // the first extension(s) of a stage that started in the last trip: what the stage's first trip does in the other variants
             const uint32_t kuse = fresh >> 8; // extensions the seed entry stands for (0: none was asked for)
             fresh = 0u;
@@ -1364,9 +1371,15 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             const uint32_t l0 = w0 >> 5, l1 = (w0 + 11u) >> 5; // the lines of the window
             d1.x = img.lce_flags[l0 >> 5] >> (l0 & 31u);
             d1.y = img.lce_flags[l1 >> 5] >> (l1 & 31u);
+            if (img.lce_lcp) { // what the occurrences after the first share with their predecessors (entries k + 1 ..: five dwords hold the fifteen)
+                const uint32_t *lp = reinterpret_cast<const uint32_t *>(img.lce_lcp + (((uint32_t)k + 1u) & ~3u));
+                const u4_t v = *reinterpret_cast<const u4_t *>(lp);
+                d1.z = v.x; d1.w = v.y; d2.x = v.z; d2.y = v.w; d2.z = lp[4];
+            }
         }
         if (LCE) ln_blk += (unsigned long long)(__popcll(__ballot(lce_lane && ((lce_g0 >> 4) >> 5) != (((lce_g0 >> 4) + 11u) >> 5))) +  // a window over two lines
-                                                __popcll(__ballot(lce_lane && ((lce_st >> 8) & 0xFFu) == 0u)));                     // the line of the interval's suffix array entries
+                                                __popcll(__ballot(lce_lane && ((lce_st >> 8) & 0xFFu) == 0u)) +                     // the line of the interval's suffix array entries
+                                                (img.lce_lcp ? __popcll(__ballot(lce_lane && ((lce_st >> 8) & 0xFFu) == 0u && s > 1u)) : 0)); // ... and of their common prefixes
         if (ph > 0 && !lce_lane && !sit_out) {
             const bool fr = !FUSE && fresh != 0u; // first extension of a backward stage: from first_ext / the seed table
             bool seed_lane = false;
@@ -1666,7 +1679,30 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 cnt = better ? 1u : (l == lce_best ? cnt + 1u : cnt);
                 a = better ? i : a;
                 lce_best = better ? l : lce_best;
-                if (i + 1u < (uint32_t)s) lce_st = 1u | ((i + 1u) << 8) | (a << 16) | (cnt << 24);
+                // The occurrences behind this one, from the common prefixes of neighbouring suffixes: with c symbols shared between occurrence t - 1 and t and a match of
+                // `cur` with t - 1, the match with t is min(cur, c - m) (m = the symbols matched before the stage) -- unless both are the same length, where t may match
+                // further: that occurrence (or one whose entry is unknown) is compared with the text itself, in the next trip.  A typical stage is ONE trip this way.
+                uint32_t nxt = i + 1u;
+                if (img.lce_lcp && (uint32_t)(len - x) <= PGX_LCP_CAP - 1u) { // (m + what is left of the read stays below the cap: a capped entry is "longer than anything asked")
+                    const uint32_t m = (uint32_t)(j - x), bsh = ((uint32_t)k + 1u) & 3u;
+                    const uint32_t W[4] = {__builtin_amdgcn_alignbyte(d1.w, d1.z, bsh), __builtin_amdgcn_alignbyte(d2.x, d1.w, bsh), __builtin_amdgcn_alignbyte(d2.y, d2.x, bsh),
+                                           __builtin_amdgcn_alignbyte(d2.z, d2.y, bsh)};
+                    uint32_t cur = l;
+                    bool stop = false;
+#pragma unroll
+                    for (uint32_t t = 1; t < PGX_LCE_MAX_OCC; t++) {
+                        const uint32_t c = (W[(t - 1u) >> 2] >> (8u * ((t - 1u) & 3u))) & 0xFFu, rel = c - m;
+                        const bool act = !stop && t > i && t < (uint32_t)s;
+                        const bool hard = c == PGX_LCP_UNKNOWN || c < m || (rel == cur && cur < rem);
+                        stop = stop || (act && hard);
+                        if (act && !hard) {
+                            cur = rel < cur ? rel : cur;
+                            cnt += cur == lce_best ? 1u : 0u;
+                            nxt = t + 1u;
+                        }
+                    }
+                }
+                if (nxt < (uint32_t)s) lce_st = 1u | (nxt << 8) | (a << 16) | (cnt << 24);
                 else { // every occurrence seen: the MEM ends where the longest match ends; the occurrences that reach it are its interval
                     Jk = k + (pos_t)a; Js = (pos_t)cnt;
                     next += lce_best + (lce_best < rem ? 1u : 0u); // (the extension that fails counts, as in the stepwise stage)

@@ -124,6 +124,37 @@ pgx_lce_pack_kernel(const uint8_t *__restrict__ text8, uint64_t n, uint64_t n_wo
     }
 }
 
+// lce_lcp (pgx_image.h): entry i = the number of symbols suffix i has in common with suffix i - 1, from the 2-bit text: 64 symbols per round (five words
+// of either suffix), PGX_LCP_CAP for "that many or more".  The words that were looked at lie in at most two 128-byte lines per suffix; if one of them is
+// flagged (an N, an endmarker, behind the text: the 2-bit codes there mean nothing) the entry says PGX_LCP_UNKNOWN and the search compares with the text itself.
+__global__ void __launch_bounds__(256)
+pgx_lce_lcp_kernel(const uint32_t *__restrict__ sa32, const uint32_t *__restrict__ text32, const uint32_t *__restrict__ flags, uint64_t n, uint8_t *__restrict__ lcp) {
+    typedef struct __attribute__((packed, aligned(4))) { uint32_t x, y, z, w; } u4_t;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (i == 0) { lcp[0] = 0; continue; }
+        const uint32_t p = sa32[i - 1], q = sa32[i];
+        const uint32_t wp = p >> 4, wq = q >> 4, sp = 2u * (p & 15u), sq = 2u * (q & 15u);
+        uint32_t l = PGX_LCP_CAP, rounds = 0;
+#pragma unroll 1
+        for (uint32_t r = 0; r < 4u && l == PGX_LCP_CAP; r++) { // 4 x 64 symbols >= the cap
+            const u4_t a = *reinterpret_cast<const u4_t *>(text32 + wp + 4u * r), b = *reinterpret_cast<const u4_t *>(text32 + wq + 4u * r);
+            const uint32_t a4 = text32[wp + 4u * r + 4u], b4 = text32[wq + 4u * r + 4u];
+            const uint32_t A[5] = {a.x, a.y, a.z, a.w, a4}, B[5] = {b.x, b.y, b.z, b.w, b4};
+            rounds = r + 1u;
+#pragma unroll
+            for (int u = 3; u >= 0; u--) { // (from the last unit down: the first differing one wins)
+                const uint32_t df = __builtin_amdgcn_alignbit(A[u + 1], A[u], sp) ^ __builtin_amdgcn_alignbit(B[u + 1], B[u], sq);
+                l = df ? 64u * r + 16u * (uint32_t)u + ((uint32_t)__builtin_ctz(df) >> 1) : l;
+            }
+        }
+        l = l < PGX_LCP_CAP ? l : PGX_LCP_CAP;
+        // the words looked at: w .. w + 4 rounds (17 at most: two lines)
+        const uint32_t lp0 = wp >> 5, lp1 = (wp + 4u * rounds) >> 5, lq0 = wq >> 5, lq1 = (wq + 4u * rounds) >> 5;
+        const uint32_t fl = ((flags[lp0 >> 5] >> (lp0 & 31u)) | (flags[lp1 >> 5] >> (lp1 & 31u)) | (flags[lq0 >> 5] >> (lq0 & 31u)) | (flags[lq1 >> 5] >> (lq1 & 31u))) & 1u;
+        lcp[i] = (uint8_t)(fl ? PGX_LCP_UNKNOWN : l);
+    }
+}
+
 // The text comparison stands for FORWARD extensions, and the FMD index answers those through the reverse complement (src/r-index.cpp:758-764): the two agree
 // only where the collection holds every sequence in both orientations.  Checked here for the layout the reference's pipeline and the synthetic workloads
 // write -- sequence 2 i + 1 is the reverse complement of sequence 2 i --; any position that disagrees raises the flag and the image is not built.

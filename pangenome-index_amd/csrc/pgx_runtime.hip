@@ -84,7 +84,7 @@ struct pgx_device_image {
     PgxDevImage img{};
     DevBuf blocks, dir, blow, consts, tstart, tvals, tdir, tpair, tbucket, seed, seed_small, seed_end, exc, pairs, first_ext, sbase2, pbase;
     DevBuf rstart, rsamp, rdir, lpos, lnext, ldir; // locate image, uploaded on first use
-    DevBuf lce_sa, lce_text, lce_flags;            // LCE image (ensure_lce), built on the first batch
+    DevBuf lce_sa, lce_text, lce_flags, lce_lcp;   // LCE image (ensure_lce), built on the first batch
     int lce_state = 0;                             // 0 not tried, 1 built, 2 not available for this index / device
     DevBuf lit_bstart, lit_cum, lit_runs, lit_roff, lit_tabs; // literal count image (quirk 3), uploaded on first use
     PgxLitImage lit{};
@@ -102,7 +102,7 @@ void pgx_release_device_images(pgx_index *h) {
             d->tstart.release(); d->tvals.release(); d->tdir.release(); d->tpair.release(); d->tbucket.release(); d->seed.release(); d->seed_small.release(); d->seed_end.release(); d->exc.release(); d->pairs.release(); d->first_ext.release(); d->sbase2.release(); d->pbase.release();
             d->lit_bstart.release(); d->lit_cum.release(); d->lit_runs.release(); d->lit_roff.release(); d->lit_tabs.release();
             d->rstart.release(); d->rsamp.release(); d->rdir.release(); d->lpos.release(); d->lnext.release(); d->ldir.release();
-            d->lce_sa.release(); d->lce_text.release(); d->lce_flags.release();
+            d->lce_sa.release(); d->lce_text.release(); d->lce_flags.release(); d->lce_lcp.release();
         }
         delete d;
     }
@@ -249,7 +249,7 @@ static pgx_device_image *device_image(pgx_index *h, int device) {
     g.seed_k_main = g.seed_k_small = 0;
     g.seed_main = g.seed_small = nullptr;
     g.pairs = nullptr; g.first_ext = nullptr; g.pair_runs = 0;
-    g.lce_sa = nullptr; g.lce_text = nullptr; g.lce_flags = nullptr; g.lce_max = 0; g.refill_min = 1;
+    g.lce_sa = nullptr; g.lce_text = nullptr; g.lce_flags = nullptr; g.lce_lcp = nullptr; g.lce_max = 0; g.refill_min = 1;
     if (g.dense && h->has_rank) build_seed_table(d.get());
     if (m.consts.has_pairs && !m.pairs.empty() && h->has_rank) { // the two-step image next to dense2 (pgx_image.h)
         upload(d->pairs, m.pairs.data(), m.pairs.size());
@@ -1222,7 +1222,7 @@ static void ensure_lce(pgx_index *h, pgx_device_image *d) {
     {
         size_t mem_free = 0, mem_total = 0;
         if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); return; }
-        if ((double)mem_free < 16.0 * (double)n + (double)(2ull << 30)) return; // 8 n (suffix array as the locate kernels write it) + n (text bytes) + 4.25 n (the image) + room
+        if ((double)mem_free < 16.0 * (double)n + (double)(2ull << 30)) return; // 8 n (suffix array as the locate kernels write it) + n (text bytes) + 5.25 n (the image) + room
     }
     DevBuf vals, seq_len, seq_start, text8, bad;
     try {
@@ -1268,7 +1268,17 @@ static void ensure_lce(pgx_index *h, pgx_device_image *d) {
         hipLaunchKernelGGL(pgx_lce_pack_kernel, dim3((unsigned)std::min<uint64_t>((n_words + 255) / 256, 1u << 20)), dim3(256), 0, nullptr, text8.as<uint8_t>(), n, n_words,
                            d->lce_text.as<uint32_t>(), d->lce_flags.as<uint32_t>());
         HIPCHECK(hipGetLastError());
+        text8.release();
+        const char *le = std::getenv("PGX_FM_LCP"); // (PGX_FM_LCP=0: every occurrence is compared with the text, as before the table existed)
+        const bool with_lcp = !(le && le[0] == '0');
+        if (with_lcp) {
+            d->lce_lcp.ensure(n + 64); // (the kernel reads aligned windows of up to 20 entries)
+            hipLaunchKernelGGL(pgx_lce_lcp_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 20)), dim3(256), 0, nullptr, d->lce_sa.as<uint32_t>(),
+                               d->lce_text.as<uint32_t>(), d->lce_flags.as<uint32_t>(), n, d->lce_lcp.as<uint8_t>());
+            HIPCHECK(hipGetLastError());
+        }
         HIPCHECK(hipDeviceSynchronize());
+        d->img.lce_lcp = with_lcp ? d->lce_lcp.as<uint8_t>() : nullptr;
         d->img.lce_sa = d->lce_sa.as<uint32_t>();
         d->img.lce_text = d->lce_text.as<uint32_t>();
         d->img.lce_flags = d->lce_flags.as<uint32_t>();
@@ -1279,8 +1289,8 @@ static void ensure_lce(pgx_index *h, pgx_device_image *d) {
         d->lce_state = 1;
     } catch (...) { // (no LCE image: the search runs on the PAIRS image alone, as before)
         (void)hipGetLastError();
-        d->lce_sa.release(); d->lce_text.release(); d->lce_flags.release();
-        d->img.lce_sa = nullptr; d->img.lce_text = nullptr; d->img.lce_flags = nullptr;
+        d->lce_sa.release(); d->lce_text.release(); d->lce_flags.release(); d->lce_lcp.release();
+        d->img.lce_sa = nullptr; d->img.lce_text = nullptr; d->img.lce_flags = nullptr; d->img.lce_lcp = nullptr;
     }
     vals.release(); seq_len.release(); seq_start.release(); text8.release(); bad.release();
 }

@@ -320,7 +320,9 @@ def test_forward_stages_through_the_text(workdir, monkeypatch, haps, stride):
     the text -- one occurrence per trip, longest match and the occurrences that reach it -- instead of two symbols per trip (algorithm.hpp:676-700 is the
     loop it replaces: the forward extensions of find_mems_function).  Same bytes as the oracle and as the stepwise kernel (PGX_FM_LCE=0), extension counts
     included, for min_occ 0 / 1 (min_occ > 1 never takes this path); reads that end / start a sequence, reads over N runs (flagged text lines), short reads,
-    reads longer than the 144 symbols a text window holds; 40 haplotypes: intervals too wide, the path is not taken; and fewer lines where it is."""
+    reads longer than the 144 symbols a text window holds; 40 haplotypes: intervals too wide, the path is not taken; and fewer lines where it is.
+    With img.lce_lcp (the default; PGX_FM_LCP=0 without) the occurrences after a compared one follow from the common prefixes of neighbouring suffixes
+    (pgx_lce_lcp_kernel; tests/test_lce_math.py has the arithmetic): same bytes again, fewer lines again."""
     text = os.path.join(workdir, "lce_%d.txt" % haps)
     W.synth_pangenome_text(text, base_len=1_200_000 // haps, n_hap=haps, seed=70 + haps, n_runs=3, n_run_len=(60, 900))
     ri_path, tags_path = W.build_index_from_text(text, workdir, "lce_%d" % haps)[:2]
@@ -339,11 +341,12 @@ def test_forward_stages_through_the_text(workdir, monkeypatch, haps, stride):
     monkeypatch.setenv("PGX_PAIRS_STRIDE", stride)
     refs = {pr: O.find_mems_batch(ri, tags, cat, offs, pr[0], pr[1], threads=O.lib().orc_max_threads()) for pr in ((20, 1), (12, 1), (25, 0), (20, 3))}
     lines = {}
-    for lce in ("0", None):
-        if lce is None:
-            monkeypatch.delenv("PGX_FM_LCE", raising=False)
-        else:
-            monkeypatch.setenv("PGX_FM_LCE", lce)
+    for lce, lcp in (("0", None), (None, "0"), (None, None)):  # stepwise; every occurrence compared with the text; the common-prefix table (the default)
+        for name, v in (("PGX_FM_LCE", lce), ("PGX_FM_LCP", lcp)):
+            if v is None:
+                monkeypatch.delenv(name, raising=False)
+            else:
+                monkeypatch.setenv(name, v)
         idx = P.Index(ri_path, tags_path, mode=P.MODE_COMPAT | P.MODE_IMAGE_PAIRS)
         for pr, ref in refs.items():
             b = idx.batch(cat, offs)
@@ -353,13 +356,14 @@ def test_forward_stages_through_the_text(workdir, monkeypatch, haps, stride):
                 assert t.pairs_reads == (4 if (lce is None and pr[1] <= 1) else 2), (lce, pr, t.pairs_reads)
                 _same(b.result(), ref)
             if pr == (20, 1):
-                lines[lce] = int(t.main_lines)
+                lines[(lce, lcp)] = int(t.main_lines)
             b.free()
         idx.close()
     if haps <= 12:
-        assert lines[None] < 0.8 * lines["0"], (haps, lines)
+        assert lines[(None, "0")] < 0.8 * lines[("0", None)], (haps, lines)
+        assert lines[(None, None)] < (0.9 if haps >= 4 else 1.02) * lines[(None, "0")], (haps, lines)
     else:
-        assert lines[None] <= 1.02 * lines["0"], (haps, lines)
+        assert lines[(None, None)] <= 1.02 * lines[("0", None)], (haps, lines)
 
 
 def test_no_text_comparison_on_a_forward_only_collection(workdir, monkeypatch):

@@ -60,3 +60,92 @@ def test_forward_stage_equals_longest_match_over_the_occurrences(workdir):
                 assert (x, j + best, k + first, cnt) == tuple(mem), (rd, x, min_len)
                 checked += 1
     assert checked > 3000
+
+
+def _lcp_table(T, gpos, cap=254, unknown=255):
+    """what pgx_lce_lcp_kernel writes: entry i = symbols suffix i shares with suffix i - 1 (capped), `unknown` where the words it looked at -- 64 symbols per round,
+    five words of either suffix -- touch a 512-symbol line of the text that holds anything but A C G T (or lies behind the text)"""
+    n = len(T)
+    Tp = np.concatenate([T, np.full(2048, 1, dtype=np.uint8)])
+    p, q = gpos[:-1].astype(np.int64), gpos[1:].astype(np.int64)
+    l = np.zeros(n - 1, dtype=np.int64)
+    alive = np.ones(n - 1, dtype=bool)
+    for d in range(256):
+        alive &= Tp[p + d] == Tp[q + d]
+        l += alive
+    rounds = np.minimum(4, l // 64 + 1)
+    special = ~np.isin(Tp, np.frombuffer(b"ACGT", dtype=np.uint8))
+    special[n:] = True
+    line_bad = np.add.reduceat(special[: (len(Tp) // 512) * 512].astype(np.int64), np.arange(0, (len(Tp) // 512) * 512, 512)) > 0
+    bad = np.zeros(n - 1, dtype=bool)
+    for s0 in (p, q):
+        w = s0 >> 4
+        bad |= line_bad[w >> 5] | line_bad[(w + 4 * rounds) >> 5]
+    out = np.where(bad, unknown, np.minimum(l, cap)).astype(np.int64)
+    return np.concatenate([[0], out])
+
+
+def test_occurrences_after_the_first_follow_from_the_common_prefixes(workdir):
+    """the chain of pgx_find_mems_pairs_kernel<.., LCE> with img.lce_lcp: after a comparison of occurrence i with the text (match l), occurrence t > i matches
+    min(previous match, lcp[k + t] - m) symbols -- m the symbols matched before the stage -- as long as the two differ (or the read has ended); where they are
+    equal, or the entry is unknown, occurrence t is compared with the text itself.  Same MEMs as the oracle, and far fewer comparisons than occurrences."""
+    text = os.path.join(workdir, "lce_math.txt")
+    W.synth_pangenome_text(text, base_len=30_000, n_hap=5, seed=3, n_runs=3, n_run_len=(30, 300))
+    ri_path = W.build_index_from_text(text, workdir, "lce_math", with_tags=False)[0]
+    ri = O.RIndex(ri_path)
+    seqs = W.load_sequences(text)
+    ml = ri.max_length
+    sa = ri.decompress_sa()
+    seq_start = np.concatenate([[0], np.cumsum([len(s) + 1 for s in seqs])])
+    T = np.concatenate([np.concatenate([s, [10]]) for s in seqs]).astype(np.uint8)
+    gpos = seq_start[(sa // ml).astype(np.int64)] + (sa % ml).astype(np.int64)
+    lcp = _lcp_table(T, gpos)
+    assert (lcp == 255).sum() < len(lcp) // 4  # (only near the N runs and the sequence ends)
+    cat, offs = W.sample_reads(seqs, 1500, 150, seed=8, n_frac=0.05)
+    rng = np.random.default_rng(1)
+    checked = compares = occurrences = 0
+    for r in range(1500):
+        rd = bytes(cat[offs[r]:offs[r + 1]])
+        if r % 5 == 0:
+            rd = rd[: int(rng.integers(25, 150))]
+        if r % 11 == 0:
+            rd = bytes(seqs[r % len(seqs)][-len(rd):])
+        for min_len in (20, 12):
+            for x in (0, int(rng.integers(0, max(1, len(rd) - min_len)))):
+                nx, mem, _ = ri.find_mems_function(rd, min_len, 1, x)
+                if mem is None or any(ch not in b"ACGT" for ch in rd[x:]):
+                    continue
+                k, _, s = ri.bwd_pattern(rd[x:x + min_len])
+                if s > 16:
+                    continue
+                j, m = x + min_len, min_len
+                rem = len(rd) - j
+                best, first, cnt, i = -1, 0, 0, 0
+                while True:
+                    compares += 1
+                    p = int(gpos[k + i]) + m
+                    l = 0
+                    while l < rem and T[p + l] == rd[j + l]:
+                        l += 1
+                    if i == 0 or l > best:
+                        best, first, cnt = l, i, 1
+                    elif l == best:
+                        cnt += 1
+                    nxt, cur = i + 1, l
+                    if len(rd) - x <= 253:
+                        for t in range(i + 1, s):
+                            c = int(lcp[k + t])
+                            if c == 255 or c < m or (c - m == cur and cur < rem):
+                                break
+                            cur = min(cur, c - m)
+                            cnt += cur == best
+                            nxt = t + 1
+                    if nxt >= s:
+                        break
+                    i = nxt
+                assert (x, j + best, k + first, cnt) == tuple(mem), (rd, x, min_len)
+                checked += 1
+                occurrences += s
+    assert checked > 3000
+    print("stages %d, occurrences %d, comparisons with the text %d" % (checked, occurrences, compares))
+    assert compares < 0.6 * occurrences
