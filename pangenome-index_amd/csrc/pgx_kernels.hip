@@ -1119,6 +1119,9 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     // entries did not stay in L2 between two trips of the lane: a fifth of the kernel's memory-side traffic by the counters.  Five 16-byte pieces per lane (the
     // aligned window from k & ~3 on holds k .. k + 15 in at most five), piece t of lane l of wave w at s_sa4[(5 w + t) * 64 + l]
     uint4 *s_sa4 = reinterpret_cast<uint4 *>(pgx_dyn_lds + (size_t)pk_words * PGX_FM_THREADS * 4);
+    // ... and behind those what the entries after the first share with their predecessors (img.lce_lcp: one byte each), the same way: the five dwords from
+    // (k + 1) & ~3 on hold the fifteen, dword t of lane l of wave w at s_lcp[(5 w + t) * 64 + l]
+    uint32_t *s_lcp = reinterpret_cast<uint32_t *>(s_sa4 + 5u * PGX_FM_THREADS);
     for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) s_ext[i] = img.consts->ext_tab[i];
     if (threadIdx.x < 8) s_C[threadIdx.x] = (pos_t)img.consts->C[threadIdx.x];
     if (threadIdx.x < 32) s_t2[threadIdx.x] = (pos_t)img.consts->pair_t2w[threadIdx.x];
@@ -1157,7 +1160,22 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     // at the END of the trip in which the stage starts (`fresh` 1 -> 2 | extensions the entry stands for << 8, the entry into se_pre) and applied at the top
     // of the next one, after which the lane takes part in that trip like any other: 6.7 of a 150-symbol read's 25 lane trips were such first trips.
     constexpr bool FUSE = LCE;
-    uint4 se_pre = make_uint4(0u, 0u, 0u, 0u);
+    // (the entry travels through LDS -- global_load_lds into the first of the lane's five suffix array pieces, which no stage that starts is using --: kept in
+    //  registers, the compiler loaded it into others than the ones it lives in across the loop's back edge and copied it over there, behind a wait for the
+    //  load, which put the entry's latency back into every trip)
+    typedef uint32_t pgx_u32x4 __attribute__((ext_vector_type(4)));
+#ifndef PGX_SEED_VIA_LDS
+#define PGX_SEED_VIA_LDS 1 // (0: the entry in registers, loaded by the compiler -- scripts/r4_exp10.sh)
+#endif
+#ifndef PGX_LCE_ASM_LOADS
+#define PGX_LCE_ASM_LOADS 1 // (0: the lines of the LCE variant loaded by the compiler)
+#endif
+    uint4 se_reg = make_uint4(0u, 0u, 0u, 0u);
+    // (and so are the lines of the LCE variant: its two kinds of lanes load into the same registers at different points of a trip, and between them the
+    //  compiler used those registers as scratch for the other kind -- after waiting for the first kind's loads, one memory latency in front of the other)
+    pgx_u32x4 row = {0u, 0u, 0u, 0u}, hs = row, d0 = row, d1 = row, d2 = row; // (whoever reads them in a trip has loaded them in that trip)
+    uint32_t lce_f0 = 0u, lce_f1 = 0u; // the flag words of the lines of a lane's text window
+    auto ld4 = [](const uint4 *q) __attribute__((always_inline)) { return *reinterpret_cast<const pgx_u32x4 *>(q); };
 #ifdef PGX_FM_STATS
     unsigned long long st_trips = 0, st_live = 0, st_wait = 0, st_fresh = 0; // diagnostics build only (scripts/fm_stats.sh)
     unsigned long long st_t_refill = 0, st_refills = 0, st_t_seed = 0, st_t_line = 0;
@@ -1298,7 +1316,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         }
         // the five 16-byte pieces a lane loads in a trip: its block's row, counts and planes -- or, for a lane that compares with the text, three pieces of the
         // text, the flag words of the lines they lie in and the next occurrence's suffix array entry (the same registers: nothing added to the trip's pressure)
-        uint4 row = make_uint4(0u, 0u, 0u, 0u), hs = row, d0 = row, d1 = row, d2 = row;
+        if (LCE && PGX_LCE_ASM_LOADS) asm volatile("" : "=v"(row), "=v"(hs), "=v"(d0), "=v"(lce_f0), "=v"(lce_f1)); // (nothing of the last trip's lines is needed: the registers are free until here)
         const bool lce_lane = LCE && ph == 2 && (lce_st & 1u) != 0u;
         uint32_t lce_g0 = 0u;
         bool em_now = false; // this trip ends with a MEM (set by either kind of lane); `restart`: with the next start position of the read
@@ -1311,8 +1329,10 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             st_t_seed += __builtin_readcyclecounter() - st_s0;
         }
 #endif
+        if (FUSE && PGX_SEED_VIA_LDS && __any(ph > 0 && fresh >= 0x100u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the entries asked for at the end of the last trip are in LDS)
         if (FUSE && ph > 0 && fresh >= 2u) { // the first extension(s) of a stage that started in the last trip: what the stage's first trip does in the other variants
             const uint32_t kuse = fresh >> 8; // extensions the seed entry stands for (0: none was asked for)
+            const uint4 se_pre = PGX_SEED_VIA_LDS ? s_sa4[(threadIdx.x >> 6) * 5u * 64u + (uint32_t)lane] : se_reg;
             fresh = 0u;
             const bool at_end = j >= len, q1 = ph == 1;
             const uint32_t qa = (uint32_t)(base & 15ull) + (uint32_t)(at_end ? len : j);
@@ -1365,17 +1385,18 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             lce_g0 = lce_pos + (uint32_t)(j - x);           // text position that faces read symbol j
             const uint32_t w0 = lce_g0 >> 4;                // its word (16 symbols); the window: words w0 .. w0 + 11
             const uint32_t *tp = img.lce_text + w0;
-            typedef struct __attribute__((packed, aligned(4))) { uint32_t x, y, z, w; } u4_t; // (dword-aligned 16-byte pieces)
-            const u4_t a = *reinterpret_cast<const u4_t *>(tp), b = *reinterpret_cast<const u4_t *>(tp + 4), c = *reinterpret_cast<const u4_t *>(tp + 8);
-            row = make_uint4(a.x, a.y, a.z, a.w); hs = make_uint4(b.x, b.y, b.z, b.w); d0 = make_uint4(c.x, c.y, c.z, c.w);
-            const uint32_t l0 = w0 >> 5, l1 = (w0 + 11u) >> 5; // the lines of the window
-            d1.x = img.lce_flags[l0 >> 5] >> (l0 & 31u);
-            d1.y = img.lce_flags[l1 >> 5] >> (l1 & 31u);
-            if (img.lce_lcp) { // what the occurrences after the first share with their predecessors (entries k + 1 ..: five dwords hold the fifteen)
-                const uint32_t *lp = reinterpret_cast<const uint32_t *>(img.lce_lcp + (((uint32_t)k + 1u) & ~3u));
-                const u4_t v = *reinterpret_cast<const u4_t *>(lp);
-                d1.z = v.x; d1.w = v.y; d2.x = v.z; d2.y = v.w; d2.z = lp[4];
+            // (dword-aligned 16-byte pieces; nothing waits for them here: section C does)
+            if (PGX_LCE_ASM_LOADS)
+                asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:16\n\tglobal_load_dwordx4 %2, %3, off offset:32"
+                             : "+v"(row), "+v"(hs), "+v"(d0) : "v"(tp) : "memory");
+            else {
+                typedef pgx_u32x4 __attribute__((aligned(4))) u4a_t;
+                row = *reinterpret_cast<const u4a_t *>(tp); hs = *reinterpret_cast<const u4a_t *>(tp + 4); d0 = *reinterpret_cast<const u4a_t *>(tp + 8);
             }
+            const uint32_t l0 = w0 >> 5, l1 = (w0 + 11u) >> 5; // the lines of the window
+            const uint32_t *fp0 = img.lce_flags + (l0 >> 5), *fp1 = img.lce_flags + (l1 >> 5);
+            if (PGX_LCE_ASM_LOADS) asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "+v"(lce_f0), "+v"(lce_f1) : "v"(fp0), "v"(fp1) : "memory");
+            else { lce_f0 = *fp0; lce_f1 = *fp1; }
         }
         if (LCE) ln_blk += (unsigned long long)(__popcll(__ballot(lce_lane && ((lce_g0 >> 4) >> 5) != (((lce_g0 >> 4) + 11u) >> 5))) +  // a window over two lines
                                                 __popcll(__ballot(lce_lane && ((lce_st >> 8) & 0xFFu) == 0u)) +                     // the line of the interval's suffix array entries
@@ -1466,30 +1487,38 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             if (COOP) { // the line of this lane's probe is in LDS (fetched by the whole wave above)
                 const uint4 *mine = s_stage + (uint32_t)lane * 8u;
                 const uint32_t sw = (uint32_t)lane & 7u;
-                row = mine[t1 ^ sw]; hs = mine[4u ^ sw]; d0 = mine[5u ^ sw]; d1 = mine[6u ^ sw]; d2 = mine[7u ^ sw];
+                row = ld4(mine + (t1 ^ sw)); hs = ld4(mine + (4u ^ sw)); d0 = ld4(mine + (5u ^ sw)); d1 = ld4(mine + (6u ^ sw)); d2 = ld4(mine + (7u ^ sw));
             } else {
 #ifdef PGX_FM_STATS
                 const unsigned long long st_l0 = __builtin_readcyclecounter();
 #endif
                 const uint4 *bp = img.pairs + (size_t)(bfirst + pend) * 8;
-                row = bp[t1];                                                                  // pairs (t1, A C G T) before the block
-                hs = bp[4];                                                                    // positions before the block with c2 special and c1 = A, C, G, T; bit 31 of .x: flag
-                d0 = bp[5]; d1 = bp[6]; d2 = bp[7];                                            // planes: c1 bit 0, c1 bit 1, c2 bit 0, c2 bit 1, three dwords each
+                // row: pairs (t1, A C G T) before the block; hs: positions before the block with c2 special and c1 = A, C, G, T; bit 31 of .x: flag;
+                // d0 d1 d2: the planes: c1 bit 0, c1 bit 1, c2 bit 0, c2 bit 1, three dwords each
+                if (LCE && PGX_LCE_ASM_LOADS) { // (in place, and waited for by hand below: see the declaration of row)
+                    const uint4 *rp = bp + t1;
+                    asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\tglobal_load_dwordx4 %2, %4, off offset:80"
+                                 : "+v"(row), "+v"(hs), "+v"(d0) : "v"(rp), "v"(bp) : "memory");
+                    d1 = ld4(bp + 6); d2 = ld4(bp + 7); // (only this kind of lane uses these two)
+                } else {
+                    row = ld4(bp + t1); hs = ld4(bp + 4); d0 = ld4(bp + 5); d1 = ld4(bp + 6); d2 = ld4(bp + 7);
+                }
 #ifdef PGX_EXP_LOAD6 // sensitivity experiment (scripts/exp_dup.sh): a sixth piece of the same line, thrown away
                 { const uint4 xx = bp[(t1 + 1u) & 3u]; asm volatile("" ::"v"(xx.x), "v"(xx.y), "v"(xx.z), "v"(xx.w)); }
 #endif
                 __builtin_amdgcn_s_setprio(0);
 #ifdef PGX_FM_STATS
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(row.x), "+v"(hs.x), "+v"(d0.x), "+v"(d1.x), "+v"(d2.x) :: "memory");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(row), "+v"(hs), "+v"(d0), "+v"(d1), "+v"(d2) :: "memory");
                 st_t_line += __builtin_readcyclecounter() - st_l0;
 #endif
             }
-            const bool flagged = (hs.x >> 31) != 0u;
-            const uint32_t pts = (t1 == 0u ? hs.x : (t1 == 1u ? hs.y : (t1 == 2u ? hs.z : hs.w))) & 0x00FFFFFFu; // (24-bit counts: pgx_image.h)
             // masks that turn "code == t" / "code > t" into plane expressions: (x ^ i0) & (y ^ i1) and (y & ua) | (x & (y | va) & wa)
             const uint32_t i0 = (t1 & 1u) ? 0u : 0xFFFFFFFFu, i1 = (t1 & 2u) ? 0u : 0xFFFFFFFFu, j0 = (t2 & 1u) ? 0u : 0xFFFFFFFFu, j1 = (t2 & 2u) ? 0u : 0xFFFFFFFFu;
             const uint32_t ua = t1 < 2u ? 0xFFFFFFFFu : 0u, va = t1 == 0u ? 0xFFFFFFFFu : 0u, wa = (t1 & 1u) ? 0u : 0xFFFFFFFFu;
             const uint32_t ub = t2 < 2u ? 0xFFFFFFFFu : 0u, vb = t2 == 0u ? 0xFFFFFFFFu : 0u, wb = (t2 & 1u) ? 0u : 0xFFFFFFFFu;
+            if (LCE && !COOP && PGX_LCE_ASM_LOADS) asm volatile("s_waitcnt vmcnt(0)" : "+v"(row), "+v"(hs), "+v"(d0) :: "memory"); // (behind what does not need the line)
+            const bool flagged = (hs.x >> 31) != 0u;
+            const uint32_t pts = (t1 == 0u ? hs.x : (t1 == 1u ? hs.y : (t1 == 2u ? hs.z : hs.w))) & 0x00FFFFFFu; // (24-bit counts: pgx_image.h)
             const uint32_t PX[3] = {d0.x, d0.y, d0.z}, PY[3] = {d0.w, d1.x, d1.y}, PU[3] = {d1.z, d1.w, d2.x}, PV[3] = {d2.y, d2.z, d2.w};
             // counts below relA (absolute ranks need them) and in [relA, relB) (sizes and the other coordinate are differences)
             uint32_t e1p = 0, e2p = 0, e1r = 0, g1r = 0, e2r = 0, g2r = 0;
@@ -1654,12 +1683,22 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                         if (4u * t < need)
                             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(img.lce_sa + kb + 4u * t),
                                                              (void __attribute__((address_space(3))) *)(s_sa4 + ((threadIdx.x >> 6) * 5u + t) * 64u), 16, 0, 0);
+                    if (img.lce_lcp) {
+                        const uint32_t lb = ((uint32_t)k + 1u) & ~3u, needb = (((uint32_t)k + 1u) & 3u) + (uint32_t)s - 1u; // entries k + 1 .. k + s - 1
+#pragma unroll
+                        for (uint32_t t = 0; t < 5u; t++)
+                            if (4u * t < needb)
+                                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(img.lce_lcp + lb + 4u * t),
+                                                                 (void __attribute__((address_space(3))) *)(s_lcp + ((threadIdx.x >> 6) * 5u + t) * 64u), 4, 0, 0);
+                    }
                 }
             }
         }
+        if (LCE && PGX_LCE_ASM_LOADS) asm volatile("s_waitcnt vmcnt(0)" : "+v"(row), "+v"(hs), "+v"(d0), "+v"(lce_f0), "+v"(lce_f1) :: "memory"); // (the whole wave: the text of section A is in)
         if (LCE && lce_lane) { // the text behind occurrence i of the interval against the read from symbol j on
             const uint32_t T[12] = {row.x, row.y, row.z, row.w, hs.x, hs.y, hs.z, hs.w, d0.x, d0.y, d0.z, d0.w};
-            if ((d1.x | d1.y) & 1u) lce_st = 2u; // a line with an N / an endmarker / behind the text: this stage goes on stepwise (nothing has changed yet)
+            const uint32_t fl0 = lce_g0 >> 9, fl1 = ((lce_g0 >> 4) + 11u) >> 5; // the lines of the window (section A)
+            if (((lce_f0 >> (fl0 & 31u)) | (lce_f1 >> (fl1 & 31u))) & 1u) lce_st = 2u; // a line with an N / an endmarker / behind the text: this stage goes on stepwise (nothing has changed yet)
             else {
                 const uint32_t rem = (uint32_t)(len - j), q0 = (uint32_t)(base & 15ull) + (uint32_t)j;
                 const uint32_t tsh = 2u * (lce_g0 & 15u), rsh = 2u * (q0 & 15u), rw0 = q0 >> 4;
@@ -1685,12 +1724,16 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 uint32_t nxt = i + 1u;
                 if (img.lce_lcp && (uint32_t)(len - x) <= PGX_LCP_CAP - 1u) { // (m + what is left of the read stays below the cap: a capped entry is "longer than anything asked")
                     const uint32_t m = (uint32_t)(j - x), bsh = ((uint32_t)k + 1u) & 3u;
-                    const uint32_t W[4] = {__builtin_amdgcn_alignbyte(d1.w, d1.z, bsh), __builtin_amdgcn_alignbyte(d2.x, d1.w, bsh), __builtin_amdgcn_alignbyte(d2.y, d2.x, bsh),
-                                           __builtin_amdgcn_alignbyte(d2.z, d2.y, bsh)};
+                    uint32_t L5[5];
+#pragma unroll
+                    for (uint32_t t = 0; t < 5u; t++) L5[t] = s_lcp[((threadIdx.x >> 6) * 5u + t) * 64u + (uint32_t)lane];
+                    const uint32_t W[4] = {__builtin_amdgcn_alignbyte(L5[1], L5[0], bsh), __builtin_amdgcn_alignbyte(L5[2], L5[1], bsh), __builtin_amdgcn_alignbyte(L5[3], L5[2], bsh),
+                                           __builtin_amdgcn_alignbyte(L5[4], L5[3], bsh)};
                     uint32_t cur = l;
                     bool stop = false;
 #pragma unroll
                     for (uint32_t t = 1; t < PGX_LCE_MAX_OCC; t++) {
+                        if (((t - 1u) & 3u) == 0u && t > 1u && !__any(!stop && t < (uint32_t)s)) break; // (four at a time: intervals are mostly narrower than sixteen)
                         const uint32_t c = (W[(t - 1u) >> 2] >> (8u * ((t - 1u) & 3u))) & 0xFFu, rel = c - m;
                         const bool act = !stop && t > i && t < (uint32_t)s;
                         const bool hard = c == PGX_LCP_UNKNOWN || c < m || (rel == cur && cur < rem);
@@ -1726,7 +1769,9 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                     const uint32_t q = (uint32_t)(base & 15ull) + (uint32_t)((endw ? len - 1 : j) - K + 1);
                     const uint32_t w0 = s_rd[(q >> 4) * rd_stride + threadIdx.x], w1 = s_rd[((q >> 4) + 1u) * rd_stride + threadIdx.x]; // (one word of padding per thread)
                     const uint32_t sidx = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (2u * (q & 15u))) & (uint32_t)((1ull << (2 * K)) - 1ull); // (K = 16: all 32 bits)
-                    se_pre = (endw ? img.seed_end : img.seed)[sidx];
+                    const uint4 *sp = (endw ? img.seed_end : img.seed) + sidx;
+                    if (PGX_SEED_VIA_LDS) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)sp, (void __attribute__((address_space(3))) *)(s_sa4 + (threadIdx.x >> 6) * 5u * 64u), 16, 0, 0);
+                    else se_reg = *sp;
                     kuse = (uint32_t)K + (endw ? 1u : 0u);
                     asked = true;
                 }

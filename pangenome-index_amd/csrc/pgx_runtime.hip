@@ -1621,7 +1621,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                         if (img.lce_sa && !coop && !img.wide && min_occ <= 1 && !(le && le[0] == '0')) {
                             kp = s64 ? (const void *)pgx_find_mems_pairs_kernel<true, false, true, false, true, true> : (const void *)pgx_find_mems_pairs_kernel<true, false, true, false, false, true>;
                             b->timing.pairs_reads = 4u;
-                            lce_lds = (size_t)5 * PGX_FM_THREADS * 16; // the suffix array entries of every thread's interval: five 16-byte pieces each
+                            lce_lds = (size_t)5 * PGX_FM_THREADS * (16 + 4); // the suffix array entries of every thread's interval (five 16-byte pieces each) and their common prefixes (five dwords)
                         }
                         a_packed = b->packed.as<uint32_t>();
                         a_pkw = pkw;
