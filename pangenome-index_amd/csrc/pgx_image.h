@@ -105,7 +105,12 @@
  *   lce_text      the collection itself, two bits per symbol, 16 symbols per u32, A C T G = 0 1 2 3 (the order of the packed reads: XOR compares
  *                 16 symbols at once); every sequence followed by its endmarker; N and endmarkers read as 0 and are covered by
  *   lce_flags     one bit per 128-byte line of lce_text (512 symbols): the line holds an N, an endmarker, or lies behind the text
- * 4.25 n bytes (chr22 scale: 2.7 GB).  The forward stage of find_mems_function (algorithm.hpp:676-700: forward_extend until the interval is "small") over
+ *   lce_lcp[i]    u8: the number of symbols suffix i has in common with suffix i - 1 (pgx_lce_lcp_kernel, from lce_text), 254 = "254 or more", 255 = not
+ *                 known (the comparison touched a flagged line).  After ONE occurrence t - 1 of an interval has been compared with the text (match l), the
+ *                 next one matches min(l, lcp[k + t] - symbols matched before the stage) -- unless the two are equal and the read goes on, where occurrence
+ *                 t may match further and is compared itself: a forward stage is ~1.7 comparisons instead of one per occurrence (tests/test_lce_math.py).
+ *                 Used while (read length - MEM start) <= 253, so that a capped entry is longer than anything asked; PGX_FM_LCP=0: not built.
+ * 5.25 n bytes (chr22 scale: 3.4 GB).  The forward stage of find_mems_function (algorithm.hpp:676-700: forward_extend until the interval is "small") over
  * an interval of s <= 16 occurrences is finished by comparing the read with the text at SA[k] .. SA[k + s - 1] -- the occurrences that match longest are
  * consecutive and ARE the interval the extensions would end with -- in s trips of ~1.3 lines instead of (match length) / 2 trips of one line.  The text
  * is recovered from the index alone: the first symbol of suffix i is the symbol whose C-bucket holds i. */

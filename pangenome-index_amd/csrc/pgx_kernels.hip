@@ -1164,6 +1164,9 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     //  registers, the compiler loaded it into others than the ones it lives in across the loop's back edge and copied it over there, behind a wait for the
     //  load, which put the entry's latency back into every trip)
     typedef uint32_t pgx_u32x4 __attribute__((ext_vector_type(4)));
+#ifndef PGX_LCE_ENTRY_CAP
+#define PGX_LCE_ENTRY_CAP 3u // with the common-prefix table a stage through the text is ~2 trips however wide the interval: worth it from 2 x 3 symbols to go
+#endif
 #ifndef PGX_SEED_VIA_LDS
 #define PGX_SEED_VIA_LDS 1 // (0: the entry in registers, loaded by the compiler -- scripts/r4_exp10.sh)
 #endif
@@ -1673,7 +1676,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 // a forward stage over a narrow interval goes on through the text: from the next trip on one occurrence per trip (its first suffix array entry
                 // is asked for now); only where that is fewer trips than two symbols per trip, and where the window of three pieces holds what is left
                 if (LCE && img.lce_sa && ph == 2 && !em && !restart && !(lce_st & 2u) && s >= 1u && (uint32_t)s <= img.lce_max && mo <= 1u && j < len &&
-                    (uint32_t)(len - j) >= 2u * (uint32_t)s && (uint32_t)(len - j) <= 144u) {
+                    (uint32_t)(len - j) >= 2u * (img.lce_lcp && (uint32_t)s > PGX_LCE_ENTRY_CAP ? PGX_LCE_ENTRY_CAP : (uint32_t)s) && (uint32_t)(len - j) <= 144u) {
                     lce_st = 1u;
                     lce_best = 0u;
                     // SA[k .. k + s) into LDS: piece t = the four entries from (k & ~3) + 4 t on, while it holds one of them (16 entries: five pieces at most)
