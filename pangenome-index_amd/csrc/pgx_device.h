@@ -44,7 +44,7 @@ __global__ void pgx_arena_demand_kernel(unsigned long long *ctr);
 
 #define PGX_DENSE_LDS_U4 5 // uint4 slots per dense block in LDS (64 data bytes + 16 of padding)
 #define PGX_FM_THREADS 256
-#define PGX_LCE_MAX_OCC 16u // widest interval whose forward stage goes through the text (its suffix array entries sit in an LDS column per thread)
+#define PGX_LCE_MAX_OCC 128u // widest interval whose forward stage goes through the text (occurrence indexes and counts are bytes of the lane's state word)
 #define PGX_FM_WAVES_PER_SIMD 4 // __launch_bounds__ 2nd argument: caps the kernel at 128 VGPRs
 
 // passed by value to every kernel (all pointers are device pointers)

@@ -1114,14 +1114,13 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     uint4 *s_stage = reinterpret_cast<uint4 *>(pgx_dyn_lds + (size_t)pk_words * PGX_FM_THREADS * 4) + (size_t)(threadIdx.x >> 6) * 512;
     // WIDE: behind those, per superblock the sixteen pair-count bases and their four row sums (24 words each, img.n_sbp superblocks)
     uint64_t *s_pb = reinterpret_cast<uint64_t *>(pgx_dyn_lds + (size_t)pk_words * PGX_FM_THREADS * 4 + (COOP ? (size_t)(PGX_FM_THREADS / 64) * 8192 : 0));
-    // LCE (never with COOP / WIDE): behind the packed reads, the suffix array entries of a lane's interval, fetched ONCE when the lane enters the text path,
-    // straight into LDS (global_load_lds_dwordx4: no registers in between, nothing to wait for in that trip) -- re-read from memory every trip the line of those
-    // entries did not stay in L2 between two trips of the lane: a fifth of the kernel's memory-side traffic by the counters.  Five 16-byte pieces per lane (the
-    // aligned window from k & ~3 on holds k .. k + 15 in at most five), piece t of lane l of wave w at s_sa4[(5 w + t) * 64 + l]
+    // LCE (never with COOP / WIDE): behind the packed reads, what a lane has asked for at the end of a trip and uses in the next, fetched straight into LDS
+    // (global_load_lds: no registers in between, nothing the compiler could copy too early): one 16-byte slot per lane -- the seed entry of a stage that starts --,
+    // one dword -- the suffix array entry of the occurrence it compares with the text next --, five dwords -- sixteen entries of img.lce_lcp from any byte on
+    // (dword t of lane l of wave w at s_lcp[(5 w + t) * 64 + l])
     uint4 *s_sa4 = reinterpret_cast<uint4 *>(pgx_dyn_lds + (size_t)pk_words * PGX_FM_THREADS * 4);
-    // ... and behind those what the entries after the first share with their predecessors (img.lce_lcp: one byte each), the same way: the five dwords from
-    // (k + 1) & ~3 on hold the fifteen, dword t of lane l of wave w at s_lcp[(5 w + t) * 64 + l]
-    uint32_t *s_lcp = reinterpret_cast<uint32_t *>(s_sa4 + 5u * PGX_FM_THREADS);
+    uint32_t *s_sae = reinterpret_cast<uint32_t *>(s_sa4 + PGX_FM_THREADS);
+    uint32_t *s_lcp = s_sae + PGX_FM_THREADS;
     for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) s_ext[i] = img.consts->ext_tab[i];
     if (threadIdx.x < 8) s_C[threadIdx.x] = (pos_t)img.consts->C[threadIdx.x];
     if (threadIdx.x < 32) s_t2[threadIdx.x] = (pos_t)img.consts->pair_t2w[threadIdx.x];
@@ -1153,8 +1152,9 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
     bool exhausted = false;
     unsigned long long ln_blk = 0, ln_seed = 0, ln_two = 0; // wave-uniform (scalar registers): block lines / seed entries the wave asked for, trips with two extensions (PGX_CTR_PAIRS_*)
     uint32_t did2 = 0; // this lane's last trip performed two extensions (summed at the top of the next trip, where the wave is converged)
-    // LCE: bit 0 = the lane compares with the text (ph == 2), bit 1 = this stage must not (a flagged text line), bits 8..15 occurrence index, 16..23 index of
-    // the first occurrence with the longest match, 24..31 how many reach it; the longest match; the text position of the occurrence of the next trip
+    // LCE: bit 0 = the lane's stage goes through the text (ph == 2), bit 1 = this stage must not (a flagged text line), bit 2 = this trip only reads on in the
+    // table of common prefixes (no occurrence is compared), bits 8..15 the occurrence / entry the trip starts with, 16..23 index of the first occurrence with
+    // the longest match, 24..31 how many reach it; the longest match; the text position of the occurrence compared
     uint32_t lce_st = 0, lce_best = 0, lce_pos = 0;
     // FUSE: a stage's first trip (no line of the image: the seed / first_ext entry, then the transitions) is not a trip of its own.  The entry is asked for
     // at the END of the trip in which the stage starts (`fresh` 1 -> 2 | extensions the entry stands for << 8, the entry into se_pre) and applied at the top
@@ -1201,6 +1201,19 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         if (LCE) lce_st = 0u;
         if (min_len == 0) { Jk = 0; Js = n; j = x; ph = 2; }
         else { j = x + (int32_t)min_len - 1; ph = 1; fresh = 1u; }
+    };
+    // a lane on the text path asks for what its next trip reads: the suffix array entry of occurrence t (when it compares that one) and sixteen entries of the table
+    // of common prefixes -- those of the occurrences behind t, or from entry t on
+    auto lce_ask = [&](uint32_t k32, uint32_t t, bool cmp) __attribute__((always_inline)) {
+        if (cmp) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(img.lce_sa + k32 + t), (void __attribute__((address_space(3))) *)(s_sae + (threadIdx.x >> 6) * 64u), 4, 0, 0);
+        if (img.lce_lcp) {
+            const uint32_t e0 = k32 + t + (cmp ? 1u : 0u), lb = e0 & ~3u;
+#pragma unroll
+            for (uint32_t q = 0; q < 5u; q++)
+                if (q < 4u || (e0 & 3u) != 0u) // (sixteen bytes from e0 on: four dwords, five when e0 is not aligned)
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(img.lce_lcp + lb + 4u * q),
+                                                     (void __attribute__((address_space(3))) *)(s_lcp + ((threadIdx.x >> 6) * 5u + q) * 64u), 4, 0, 0);
+        }
     };
     auto emit = [&]() __attribute__((always_inline)) {
         pgx_mem m;
@@ -1324,7 +1337,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         uint32_t lce_g0 = 0u;
         bool em_now = false; // this trip ends with a MEM (set by either kind of lane); `restart`: with the next start position of the read
         restart = 0u;
-        if (LCE && __any(lce_lane && ((lce_st >> 8) & 0xFFu) == 0u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the entries asked for at the end of the last trip are in LDS)
+        if (LCE && __any(lce_lane)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (what the lanes on the text path asked for at the end of the last trip is in LDS)
 #ifdef PGX_FM_STATS
         if (FUSE && __any(ph > 0 && fresh >= 2u)) {
             const unsigned long long st_s0 = __builtin_readcyclecounter();
@@ -1335,7 +1348,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         if (FUSE && PGX_SEED_VIA_LDS && __any(ph > 0 && fresh >= 0x100u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the entries asked for at the end of the last trip are in LDS)
         if (FUSE && ph > 0 && fresh >= 2u) { // the first extension(s) of a stage that started in the last trip: what the stage's first trip does in the other variants
             const uint32_t kuse = fresh >> 8; // extensions the seed entry stands for (0: none was asked for)
-            const uint4 se_pre = PGX_SEED_VIA_LDS ? s_sa4[(threadIdx.x >> 6) * 5u * 64u + (uint32_t)lane] : se_reg;
+            const uint4 se_pre = PGX_SEED_VIA_LDS ? s_sa4[threadIdx.x] : se_reg;
             fresh = 0u;
             const bool at_end = j >= len, q1 = ph == 1;
             const uint32_t qa = (uint32_t)(base & 15ull) + (uint32_t)(at_end ? len : j);
@@ -1380,11 +1393,9 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         }
         const bool sit_out = FUSE && (fresh != 0u || em_now || restart != 0u); // no line of the image for this lane in this trip
         if (FUSE) ln_blk += (unsigned long long)__popcll(__ballot(ph > 0 && !sit_out));
-        if (LCE && lce_lane) {
-            {
-                const uint32_t e = ((uint32_t)k & 3u) + ((lce_st >> 8) & 0xFFu); // entry i of the interval inside the aligned window
-                lce_pos = reinterpret_cast<const uint32_t *>(s_sa4 + ((threadIdx.x >> 6) * 5u + (e >> 2)) * 64u + (uint32_t)lane)[e & 3u];
-            }
+        const bool lce_cmp = lce_lane && (lce_st & 4u) == 0u; // this trip compares an occurrence with the text
+        if (LCE && lce_cmp) {
+            lce_pos = s_sae[threadIdx.x];
             lce_g0 = lce_pos + (uint32_t)(j - x);           // text position that faces read symbol j
             const uint32_t w0 = lce_g0 >> 4;                // its word (16 symbols); the window: words w0 .. w0 + 11
             const uint32_t *tp = img.lce_text + w0;
@@ -1401,9 +1412,10 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             if (PGX_LCE_ASM_LOADS) asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "+v"(lce_f0), "+v"(lce_f1) : "v"(fp0), "v"(fp1) : "memory");
             else { lce_f0 = *fp0; lce_f1 = *fp1; }
         }
-        if (LCE) ln_blk += (unsigned long long)(__popcll(__ballot(lce_lane && ((lce_g0 >> 4) >> 5) != (((lce_g0 >> 4) + 11u) >> 5))) +  // a window over two lines
-                                                __popcll(__ballot(lce_lane && ((lce_st >> 8) & 0xFFu) == 0u)) +                     // the line of the interval's suffix array entries
-                                                (img.lce_lcp ? __popcll(__ballot(lce_lane && ((lce_st >> 8) & 0xFFu) == 0u && s > 1u)) : 0)); // ... and of their common prefixes
+        if (LCE) ln_blk += (unsigned long long)(__popcll(__ballot(lce_cmp && ((lce_g0 >> 4) >> 5) != (((lce_g0 >> 4) + 11u) >> 5))) + // a window over two lines
+                                                __popcll(__ballot(lce_cmp)) +                                                    // the line of the suffix array entry
+                                                (img.lce_lcp ? __popcll(__ballot(lce_lane && s > 1u)) : 0)) -                      // ... and of the common prefixes
+                             (unsigned long long)__popcll(__ballot(lce_lane && !lce_cmp));                                        // (no text line in such a trip: counted above as one)
         if (ph > 0 && !lce_lane && !sit_out) {
             const bool fr = !FUSE && fresh != 0u; // first extension of a backward stage: from first_ext / the seed table
             bool seed_lane = false;
@@ -1676,34 +1688,24 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                 // a forward stage over a narrow interval goes on through the text: from the next trip on one occurrence per trip (its first suffix array entry
                 // is asked for now); only where that is fewer trips than two symbols per trip, and where the window of three pieces holds what is left
                 if (LCE && img.lce_sa && ph == 2 && !em && !restart && !(lce_st & 2u) && s >= 1u && (uint32_t)s <= img.lce_max && mo <= 1u && j < len &&
-                    (uint32_t)(len - j) >= 2u * (img.lce_lcp && (uint32_t)s > PGX_LCE_ENTRY_CAP ? PGX_LCE_ENTRY_CAP : (uint32_t)s) && (uint32_t)(len - j) <= 144u) {
+                    (uint32_t)(len - j) >= 2u * (img.lce_lcp && (uint32_t)s > PGX_LCE_ENTRY_CAP ? PGX_LCE_ENTRY_CAP : (uint32_t)s) && (uint32_t)(len - j) <= 144u &&
+                    ((uint32_t)s <= 16u || (img.lce_lcp && (uint32_t)(len - x) <= PGX_LCP_CAP - 1u))) { // (wider than sixteen only where the table of common prefixes can be used)
                     lce_st = 1u;
                     lce_best = 0u;
-                    // SA[k .. k + s) into LDS: piece t = the four entries from (k & ~3) + 4 t on, while it holds one of them (16 entries: five pieces at most)
-                    const uint32_t kb = (uint32_t)k & ~3u, need = ((uint32_t)k & 3u) + (uint32_t)s;
-#pragma unroll
-                    for (uint32_t t = 0; t < 5u; t++)
-                        if (4u * t < need)
-                            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(img.lce_sa + kb + 4u * t),
-                                                             (void __attribute__((address_space(3))) *)(s_sa4 + ((threadIdx.x >> 6) * 5u + t) * 64u), 16, 0, 0);
-                    if (img.lce_lcp) {
-                        const uint32_t lb = ((uint32_t)k + 1u) & ~3u, needb = (((uint32_t)k + 1u) & 3u) + (uint32_t)s - 1u; // entries k + 1 .. k + s - 1
-#pragma unroll
-                        for (uint32_t t = 0; t < 5u; t++)
-                            if (4u * t < needb)
-                                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(img.lce_lcp + lb + 4u * t),
-                                                                 (void __attribute__((address_space(3))) *)(s_lcp + ((threadIdx.x >> 6) * 5u + t) * 64u), 4, 0, 0);
-                    }
+                    lce_ask((uint32_t)k, 0u, true); // SA[k] and the common prefixes of the sixteen entries behind it
                 }
             }
         }
         if (LCE && PGX_LCE_ASM_LOADS) asm volatile("s_waitcnt vmcnt(0)" : "+v"(row), "+v"(hs), "+v"(d0), "+v"(lce_f0), "+v"(lce_f1) :: "memory"); // (the whole wave: the text of section A is in)
-        if (LCE && lce_lane) { // the text behind occurrence i of the interval against the read from symbol j on
-            const uint32_t T[12] = {row.x, row.y, row.z, row.w, hs.x, hs.y, hs.z, hs.w, d0.x, d0.y, d0.z, d0.w};
-            const uint32_t fl0 = lce_g0 >> 9, fl1 = ((lce_g0 >> 4) + 11u) >> 5; // the lines of the window (section A)
-            if (((lce_f0 >> (fl0 & 31u)) | (lce_f1 >> (fl1 & 31u))) & 1u) lce_st = 2u; // a line with an N / an endmarker / behind the text: this stage goes on stepwise (nothing has changed yet)
-            else {
-                const uint32_t rem = (uint32_t)(len - j), q0 = (uint32_t)(base & 15ull) + (uint32_t)j;
+        if (LCE && lce_lane) { // the text behind occurrence i of the interval against the read from symbol j on, then sixteen entries of the table
+            const uint32_t rem = (uint32_t)(len - j), i = (lce_st >> 8) & 0xFFu;
+            uint32_t a = (lce_st >> 16) & 0xFFu, cnt = lce_st >> 24, t0 = i;
+            bool fin = false, banned = false;
+            if (lce_cmp) {
+                const uint32_t T[12] = {row.x, row.y, row.z, row.w, hs.x, hs.y, hs.z, hs.w, d0.x, d0.y, d0.z, d0.w};
+                const uint32_t fl0 = lce_g0 >> 9, fl1 = ((lce_g0 >> 4) + 11u) >> 5; // the lines of the window (section A)
+                banned = (((lce_f0 >> (fl0 & 31u)) | (lce_f1 >> (fl1 & 31u))) & 1u) != 0u; // a line with an N / an endmarker / behind the text: this stage goes on stepwise (nothing has changed yet)
+                const uint32_t q0 = (uint32_t)(base & 15ull) + (uint32_t)j;
                 const uint32_t tsh = 2u * (lce_g0 & 15u), rsh = 2u * (q0 & 15u), rw0 = q0 >> 4;
                 uint32_t R[10];
 #pragma unroll
@@ -1715,41 +1717,48 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                     l = df ? 16u * (uint32_t)u + ((uint32_t)__builtin_ctz(df) >> 1) : l;
                 }
                 l = l < rem ? l : rem;
-                const uint32_t i = (lce_st >> 8) & 0xFFu;
-                uint32_t a = (lce_st >> 16) & 0xFFu, cnt = lce_st >> 24;
+                // (the matches of one pattern with suffixes in sorted order rise, stay, fall and never rise again: one below the best ends the stage)
                 const bool better = i == 0u || l > lce_best;
+                fin = !better && l < lce_best;
                 cnt = better ? 1u : (l == lce_best ? cnt + 1u : cnt);
                 a = better ? i : a;
                 lce_best = better ? l : lce_best;
-                // The occurrences behind this one, from the common prefixes of neighbouring suffixes: with c symbols shared between occurrence t - 1 and t and a match of
-                // `cur` with t - 1, the match with t is min(cur, c - m) (m = the symbols matched before the stage) -- unless both are the same length, where t may match
-                // further: that occurrence (or one whose entry is unknown) is compared with the text itself, in the next trip.  A typical stage is ONE trip this way.
-                uint32_t nxt = i + 1u;
-                if (img.lce_lcp && (uint32_t)(len - x) <= PGX_LCP_CAP - 1u) { // (m + what is left of the read stays below the cap: a capped entry is "longer than anything asked")
-                    const uint32_t m = (uint32_t)(j - x), bsh = ((uint32_t)k + 1u) & 3u;
+                t0 = i + 1u;
+            }
+            if (banned) lce_st = 2u;
+            else {
+                // The occurrences behind, from the common prefixes of neighbouring suffixes: with c symbols shared between occurrence t - 1 and t, occurrence t matches
+                // min(match of t - 1, c - m) symbols (m = the symbols matched before the stage).  Here the match of t - 1 is the best one (anything shorter has ended the
+                // stage): an entry above it (or at it, once the read is used up) is one more occurrence of the final interval; one below it ends the stage; one AT it --
+                // occurrence t may match further -- or an unknown one is compared with the text itself in the next trip.  Sixteen entries per trip.
+                uint32_t tt = t0; // the entry the next trip starts with
+                bool cmp_next = true;
+                if (!fin && tt < (uint32_t)s && img.lce_lcp && (uint32_t)(len - x) <= PGX_LCP_CAP - 1u) { // (m + what is left of the read stays below the cap: a capped entry is "longer than anything asked")
+                    const uint32_t m = (uint32_t)(j - x), bsh = ((uint32_t)k + t0) & 3u;
                     uint32_t L5[5];
 #pragma unroll
                     for (uint32_t t = 0; t < 5u; t++) L5[t] = s_lcp[((threadIdx.x >> 6) * 5u + t) * 64u + (uint32_t)lane];
                     const uint32_t W[4] = {__builtin_amdgcn_alignbyte(L5[1], L5[0], bsh), __builtin_amdgcn_alignbyte(L5[2], L5[1], bsh), __builtin_amdgcn_alignbyte(L5[3], L5[2], bsh),
                                            __builtin_amdgcn_alignbyte(L5[4], L5[3], bsh)};
-                    uint32_t cur = l;
                     bool stop = false;
+                    cmp_next = false;
 #pragma unroll
-                    for (uint32_t t = 1; t < PGX_LCE_MAX_OCC; t++) {
-                        if (((t - 1u) & 3u) == 0u && t > 1u && !__any(!stop && t < (uint32_t)s)) break; // (four at a time: intervals are mostly narrower than sixteen)
-                        const uint32_t c = (W[(t - 1u) >> 2] >> (8u * ((t - 1u) & 3u))) & 0xFFu, rel = c - m;
-                        const bool act = !stop && t > i && t < (uint32_t)s;
-                        const bool hard = c == PGX_LCP_UNKNOWN || c < m || (rel == cur && cur < rem);
-                        stop = stop || (act && hard);
-                        if (act && !hard) {
-                            cur = rel < cur ? rel : cur;
-                            cnt += cur == lce_best ? 1u : 0u;
-                            nxt = t + 1u;
-                        }
+                    for (uint32_t u = 0; u < 16u; u++) {
+                        if ((u & 3u) == 0u && u > 0u && !__any(!stop && t0 + u < (uint32_t)s)) break; // (four at a time)
+                        const uint32_t c = (W[u >> 2] >> (8u * (u & 3u))) & 0xFFu, rel = c - m;
+                        const bool act = !stop && t0 + u < (uint32_t)s;
+                        const bool hard = c == PGX_LCP_UNKNOWN || c < m || (rel == lce_best && lce_best < rem);
+                        const bool drop = !hard && rel < lce_best;
+                        cmp_next = cmp_next || (act && hard);
+                        fin = fin || (act && drop);
+                        stop = stop || (act && (hard || drop));
+                        if (act && !hard && !drop) { cnt++; tt = t0 + u + 1u; }
                     }
                 }
-                if (nxt < (uint32_t)s) lce_st = 1u | (nxt << 8) | (a << 16) | (cnt << 24);
-                else { // every occurrence seen: the MEM ends where the longest match ends; the occurrences that reach it are its interval
+                if (!fin && tt < (uint32_t)s) { // on with occurrence / entry tt
+                    lce_st = 1u | (cmp_next ? 0u : 4u) | (tt << 8) | (a << 16) | (cnt << 24);
+                    lce_ask((uint32_t)k, tt, cmp_next);
+                } else { // the MEM ends where the longest match ends; the occurrences that reach it are its interval
                     Jk = k + (pos_t)a; Js = (pos_t)cnt;
                     next += lce_best + (lce_best < rem ? 1u : 0u); // (the extension that fails counts, as in the stepwise stage)
                     j += (int32_t)lce_best;
@@ -1773,7 +1782,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
                     const uint32_t w0 = s_rd[(q >> 4) * rd_stride + threadIdx.x], w1 = s_rd[((q >> 4) + 1u) * rd_stride + threadIdx.x]; // (one word of padding per thread)
                     const uint32_t sidx = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (2u * (q & 15u))) & (uint32_t)((1ull << (2 * K)) - 1ull); // (K = 16: all 32 bits)
                     const uint4 *sp = (endw ? img.seed_end : img.seed) + sidx;
-                    if (PGX_SEED_VIA_LDS) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)sp, (void __attribute__((address_space(3))) *)(s_sa4 + (threadIdx.x >> 6) * 5u * 64u), 16, 0, 0);
+                    if (PGX_SEED_VIA_LDS) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)sp, (void __attribute__((address_space(3))) *)(s_sa4 + (threadIdx.x >> 6) * 64u), 16, 0, 0);
                     else se_reg = *sp;
                     kuse = (uint32_t)K + (endw ? 1u : 0u);
                     asked = true;

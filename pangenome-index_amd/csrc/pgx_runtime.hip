@@ -1282,7 +1282,7 @@ static void ensure_lce(pgx_index *h, pgx_device_image *d) {
         d->img.lce_sa = d->lce_sa.as<uint32_t>();
         d->img.lce_text = d->lce_text.as<uint32_t>();
         d->img.lce_flags = d->lce_flags.as<uint32_t>();
-        d->img.lce_max = 16;
+        d->img.lce_max = with_lcp ? PGX_LCE_MAX_OCC : 16; // (without the table of common prefixes every occurrence costs a trip)
         if (const char *e = std::getenv("PGX_FM_LCE_MAX")) d->img.lce_max = (uint32_t)std::min<unsigned long>(std::strtoul(e, nullptr, 10), (unsigned long)PGX_LCE_MAX_OCC);
         d->img.refill_min = 12; // (chr22 scale, 1 / 3 / 6 / 10 / 16 / 24: main kernel 10.76 / 10.44 / 10.24 / 10.15 / 10.10 / 10.08 ms, step 13.16 / 12.87 / 12.62 / 12.59 / 12.56 / 12.65)
         if (const char *e = std::getenv("PGX_FM_REFILL_MIN")) d->img.refill_min = (uint32_t)std::max<unsigned long>(1ul, std::min<unsigned long>(std::strtoul(e, nullptr, 10), 64ul));
@@ -1621,7 +1621,7 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                         if (img.lce_sa && !coop && !img.wide && min_occ <= 1 && !(le && le[0] == '0')) {
                             kp = s64 ? (const void *)pgx_find_mems_pairs_kernel<true, false, true, false, true, true> : (const void *)pgx_find_mems_pairs_kernel<true, false, true, false, false, true>;
                             b->timing.pairs_reads = 4u;
-                            lce_lds = (size_t)5 * PGX_FM_THREADS * (16 + 4); // the suffix array entries of every thread's interval (five 16-byte pieces each) and their common prefixes (five dwords)
+                            lce_lds = (size_t)PGX_FM_THREADS * (16 + 4 + 20); // per thread: a seed entry, a suffix array entry, sixteen common prefixes from any byte on (five dwords)
                         }
                         a_packed = b->packed.as<uint32_t>();
                         a_pkw = pkw;

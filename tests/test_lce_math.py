@@ -7,6 +7,7 @@ Also: the text can be recovered from the index alone -- the first symbol of suff
 import os
 
 import numpy as np
+import pytest
 
 import oracle_ffi as O
 import pgx_workload as W
@@ -85,13 +86,16 @@ def _lcp_table(T, gpos, cap=254, unknown=255):
     return np.concatenate([[0], out])
 
 
-def test_occurrences_after_the_first_follow_from_the_common_prefixes(workdir):
-    """the chain of pgx_find_mems_pairs_kernel<.., LCE> with img.lce_lcp: after a comparison of occurrence i with the text (match l), occurrence t > i matches
-    min(previous match, lcp[k + t] - m) symbols -- m the symbols matched before the stage -- as long as the two differ (or the read has ended); where they are
-    equal, or the entry is unknown, occurrence t is compared with the text itself.  Same MEMs as the oracle, and far fewer comparisons than occurrences."""
-    text = os.path.join(workdir, "lce_math.txt")
-    W.synth_pangenome_text(text, base_len=30_000, n_hap=5, seed=3, n_runs=3, n_run_len=(30, 300))
-    ri_path = W.build_index_from_text(text, workdir, "lce_math", with_tags=False)[0]
+@pytest.mark.parametrize("haps", [5, 40])
+def test_occurrences_after_the_first_follow_from_the_common_prefixes(workdir, haps):
+    """the text path of pgx_find_mems_pairs_kernel<.., LCE> with img.lce_lcp, trip by trip: a COMPARE trip matches occurrence i with the text (l); a shorter match
+    than the best so far ends the stage (the matches of sorted suffixes with one pattern rise, stay, fall -- never rise again); then, and in CHAIN trips, up to 16
+    entries of the table: occurrence t matches min(previous, lcp[k + t] - m) -- m the symbols matched before the stage --, so an entry above the best adds one to the
+    count, one below it ends the stage, one EQUAL to it (while the read goes on) or unknown asks for a COMPARE trip of occurrence t.  Same MEMs as the oracle,
+    for intervals of up to 128 occurrences, in far fewer trips than occurrences."""
+    text = os.path.join(workdir, "lce_math_%d.txt" % haps)
+    W.synth_pangenome_text(text, base_len=800_000 // haps, n_hap=haps, seed=3 + haps, n_runs=3, n_run_len=(30, 300))
+    ri_path = W.build_index_from_text(text, workdir, "lce_math_%d" % haps, with_tags=False)[0]
     ri = O.RIndex(ri_path)
     seqs = W.load_sequences(text)
     ml = ri.max_length
@@ -100,10 +104,10 @@ def test_occurrences_after_the_first_follow_from_the_common_prefixes(workdir):
     T = np.concatenate([np.concatenate([s, [10]]) for s in seqs]).astype(np.uint8)
     gpos = seq_start[(sa // ml).astype(np.int64)] + (sa % ml).astype(np.int64)
     lcp = _lcp_table(T, gpos)
-    assert (lcp == 255).sum() < len(lcp) // 4  # (only near the N runs and the sequence ends)
+    assert (lcp == 255).sum() < len(lcp) // 2  # (only near the N runs and the sequence ends)
     cat, offs = W.sample_reads(seqs, 1500, 150, seed=8, n_frac=0.05)
     rng = np.random.default_rng(1)
-    checked = compares = occurrences = 0
+    checked = trips = occurrences = widest = 0
     for r in range(1500):
         rd = bytes(cat[offs[r]:offs[r + 1]])
         if r % 5 == 0:
@@ -116,36 +120,50 @@ def test_occurrences_after_the_first_follow_from_the_common_prefixes(workdir):
                 if mem is None or any(ch not in b"ACGT" for ch in rd[x:]):
                     continue
                 k, _, s = ri.bwd_pattern(rd[x:x + min_len])
-                if s > 16:
+                if s > 128:
                     continue
                 j, m = x + min_len, min_len
                 rem = len(rd) - j
-                best, first, cnt, i = -1, 0, 0, 0
-                while True:
-                    compares += 1
-                    p = int(gpos[k + i]) + m
-                    l = 0
-                    while l < rem and T[p + l] == rd[j + l]:
-                        l += 1
-                    if i == 0 or l > best:
-                        best, first, cnt = l, i, 1
-                    elif l == best:
+                best, first, cnt, i, compare = -1, 0, 0, 0, True
+                while True:  # one trip
+                    trips += 1
+                    done = False
+                    if compare:
+                        p = int(gpos[k + i]) + m
+                        l = 0
+                        while l < rem and T[p + l] == rd[j + l]:
+                            l += 1
+                        if i == 0 or l > best:
+                            best, first, cnt = l, i, 1
+                        elif l == best:
+                            cnt += 1
+                        else:
+                            break  # shorter than the best: so is everything behind it
+                        t = i + 1
+                    else:
+                        t = i
+                    t0, compare = t, True
+                    while t < s and t < t0 + 16:
+                        c = int(lcp[k + t])
+                        if c == 255 or c < m or (c - m == best and best < rem):
+                            break  # occurrence t is compared itself
+                        if c - m < best:
+                            done = True
+                            break
                         cnt += 1
-                    nxt, cur = i + 1, l
-                    if len(rd) - x <= 253:
-                        for t in range(i + 1, s):
-                            c = int(lcp[k + t])
-                            if c == 255 or c < m or (c - m == cur and cur < rem):
-                                break
-                            cur = min(cur, c - m)
-                            cnt += cur == best
-                            nxt = t + 1
-                    if nxt >= s:
+                        t += 1
+                    else:
+                        if t >= s:
+                            done = True
+                        else:
+                            compare = False  # the window is used up: on with the next sixteen entries
+                    if done:
                         break
-                    i = nxt
+                    i = t
                 assert (x, j + best, k + first, cnt) == tuple(mem), (rd, x, min_len)
                 checked += 1
                 occurrences += s
-    assert checked > 3000
-    print("stages %d, occurrences %d, comparisons with the text %d" % (checked, occurrences, compares))
-    assert compares < 0.6 * occurrences
+                widest = max(widest, s)
+    assert checked > 3000 and widest > (16 if haps > 16 else 4)
+    print("haplotypes %d: stages %d, occurrences %d (widest interval %d), trips %d" % (haps, checked, occurrences, widest, trips))
+    assert trips < 0.6 * occurrences
