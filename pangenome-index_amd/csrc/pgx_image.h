@@ -111,8 +111,9 @@
  *                 t may match further and is compared itself: a forward stage is ~1.7 comparisons instead of one per occurrence (tests/test_lce_math.py).
  *                 Used while (read length - MEM start) <= 253, so that a capped entry is longer than anything asked; PGX_FM_LCP=0: not built.
  * 5.25 n bytes (chr22 scale: 3.4 GB).  The forward stage of find_mems_function (algorithm.hpp:676-700: forward_extend until the interval is "small") over
- * an interval of s <= 16 occurrences is finished by comparing the read with the text at SA[k] .. SA[k + s - 1] -- the occurrences that match longest are
- * consecutive and ARE the interval the extensions would end with -- in s trips of ~1.3 lines instead of (match length) / 2 trips of one line.  The text
+ * an interval of s <= 128 occurrences (16 without lce_lcp) is finished by comparing the read with the text at occurrences of SA[k] .. SA[k + s - 1] -- the
+ * occurrences that match longest are consecutive and ARE the interval the extensions would end with -- in a few trips (one comparison, then sixteen entries of
+ * lce_lcp per trip; a further comparison where two lengths tie) instead of (match length) / 2 trips of one line.  The text
  * is recovered from the index alone: the first symbol of suffix i is the symbol whose C-bucket holds i. */
 /* WIDE variants of DENSE2 and PAIRS (BWTs of 2^32 symbols or more, up to PGX_SB_MAX superblocks; FastLocate is size_t end to end,
  * r-index.hpp:118-130): the same 128-byte blocks, but every count in a block header is a 32-bit DELTA against its superblock --
