@@ -491,6 +491,16 @@ def roofline_record(info, cat_len, n_reads, counts, k_ms, timing, workload_key, 
                     rec["traffic_over_model"] = rec["traffic"] / total_model
         except Exception:
             pass
+    # ... and what the dominant kernel is bound by when it is not the lines: counters of THIS workload's kernel (scripts/r4_final2.sh -> profiles/counters_<workload>.json)
+    cfile = os.path.join(ROOT, "profiles", "counters_%s.json" % workload_key)
+    if os.path.exists(cfile) and not in_lds:
+        try:
+            c = json.load(open(cfile))
+            if int(c.get("bwt_size", -1)) == int(info.bwt_size) and int(c.get("reads", -1)) == int(n_reads) and c.get("kernel_variant") == rec.get("kernel_variant"):
+                rec["lds_valu_utilisation"] = {k: c[k] for k in ("VALUBusy_pct", "valu_instructions_per_launch", "salu_instructions_per_launch", "wave_trips", "valu_per_wave_trip",
+                                                                "lane_trips_per_read", "TA_busy_pct", "source") if k in c}
+        except Exception:
+            pass
     return rec
 
 
