@@ -137,7 +137,10 @@ pgx_status pgx_index_to_device(pgx_index *h, int device);
 pgx_status pgx_index_image_view(const pgx_index *h, int which, const void **ptr, uint64_t *bytes);
 
 /* The DEVICE copy of a view (tests: what the kernels read must be what the host built): which = 0 (rank blocks), 15 (exception runs),
- * 20 (PAIRS blocks), 22 / 23 (superblock bases); copies min(bytes, size of the view) bytes into out. */
+ * 20 (PAIRS blocks), 22 / 23 (superblock bases); copies min(bytes, size of the view) bytes into out.
+ * 30 .. 33: the LCE image, which exists on the device only (pgx_image.h; built by this call if it has not been): suffix array in text
+ * coordinates (u32 x n), text at two bits per symbol, flag bits per 128-byte text line, common prefixes of neighbouring suffixes (u8 x n);
+ * nothing is copied where the index has no such image. */
 pgx_status pgx_index_device_view(pgx_index *h, int device, int which, void *out, uint64_t bytes);
 
 /* ---- index construction (build side; CPU, run once) --------------------------------------- */

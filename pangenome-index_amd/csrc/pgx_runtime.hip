@@ -280,6 +280,7 @@ extern "C" pgx_status pgx_index_to_device(pgx_index *h, int device) {
     PGX_GUARD_END
 }
 
+static void ensure_lce(pgx_index *h, pgx_device_image *d);
 extern "C" pgx_status pgx_index_device_view(pgx_index *h, int device, int which, void *out, uint64_t bytes) {
     PGX_GUARD_BEGIN
     if (!h || !out) throw Error(PGX_ERR_ARG, "pgx_index_device_view: null argument");
@@ -293,6 +294,17 @@ extern "C" pgx_status pgx_index_device_view(pgx_index *h, int device, int which,
     case 20: src = d->pairs.p; have = m.pairs.size(); break;
     case 22: src = d->sbase2.p; have = m.sbase2.size() * 8; break;
     case 23: src = d->pbase.p; have = m.pbase.size() * 8; break;
+    case 30: case 31: case 32: case 33: { // the LCE image (device only; nothing where it does not exist for this index)
+        if (h->has_rank) ensure_lce(h, d);
+        if (d->img.lce_sa) {
+            const uint64_t n = d->img.n, n_words = (n + 15) / 16 + 64;
+            if (which == 30) { src = d->lce_sa.p; have = n * 4; }
+            else if (which == 31) { src = d->lce_text.p; have = n_words * 4; }
+            else if (which == 32) { src = d->lce_flags.p; have = (n_words / 1024 + 2) * 4; }
+            else if (d->img.lce_lcp) { src = d->lce_lcp.p; have = n; }
+        }
+        break;
+    }
     default: throw Error(PGX_ERR_ARG, "pgx_index_device_view: unknown view");
     }
     const uint64_t k = std::min(bytes, have);

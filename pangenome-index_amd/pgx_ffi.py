@@ -315,6 +315,12 @@ class Index:
         _check(self.L.pgx_index_device_view(self.h, device, which, C.c_void_p(out.ctypes.data), u64(host.nbytes)))
         return out.view(host.dtype)
 
+    def lce_view(self, which, nbytes, device=0):
+        """the device's LCE image (which = 30 suffix array, 31 text, 32 line flags, 33 common prefixes) as bytes; zeros where the index has none"""
+        out = np.zeros(int(nbytes), dtype=np.uint8)
+        _check(self.L.pgx_index_device_view(self.h, device, which, C.c_void_p(out.ctypes.data), u64(int(nbytes))))
+        return out
+
     # ---- primitives -------------------------------------------------------------------------
     def rank_batch(self, pos, true_codes=False, device=0):
         pos = np.ascontiguousarray(pos, dtype=np.uint64)
