@@ -1167,6 +1167,9 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
 #ifndef PGX_LCE_ENTRY_CAP
 #define PGX_LCE_ENTRY_CAP 3u // with the common-prefix table a stage through the text is ~2 trips however wide the interval: worth it from 2 x 3 symbols to go
 #endif
+#ifndef PGX_FUSE2
+#define PGX_FUSE2 0 // (1: two first steps per trip -- scripts/r4_exp13.sh: 11 % fewer wave trips, the same time: what a trip saves in number it costs in instructions)
+#endif
 #ifndef PGX_SEED_VIA_LDS
 #define PGX_SEED_VIA_LDS 1 // (0: the entry in registers, loaded by the compiler -- scripts/r4_exp10.sh)
 #endif
@@ -1346,7 +1349,8 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         }
 #endif
         if (FUSE && PGX_SEED_VIA_LDS && __any(ph > 0 && fresh >= 0x100u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the entries asked for at the end of the last trip are in LDS)
-        if (FUSE && ph > 0 && fresh >= 2u) { // the first extension(s) of a stage that started in the last trip: what the stage's first trip does in the other variants
+        // the first extension(s) of a stage whose seed entry has arrived: what the stage's first trip does in the other variants
+        auto prestep = [&]() __attribute__((always_inline)) {
             const uint32_t kuse = fresh >> 8; // extensions the seed entry stands for (0: none was asked for)
             const uint4 se_pre = PGX_SEED_VIA_LDS ? s_sa4[threadIdx.x] : se_reg;
             fresh = 0u;
@@ -1390,6 +1394,36 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             ph = to2 ? 2 : ph;
             j = jn;
             em_now = to2 && jn >= len;
+        };
+        // the stages that have just started (in the refill round, by a restart or behind a MEM): their seed entries are asked for
+        auto prefetch = [&]() __attribute__((always_inline)) {
+            const bool ask = ph > 0 && fresh == 1u;
+            bool asked = false;
+            if (ask) {
+                const bool endw = j >= len; // (the end table: see pgx_find_mems_kernel)
+                const int32_t K = endw ? (int32_t)img.seed_end_k : (int32_t)img.seed_k;
+                const int32_t avail = (ph == 1) ? (j - x + 1) : (j - x);
+                uint32_t kuse = 0u;
+                if (K && avail >= K + (endw ? 1 : 0)) { // the window's 2 K bits of the packed read are the index
+                    const uint32_t q = (uint32_t)(base & 15ull) + (uint32_t)((endw ? len - 1 : j) - K + 1);
+                    const uint32_t w0 = s_rd[(q >> 4) * rd_stride + threadIdx.x], w1 = s_rd[((q >> 4) + 1u) * rd_stride + threadIdx.x]; // (one word of padding per thread)
+                    const uint32_t sidx = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (2u * (q & 15u))) & (uint32_t)((1ull << (2 * K)) - 1ull); // (K = 16: all 32 bits)
+                    const uint4 *sp = (endw ? img.seed_end : img.seed) + sidx;
+                    if (PGX_SEED_VIA_LDS) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)sp, (void __attribute__((address_space(3))) *)(s_sa4 + (threadIdx.x >> 6) * 64u), 16, 0, 0);
+                    else se_reg = *sp;
+                    kuse = (uint32_t)K + (endw ? 1u : 0u);
+                    asked = true;
+                }
+                fresh = 2u | (kuse << 8);
+            }
+            ln_seed += (unsigned long long)__popcll(__ballot(asked));
+        };
+        if (FUSE && ph > 0 && fresh >= 2u) prestep();
+        // (experiment, off: a stage that ENDS in its first step -- a dead seed entry, step 3 behind a seed: 6.8 of a read's 12 lane trips -- starts the next one at
+        //  once and asks for ITS entry now: it arrives with this trip's lines and is applied behind them (second call below) -- two such steps per trip.)
+        if (FUSE && PGX_FUSE2) {
+            if (restart) { begin(); restart = 0u; }
+            prefetch();
         }
         const bool sit_out = FUSE && (fresh != 0u || em_now || restart != 0u); // no line of the image for this lane in this trip
         if (FUSE) ln_blk += (unsigned long long)__popcll(__ballot(ph > 0 && !sit_out));
@@ -1697,6 +1731,8 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
             }
         }
         if (LCE && PGX_LCE_ASM_LOADS) asm volatile("s_waitcnt vmcnt(0)" : "+v"(row), "+v"(hs), "+v"(d0), "+v"(lce_f0), "+v"(lce_f1) :: "memory"); // (the whole wave: the text of section A is in)
+        if (FUSE && PGX_FUSE2 && !PGX_LCE_ASM_LOADS && __any(ph > 0 && fresh >= 0x100u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (FUSE && PGX_FUSE2 && ph > 0 && fresh >= 2u) prestep(); // (the entries asked for in front of this trip's lines are in LDS: see above)
         if (LCE && lce_lane) { // the text behind occurrence i of the interval against the read from symbol j on, then sixteen entries of the table
             const uint32_t rem = (uint32_t)(len - j), i = (lce_st >> 8) & 0xFFu;
             uint32_t a = (lce_st >> 16) & 0xFFu, cnt = lce_st >> 24, t0 = i;
@@ -1769,28 +1805,7 @@ pgx_find_mems_pairs_kernel(PgxDevImage img, const uint8_t *__restrict__ reads, c
         }
         if (em_now) emit();
         if (restart) begin();
-        if (FUSE) { // the stages that have just started (here or in the refill round): their seed entries are on the way while the wave loops
-            const bool ask = ph > 0 && fresh == 1u;
-            bool asked = false;
-            if (ask) {
-                const bool endw = j >= len; // (the end table: see pgx_find_mems_kernel)
-                const int32_t K = endw ? (int32_t)img.seed_end_k : (int32_t)img.seed_k;
-                const int32_t avail = (ph == 1) ? (j - x + 1) : (j - x);
-                uint32_t kuse = 0u;
-                if (K && avail >= K + (endw ? 1 : 0)) { // the window's 2 K bits of the packed read are the index
-                    const uint32_t q = (uint32_t)(base & 15ull) + (uint32_t)((endw ? len - 1 : j) - K + 1);
-                    const uint32_t w0 = s_rd[(q >> 4) * rd_stride + threadIdx.x], w1 = s_rd[((q >> 4) + 1u) * rd_stride + threadIdx.x]; // (one word of padding per thread)
-                    const uint32_t sidx = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (2u * (q & 15u))) & (uint32_t)((1ull << (2 * K)) - 1ull); // (K = 16: all 32 bits)
-                    const uint4 *sp = (endw ? img.seed_end : img.seed) + sidx;
-                    if (PGX_SEED_VIA_LDS) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)sp, (void __attribute__((address_space(3))) *)(s_sa4 + (threadIdx.x >> 6) * 64u), 16, 0, 0);
-                    else se_reg = *sp;
-                    kuse = (uint32_t)K + (endw ? 1u : 0u);
-                    asked = true;
-                }
-                fresh = 2u | (kuse << 8);
-            }
-            ln_seed += (unsigned long long)__popcll(__ballot(asked));
-        }
+        if (FUSE) prefetch(); // (their seed entries are on the way while the wave loops)
     }
     unsigned long long tot = next;
 #pragma unroll
