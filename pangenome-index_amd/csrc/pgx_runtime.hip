@@ -1588,8 +1588,10 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                   record(b, 9, s); fresh_mark = true;
                   if (b->class_ok) {
                     a_skip = b->read_flags.as<uint8_t>();
+                    const char *sse = std::getenv("PGX_FM_SIDE_SERIAL"); // (experiment: the launch in front of the pairs kernel on the same stream, not next to it)
+                    hipStream_t side_stream = (sse && sse[0] == '1') ? s : b->side;
                     HIPCHECK(hipEventRecord(b->ev_side[0], s));
-                    HIPCHECK(hipStreamWaitEvent(b->side, b->ev_side[0], 0));
+                    HIPCHECK(hipStreamWaitEvent(side_stream, b->ev_side[0], 0));
                     const pgx_heavy_item *s_list = b->side_list.as<pgx_heavy_item>();
                     const unsigned long long *s_count = b->side_count.as<unsigned long long>();
                     unsigned long long *s_cur = d_next + PGX_CTR_SIDE_CURSOR;
@@ -1602,9 +1604,12 @@ extern "C" pgx_status pgx_batch_run(pgx_batch *b, uint64_t min_len, uint64_t min
                     // one workgroup per CU next to the pairs kernel while these reads are few (0.4 % of the chr22 workload: 43 k reads, less than one per lane);
                     // with many of them the launch was the longest thing in the step (5 % = 500 k reads, 7.6 per lane one after the other: 21.8 ms next
                     // to a 17 ms pairs kernel): up to four per CU, two reads per lane
-                    const unsigned side_wgs = (unsigned)std::min<uint64_t>(4ull * (uint64_t)cus, std::max<uint64_t>((uint64_t)cus, b->side_reads_est / (2ull * PGX_FM_THREADS) + 1));
-                    HIPCHECK(hipLaunchKernel(kf, dim3(std::min<unsigned>(grid, side_wgs)), dim3(PGX_FM_THREADS), sargs, b->dimg->lds_bytes, b->side));
-                    HIPCHECK(hipEventRecord(b->ev_side[1], b->side));
+                    uint64_t side_min = (uint64_t)cus, side_per_lane = 2;
+                    if (const char *e = std::getenv("PGX_FM_SIDE_WGS_MIN")) side_min = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
+                    if (const char *e = std::getenv("PGX_FM_SIDE_PER_LANE")) side_per_lane = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
+                    const unsigned side_wgs = (unsigned)std::min<uint64_t>(4ull * (uint64_t)cus, std::max<uint64_t>(side_min, b->side_reads_est / (side_per_lane * PGX_FM_THREADS) + 1));
+                    HIPCHECK(hipLaunchKernel(kf, dim3(std::min<unsigned>(grid, side_wgs)), dim3(PGX_FM_THREADS), sargs, b->dimg->lds_bytes, side_stream));
+                    HIPCHECK(hipEventRecord(b->ev_side[1], side_stream));
                     side_running = true;
                   }
                 }
