@@ -1079,13 +1079,17 @@ __device__ __forceinline__ uint32_t pgx_window_byte(uint64_t w0, uint64_t w1, ui
 // probe sat on the 5.8 GB image of the 4.35e9-symbol index (17 G lines/s).
 // S64: the image with a block every 64 positions (pgx_image.h): block b covers [64 b, 64 b + 96), so an interval of up to 32 positions
 // never needs a second block; the second block of one that does overlaps the first by 32 positions and is read from position 32 on.
-// LCE (needs PACKED; narrow images without COOP): the forward stage of a MEM whose interval has become narrow (s <= img.lce_max occurrences) is finished
-// from the suffix array and the text (pgx_image.h "LCE image") instead of two symbols per line: every trip the lane compares what is left of its read with
-// the text behind ONE occurrence of the interval (SA[k + i], three 16-byte loads from one or two lines of the 2-bit text) and keeps the longest match and
-// the occurrences that reach it -- consecutive in suffix order, so they ARE the interval the stepwise extension would end with: MEM end = j + longest
-// match, bwt_start = k + index of the first of them, size = their number; the extensions count as if made one by one (the failing one included).  A MEM over
-// 8 haplotypes costs 9 trips and ~11 lines this way instead of ~33 and 33.  min_occ <= 1 only (the longest match decides); a window that touches a line
-// with an N or an endmarker sends the lane back to the stepwise path for that stage.  Results are bit-identical (tests run both ways).
+// LCE (needs PACKED; narrow images without COOP): the forward stage of a MEM over an interval of s <= img.lce_max occurrences is finished from the suffix array
+// and the text (pgx_image.h "LCE image") instead of two symbols per line.  A trip compares what is left of the read with the text behind ONE occurrence of the
+// interval (SA[k + i], three 16-byte loads from one or two lines of the 2-bit text) and then reads up to sixteen entries of img.lce_lcp, the common prefixes of
+// neighbouring suffixes: occurrence t matches min(match of t - 1, lcp[k + t] - symbols matched before the stage), so an entry above the best match is one more
+// occurrence of the final interval, one below it ends the stage (the matches of sorted suffixes with one pattern rise, stay, fall), one equal to it (or unknown)
+// has occurrence t compared itself in the next trip.  The longest match and the occurrences that reach it -- consecutive in suffix order -- ARE what the stepwise
+// extension would end with: MEM end = j + longest match, bwt_start = k + index of the first of them, size = their number; the extensions count as if made one by
+// one (the failing one included).  ~1.6 trips per stage at 8 haplotypes instead of ~33.  min_occ <= 1 only (the longest match decides); a window that touches a
+// line with an N or an endmarker sends the lane back to the stepwise path for that stage.  Without the table (PGX_FM_LCP=0) every occurrence is compared and only
+// intervals of up to sixteen go this way.  In this variant a stage's first step (seed / first_ext entry) is applied at the top of the trip after the one in which
+// the stage started (FUSE below).  Results are bit-identical (tests run all three ways).
 template <bool SEED, bool WIDE, bool PACKED, bool COOP, bool S64, bool LCE>
 #ifndef PGX_LCE_WAVES
 #define PGX_LCE_WAVES PGX_FM_WAVES_PER_SIMD // (the text path holds its three pieces of text across the trip's body: 110 VGPRs; bounded to 96 it spills 56 bytes per lane: scripts/r4_exp7.sh)
